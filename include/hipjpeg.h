@@ -1,0 +1,127 @@
+/*
+ * hipjpeg.h -- C-ABI of the MI355X-native JPEG hot path (libhipjpeg_ext.so).
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  These are the entry points a host-language binding
+ * (ctypes / cgo / JNI ...) uses, and the same library also exports the nvImageCodec plugin entry symbol
+ * `nvimgcodecExtensionModuleEntry` (include/nvimgcodec_abi.h) through which an unmodified nvImageCodec loads it.
+ *
+ * Each group of functions names the reference interface it replaces (paths relative to /root/reference):
+ *
+ *   hipjpegGetImageInfo          nvjpegJpegStreamParse(Header)       extensions/nvjpeg/cuda_decoder.cpp:503-504,
+ *                                / the framework's JPEG parser       src/parsers/jpeg.cpp:202-361
+ *   hipjpegEntropyDecodeHost     nvjpegDecodeJpegHost                extensions/nvjpeg/cuda_decoder.cpp:527-530
+ *   hipjpegDecodeBatch*          nvjpegDecodeJpegTransferToDevice +  extensions/nvjpeg/cuda_decoder.cpp:544-549
+ *                                nvjpegDecodeJpegDevice               (one batched launch instead of one per image)
+ *   hipjpegEncodeBatch*          nvjpegEncodeImage/RetrieveBitstream extensions/nvjpeg/cuda_encoder.cpp:362-381
+ *
+ * All device pointers are ordinary HIP device allocations; `stream` is a hipStream_t passed as void*.
+ * Every function returns hipjpegStatus_t (0 = success).  The library never falls back to a CPU pixel path:
+ * if no HIP device is usable, the device entry points return HIPJPEG_STATUS_NO_DEVICE.
+ */
+#ifndef HIPJPEG_H_
+#define HIPJPEG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPJPEG_API __attribute__((visibility("default")))
+
+typedef enum {
+    HIPJPEG_STATUS_SUCCESS = 0,
+    HIPJPEG_STATUS_INVALID_ARGUMENT = 1,
+    HIPJPEG_STATUS_BAD_JPEG = 2,         /* not a JPEG or malformed marker segment */
+    HIPJPEG_STATUS_UNSUPPORTED = 3,      /* valid JPEG outside this decoder's scope (arithmetic, 12-bit, CMYK, ...) */
+    HIPJPEG_STATUS_TRUNCATED = 4,        /* entropy-coded data ends early */
+    HIPJPEG_STATUS_CORRUPT = 5,          /* invalid Huffman code / restart marker / coefficient index */
+    HIPJPEG_STATUS_ALLOC_FAILED = 6,
+    HIPJPEG_STATUS_HIP_ERROR = 7,
+    HIPJPEG_STATUS_NO_DEVICE = 8,
+    HIPJPEG_STATUS_BUFFER_TOO_SMALL = 9
+} hipjpegStatus_t;
+
+/* Output pixel layouts; numeric values equal hipjpeg::OutFormat (csrc/device_layout.h). They correspond to
+ * nvimgcodecSampleFormat_t I_RGB, I_BGR, P_RGB, P_BGR, P_Y, P_YUV (type_convert.cpp:19-41 in the reference). */
+typedef enum {
+    HIPJPEG_OUTPUT_RGBI = 0,
+    HIPJPEG_OUTPUT_BGRI = 1,
+    HIPJPEG_OUTPUT_RGB_PLANAR = 2,
+    HIPJPEG_OUTPUT_BGR_PLANAR = 3,
+    HIPJPEG_OUTPUT_Y = 4,
+    HIPJPEG_OUTPUT_YUV_PLANAR = 5
+} hipjpegOutputFormat_t;
+
+typedef enum {
+    HIPJPEG_CSS_444 = 0,
+    HIPJPEG_CSS_422 = 1,
+    HIPJPEG_CSS_420 = 2,
+    HIPJPEG_CSS_440 = 3,
+    HIPJPEG_CSS_411 = 4,
+    HIPJPEG_CSS_410 = 5,
+    HIPJPEG_CSS_GRAY = 6,
+    HIPJPEG_CSS_410V = 7,
+    HIPJPEG_CSS_UNKNOWN = -1
+} hipjpegChromaSubsampling_t;
+
+#define HIPJPEG_FLAG_FANCY_UPSAMPLING 1u /* libjpeg do_fancy_upsampling (plugin option fancy_upsampling, default on) */
+
+typedef struct {
+    int32_t width, height, num_components;
+    int32_t sof_marker;  /* 0xC0 baseline, 0xC1 extended, 0xC2 progressive, other = unsupported type */
+    int32_t color_model; /* 0 gray, 1 YCbCr, 2 RGB, 3 CMYK, 4 YCCK */
+    int32_t subsampling; /* hipjpegChromaSubsampling_t */
+    int32_t restart_interval, num_scans;
+    int32_t h[4], v[4];
+    int32_t blocks_w[4], blocks_h[4]; /* MCU-padded block grid per component */
+    int32_t samp_w[4], samp_h[4];     /* true component size in samples */
+    uint64_t coef_bytes;              /* bytes of int16 coefficient storage for the whole image */
+} hipjpegImageInfo_t;
+
+typedef struct {
+    void* plane[3];     /* device pointers; interleaved formats use plane[0] only */
+    uint32_t pitch[3];  /* bytes per row */
+} hipjpegOutput_t;
+
+typedef struct hipjpegHandle* hipjpegHandle_t;
+
+HIPJPEG_API const char* hipjpegStatusString(hipjpegStatus_t status);
+HIPJPEG_API int hipjpegVersion(void);
+
+/* ---- host-only entry points (usable without a GPU) ---- */
+HIPJPEG_API hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t length, hipjpegImageInfo_t* info);
+
+/* Huffman-decode every scan into quantized coefficient blocks in the device layout (block raster order per
+ * component, 64 int16 per block stored column-major).  comp_offsets[c] receives the int16 offset of component c
+ * inside `coef`; qtables[c*64 .. ] the (column-major) quantisation table of component c. */
+HIPJPEG_API hipjpegStatus_t hipjpegEntropyDecodeHost(const uint8_t* data, size_t length, int16_t* coef, size_t coef_capacity_bytes,
+                                                     uint64_t comp_offsets[4], uint16_t qtables[256]);
+
+/* ---- device pipeline ---- */
+/* num_host_threads: CPU threads for the entropy stage (0 = hardware concurrency). */
+HIPJPEG_API hipjpegStatus_t hipjpegCreate(hipjpegHandle_t* handle, int device_id, int num_host_threads);
+HIPJPEG_API hipjpegStatus_t hipjpegDestroy(hipjpegHandle_t handle);
+
+/* One call = host entropy stage (thread pool) + H2D staging + batched device stage, asynchronous on `stream`
+ * (the call returns after the last kernel is enqueued; per-image host failures are reported in `statuses`). */
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatch(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
+                                               const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags,
+                                               hipjpegStatus_t* statuses, void* stream);
+
+/* The three phases separately (what hipjpegDecodeBatch does internally); used by bench.py to time the device
+ * stage with the coefficient blocks already resident in HBM. */
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
+                                                   const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags,
+                                                   hipjpegStatus_t* statuses);
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchTransfer(hipjpegHandle_t handle, void* stream);
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, void* stream);
+/* Launch statistics of the prepared batch: workgroups per kernel (idct_plane, luma_color, generic). */
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchStats(hipjpegHandle_t handle, int32_t num_units[3], uint64_t* coef_bytes,
+                                                    uint64_t* output_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPJPEG_H_ */

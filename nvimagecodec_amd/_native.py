@@ -1,0 +1,58 @@
+"""ctypes loader for libhipjpeg_ext.so (the HIP extension).  No fallback: if the library is missing the
+import error says how to build it, and every device entry point reports HIPJPEG_STATUS_NO_DEVICE without a GPU."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhipjpeg_ext.so")
+
+STATUS_NAMES = {0: "SUCCESS", 1: "INVALID_ARGUMENT", 2: "BAD_JPEG", 3: "UNSUPPORTED", 4: "TRUNCATED", 5: "CORRUPT", 6: "ALLOC_FAILED",
+                7: "HIP_ERROR", 8: "NO_DEVICE", 9: "BUFFER_TOO_SMALL"}
+
+OUTPUT_RGBI, OUTPUT_BGRI, OUTPUT_RGB_PLANAR, OUTPUT_BGR_PLANAR, OUTPUT_Y, OUTPUT_YUV_PLANAR = range(6)
+FLAG_FANCY_UPSAMPLING = 1
+
+
+class HipJpegError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = int(status)
+        super().__init__(f"{what}: HIPJPEG_STATUS_{STATUS_NAMES.get(self.status, self.status)}")
+
+
+class ImageInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("width", "height", "num_components", "sof_marker", "color_model", "subsampling",
+                                              "restart_interval", "num_scans")] + [
+        ("h", ctypes.c_int32 * 4), ("v", ctypes.c_int32 * 4), ("blocks_w", ctypes.c_int32 * 4), ("blocks_h", ctypes.c_int32 * 4),
+        ("samp_w", ctypes.c_int32 * 4), ("samp_h", ctypes.c_int32 * 4), ("coef_bytes", ctypes.c_uint64)]
+
+
+class Output(ctypes.Structure):
+    _fields_ = [("plane", ctypes.c_void_p * 3), ("pitch", ctypes.c_uint32 * 3)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+                          "or make -C nvimagecodec_amd/csrc)")
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.hipjpegStatusString.restype = ctypes.c_char_p
+    L.hipjpegStatusString.argtypes = [i32]
+    L.hipjpegVersion.restype = i32
+    L.hipjpegGetImageInfo.argtypes = [vp, sz, ctypes.POINTER(ImageInfo)]
+    L.hipjpegEntropyDecodeHost.argtypes = [vp, sz, vp, sz, vp, vp]
+    L.hipjpegCreate.argtypes = [ctypes.POINTER(vp), i32, i32]
+    L.hipjpegDestroy.argtypes = [vp]
+    L.hipjpegDecodeBatch.argtypes = [vp, vp, vp, i32, vp, i32, ctypes.c_uint, vp, vp]
+    L.hipjpegDecodeBatchHost.argtypes = [vp, vp, vp, i32, vp, i32, ctypes.c_uint, vp]
+    L.hipjpegDecodeBatchTransfer.argtypes = [vp, vp]
+    L.hipjpegDecodeBatchDevice.argtypes = [vp, vp]
+    L.hipjpegDecodeBatchStats.argtypes = [vp, vp, vp, vp]
+    _lib = L
+    return L

@@ -1,0 +1,15 @@
+// decode_kernels.h -- host-callable launchers of the decode kernels (implemented in decode_kernels.hip).
+// `stream` is a hipStream_t passed as void* so that plain C++ translation units need no HIP headers.
+#pragma once
+#include "device_layout.h"
+
+namespace hipjpeg {
+
+// K1: IDCT of component blocks into u8 planes.  One WorkUnit = 256 blocks.
+int launch_idct_plane(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+// K2: fused luma IDCT + chroma upsample (factors hs x vs, 0 = no chroma) + colour conversion + store.
+int launch_luma_color(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+// K3: per-pixel colour stage from planes (replication upsampling) for uncommon sampling layouts.
+int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+
+}  // namespace hipjpeg

@@ -1,0 +1,513 @@
+// decode_kernels.hip -- gfx950 kernels of the JPEG decode device stage
+// (what nvjpegDecodeJpegDevice does for the reference: extensions/nvjpeg/cuda_decoder.cpp:546-549).
+//
+// Mapping to the machine (wave64, 256 CUs, 160 KB LDS/CU, no MFMA -- this is integer butterfly + byte work):
+//   * one LANE owns one 8x8 block: both 1-D passes of the ISLOW IDCT run in that lane's registers, so there is
+//     no cross-lane transpose at all and every lane is busy.
+//   * coefficient blocks are fetched from HBM with fully coalesced 16 B/lane loads (a wave reads 8 KB contiguous),
+//     staged through LDS with a 144-byte block stride (bank-conflict-free ds_read_b128), and each lane then pulls
+//     its own 128-byte block out of LDS.  Host code stores blocks column-major so one 16-byte chunk is one IDCT column.
+//   * idct_plane_kernel writes component planes (coalesced 8 B/lane rows); luma_color_kernel fuses the luma IDCT with
+//     chroma upsampling (libjpeg "fancy" triangle filters), YCbCr->RGB and the output store, so the big luma plane and
+//     the RGB image never make an extra HBM round trip.
+//   * work is described by WorkUnit tables so a batch of different-shaped images is ONE launch per kernel.
+//
+// Arithmetic is the integer arithmetic of libjpeg-turbo's jidctint.c / jdsample.c / jdcolor.c, restated; results are
+// compared bit-for-bit with the CPU oracle in tests/.
+#include <hip/hip_runtime.h>
+
+#include "decode_kernels.h"
+#include "device_layout.h"
+
+namespace hipjpeg {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLdsBlockStride = 144;  // 128 B of coefficients + 16 B pad: ds_read_b128 at lane stride 144 B hits 64 distinct banks
+constexpr int kLdsWaveBytes = 64 * kLdsBlockStride;
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+constexpr int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633;
+constexpr int F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
+
+// EXACT=false: 24-bit multiplier (full rate); exact whenever both operands fit in 24 signed bits, which the host
+// guarantees per image (kFlagExactMul32 otherwise) for pass 1 and which always holds in pass 2 (inputs are int32>>11).
+template <bool EXACT>
+__device__ __forceinline__ int mulc(int a, int c)
+{
+    if constexpr (EXACT)
+        return (int)((unsigned)a * (unsigned)c);
+    else
+        return __mul24(a, c);
+}
+
+__device__ __forceinline__ int shl13(int a) { return (int)((unsigned)a << 13); }
+
+// jidctint.c jpeg_idct_islow, one 1-D pass over d[0..7]; the DESCALE rounding term is folded into the even part.
+template <bool EXACT, int SHIFT>
+__device__ __forceinline__ void idct8(int (&d)[8])
+{
+    constexpr int rnd = 1 << (SHIFT - 1);
+    int z2 = d[2], z3 = d[6];
+    int z1 = mulc<EXACT>(z2 + z3, F_0_541);
+    int tmp2 = z1 + mulc<EXACT>(z3, -F_1_847);
+    int tmp3 = z1 + mulc<EXACT>(z2, F_0_765);
+    int tmp0 = shl13(d[0] + d[4]) + rnd;
+    int tmp1 = shl13(d[0] - d[4]) + rnd;
+    int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    int t0 = d[7], t1 = d[5], t2 = d[3], t3 = d[1];
+    z1 = t0 + t3;
+    z2 = t1 + t2;
+    z3 = t0 + t2;
+    int z4 = t1 + t3;
+    int z5 = mulc<EXACT>(z3 + z4, F_1_175);
+    t0 = mulc<EXACT>(t0, F_0_298);
+    t1 = mulc<EXACT>(t1, F_2_053);
+    t2 = mulc<EXACT>(t2, F_3_072);
+    t3 = mulc<EXACT>(t3, F_1_501);
+    z1 = mulc<EXACT>(z1, -F_0_899);
+    z2 = mulc<EXACT>(z2, -F_2_562);
+    z3 = mulc<EXACT>(z3, -F_1_961) + z5;
+    z4 = mulc<EXACT>(z4, -F_0_390) + z5;
+    t0 += z1 + z3;
+    t1 += z2 + z4;
+    t2 += z2 + z3;
+    t3 += z1 + z4;
+    d[0] = (tmp10 + t3) >> SHIFT;
+    d[7] = (tmp10 - t3) >> SHIFT;
+    d[1] = (tmp11 + t2) >> SHIFT;
+    d[6] = (tmp11 - t2) >> SHIFT;
+    d[2] = (tmp12 + t1) >> SHIFT;
+    d[5] = (tmp12 - t1) >> SHIFT;
+    d[3] = (tmp13 + t0) >> SHIFT;
+    d[4] = (tmp13 - t0) >> SHIFT;
+}
+
+// libjpeg's post-IDCT range-limit table (jdmaster.c prepare_range_limit_table) as arithmetic:
+// index = v & 1023 read as a signed 10-bit number, +128, clamped to [0,255].
+__device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }  // v_med3_i32
+
+__device__ __forceinline__ int range_limit(int v)
+{
+    int s = __builtin_amdgcn_sbfe(v, 0, 10);
+    return clamp255(s + 128);
+}
+
+__device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) { return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24); }
+
+// Coalesced HBM -> LDS staging of the 64 blocks a wave owns, then each lane reads back its own block.
+// cols[c] = the 16-byte column chunk c of this lane's block.
+__device__ __forceinline__ void fetch_block(const int16_t* __restrict__ comp_coef, int wave_first_block, int nblocks, char* lds_wave, int lane,
+                                            u32x4 (&cols)[8])
+{
+    const u32x4* src = reinterpret_cast<const u32x4*>(comp_coef) + (size_t)wave_first_block * 8;
+    const int nchunks = min(64, nblocks - wave_first_block) * 8;  // valid 16-byte chunks for this wave (may be <= 0)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int g = k * 64 + lane;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (g < nchunks) v = __builtin_nontemporal_load(src + g);
+        *reinterpret_cast<u32x4*>(lds_wave + (g >> 3) * kLdsBlockStride + (g & 7) * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; c++) cols[c] = *reinterpret_cast<const u32x4*>(lds_wave + lane * kLdsBlockStride + c * 16);
+}
+
+// Dequantize + column pass.  ws[r][c] afterwards holds the pass-1 workspace.
+template <bool EXACT>
+__device__ __forceinline__ void dequant_column_pass(const u32x4 (&cols)[8], const uint16_t* __restrict__ qt, int (&ws)[8][8])
+{
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const unsigned w[4] = {cols[c].x, cols[c].y, cols[c].z, cols[c].w};
+        int d[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int lo = (int)(short)(w[i] & 0xFFFF);
+            int hi = (int)w[i] >> 16;
+            // coefficient (int16) x quantizer (<= 16 bit): always exact in the 24-bit multiplier
+            d[2 * i] = __mul24(lo, (int)qt[c * 8 + 2 * i]);
+            d[2 * i + 1] = __mul24(hi, (int)qt[c * 8 + 2 * i + 1]);
+        }
+        idct8<EXACT, 11>(d);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ws[r][c] = d[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: IDCT of 256 consecutive blocks of one component into a u8 plane (internal plane or user output).
+// ------------------------------------------------------------------------------------------------
+template <bool EXACT>
+__device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const WorkUnit& u, char* lds)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int comp = u.comp;
+    const int bw = im.blocks_w[comp], nblocks = bw * im.blocks_h[comp];
+    const int wave_first = u.block_base + wave * 64;
+    u32x4 cols[8];
+    fetch_block(im.coef[comp], wave_first, nblocks, lds + wave * kLdsWaveBytes, lane, cols);
+    const int b = wave_first + lane;
+    if (b >= nblocks) return;
+    int ws[8][8];
+    dequant_column_pass<EXACT>(cols, im.qt[comp], ws);
+
+    const int by = b / bw, bx = b - by * bw;
+    const bool to_out = (u.mode & 0xFF) == kToOutput;
+    const int op = u.mode >> 8;
+    uint8_t* dst = to_out ? im.out[op] : im.plane[comp];
+    const unsigned pitch = to_out ? im.out_pitch[op] : im.plane_pitch[comp];
+    // kToPlane: every allocated block is written; kToOutput: crop to the true component size
+    const int lim_w = to_out ? im.samp_w[comp] : bw * 8;
+    const int lim_h = to_out ? im.samp_h[comp] : im.blocks_h[comp] * 8;
+    const int x0 = bx * 8, y0 = by * 8;
+    if (x0 >= lim_w) return;
+    uint8_t* p = dst + (size_t)y0 * pitch + x0;
+    const bool fast = (x0 + 8 <= lim_w) && (((uintptr_t)p | pitch) & 7) == 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int d[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) d[c] = ws[r][c];
+        idct8<false, 18>(d);
+        if (y0 + r < lim_h) {
+            int px[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) px[c] = range_limit(d[c]);
+            uint8_t* q = p + (size_t)r * pitch;
+            if (fast) {
+                *reinterpret_cast<uint2*>(q) = make_uint2(pack4(px[0], px[1], px[2], px[3]), pack4(px[4], px[5], px[6], px[7]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if (x0 + c < lim_w) q[c] = (uint8_t)px[c];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void idct_plane_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
+{
+    __shared__ __attribute__((aligned(16))) char lds[4 * kLdsWaveBytes];
+    const WorkUnit u = units[blockIdx.x];
+    const DecodeImage& im = images[u.image];
+    if (im.flags & kFlagExactMul32)
+        idct_plane_body<true>(im, u, lds);
+    else
+        idct_plane_body<false>(im, u, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: luma IDCT fused with chroma upsampling, colour conversion and the output store.
+//   HS, VS = chroma upsampling factors (1 or 2); HS == 0 means "no chroma" (gray source -> RGB).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int byte_of(unsigned long long v, int j) { return (int)((v >> (8 * j)) & 0xFF); }
+
+// Loads the chroma window rows this lane needs.  After the call, byte j of rows[i] is the sample at
+// (clamp(wy + i, 0, dh-1), clamp(wx + j, 0, dw-1)) -- i.e. libjpeg's edge replication is already applied.
+template <int NR, int NW>
+__device__ __forceinline__ void load_chroma_window(const uint8_t* __restrict__ plane, unsigned pitch, int dw, int dh, int wx, int wy,
+                                                   unsigned long long (&rows)[NR])
+{
+    const int base = max(wx, 0);
+    const bool edge = (wx < 0) || (wx + NW - 1 > dw - 1);
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        int y = min(max(wy + i, 0), dh - 1);
+        const uint8_t* p = plane + (size_t)y * pitch + base;
+        // planes are allocated with >= 16 bytes of slack per row, so an 8-byte read starting inside the row is in bounds
+        unsigned long long v;
+        __builtin_memcpy(&v, p, 8);
+        rows[i] = v;
+    }
+    if (__builtin_amdgcn_ballot_w64(edge) != 0) {
+        if (edge) {
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                unsigned long long v = rows[i], f = 0;
+#pragma unroll
+                for (int j = 0; j < NW; j++) {
+                    int idx = min(max(wx + j, 0), dw - 1) - base;
+                    f |= ((v >> (8 * idx)) & 0xFFull) << (8 * j);
+                }
+                rows[i] = f;
+            }
+        }
+    }
+}
+
+// Upsampled chroma for one output row of the lane's 8 pixels.
+template <int HS, int VS>
+__device__ __forceinline__ void upsample_row(unsigned long long near, unsigned long long far, int r, bool fancy, int (&o)[8])
+{
+    if constexpr (HS == 2) {
+        // window byte j <-> chroma column (4*bx - 1 + j); output pixel 2i+e sits over window column i+1
+        if (fancy) {
+            int cs[6];
+            if constexpr (VS == 2) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) cs[j] = 3 * byte_of(near, j) + byte_of(far, j);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    o[2 * i] = (3 * cs[i + 1] + cs[i] + 8) >> 4;
+                    o[2 * i + 1] = (3 * cs[i + 1] + cs[i + 2] + 7) >> 4;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) cs[j] = byte_of(near, j);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    o[2 * i] = (3 * cs[i + 1] + cs[i] + 1) >> 2;
+                    o[2 * i + 1] = (3 * cs[i + 1] + cs[i + 2] + 2) >> 2;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[2 * i] = o[2 * i + 1] = byte_of(near, i + 1);
+        }
+    } else {
+        if (VS == 2 && fancy) {
+            const int bias = (r & 1) ? 2 : 1;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (3 * byte_of(near, j) + byte_of(far, j) + bias) >> 2;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = byte_of(near, j);
+        }
+    }
+}
+
+template <bool EXACT, int HS, int VS>
+__device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bw = im.blocks_w[0], nblocks = bw * im.blocks_h[0];
+    const int wave_first = u.block_base + wave * 64;
+    u32x4 cols[8];
+    fetch_block(im.coef[0], wave_first, nblocks, lds + wave * kLdsWaveBytes, lane, cols);
+    const int b = wave_first + lane;
+    if (b >= nblocks) return;
+    const int by = b / bw, bx = b - by * bw;
+    const int x0 = bx * 8, y0 = by * 8;
+    const int W = im.width, H = im.height;
+    if (x0 >= W || y0 >= H) return;  // block entirely inside MCU padding
+
+    // chroma window (issued before the IDCT so the loads fly while we compute)
+    constexpr int NW = HS == 2 ? 6 : 8;
+    constexpr int NR = (HS == 0) ? 1 : (VS == 2 ? 6 : 8);
+    unsigned long long cbw[NR], crw[NR];
+    bool fancy = false;
+    if constexpr (HS != 0) {
+        const int dw = im.samp_w[1], dh = im.samp_h[1];
+        // libjpeg picks the triangle filters only when do_fancy_upsampling and (for h2v1/h2v2) downsampled_width > 2
+        fancy = (im.flags & kFlagFancyUpsampling) && (HS == 1 || dw > 2);
+        const int wx = HS == 2 ? 4 * bx - 1 : 8 * bx;
+        const int wy = VS == 2 ? 4 * by - 1 : 8 * by;
+        load_chroma_window<NR, NW>(im.plane[1], im.plane_pitch[1], dw, dh, wx, wy, cbw);
+        load_chroma_window<NR, NW>(im.plane[2], im.plane_pitch[2], dw, dh, wx, wy, crw);
+    }
+
+    int ws[8][8];
+    dequant_column_pass<EXACT>(cols, im.qt[0], ws);
+
+    const int fmt = im.out_format;
+    const bool planar = fmt == kOutPlanarRGB || fmt == kOutPlanarBGR;
+    const bool bgr = fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR;
+    const bool ycc = im.color_model == 1;
+    const bool full = x0 + 8 <= W;
+
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int d[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) d[c] = ws[r][c];
+        idct8<false, 18>(d);
+        if (y0 + r >= H) continue;
+        int R[8], G[8], B[8];
+        if constexpr (HS == 0) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) R[c] = G[c] = B[c] = range_limit(d[c]);
+        } else {
+            int cb[8], cr[8];
+            int near, far;
+            if constexpr (VS == 2) {
+                near = 1 + (r >> 1);
+                far = (r & 1) ? near + 1 : near - 1;
+            } else {
+                near = far = r;
+            }
+            upsample_row<HS, VS>(cbw[near], cbw[far], r, fancy, cb);
+            upsample_row<HS, VS>(crw[near], crw[far], r, fancy, cr);
+            if (ycc) {
+                // jdcolor.c ycc_rgb_convert with SCALEBITS = 16; (x - 128) folded into the additive constants
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    int y = range_limit(d[c]);
+                    int rr = (__mul24(cr[c], 91881) + (32768 - 128 * 91881)) >> 16;
+                    int bb = (__mul24(cb[c], 116130) + (32768 - 128 * 116130)) >> 16;
+                    int gg = (__mul24(cb[c], -22554) + __mul24(cr[c], -46802) + (32768 + 128 * 22554 + 128 * 46802)) >> 16;
+                    R[c] = clamp255(y + rr);
+                    G[c] = clamp255(y + gg);
+                    B[c] = clamp255(y + bb);
+                }
+            } else {
+                // Adobe RGB JPEG: the three components already are R, G, B
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    R[c] = range_limit(d[c]);
+                    G[c] = cb[c];
+                    B[c] = cr[c];
+                }
+            }
+        }
+        if (bgr) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                int t = R[c];
+                R[c] = B[c];
+                B[c] = t;
+            }
+        }
+        const int y = y0 + r;
+        if (planar) {
+            uint8_t* p0 = im.out[0] + (size_t)y * im.out_pitch[0] + x0;
+            uint8_t* p1 = im.out[1] + (size_t)y * im.out_pitch[1] + x0;
+            uint8_t* p2 = im.out[2] + (size_t)y * im.out_pitch[2] + x0;
+            if (full && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 7) == 0) {
+                *reinterpret_cast<uint2*>(p0) = make_uint2(pack4(R[0], R[1], R[2], R[3]), pack4(R[4], R[5], R[6], R[7]));
+                *reinterpret_cast<uint2*>(p1) = make_uint2(pack4(G[0], G[1], G[2], G[3]), pack4(G[4], G[5], G[6], G[7]));
+                *reinterpret_cast<uint2*>(p2) = make_uint2(pack4(B[0], B[1], B[2], B[3]), pack4(B[4], B[5], B[6], B[7]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if (x0 + c < W) {
+                        p0[c] = (uint8_t)R[c];
+                        p1[c] = (uint8_t)G[c];
+                        p2[c] = (uint8_t)B[c];
+                    }
+            }
+        } else {
+            uint8_t* p = im.out[0] + (size_t)y * im.out_pitch[0] + (size_t)x0 * 3;
+            if (full && ((uintptr_t)p & 7) == 0) {
+                uint2* q = reinterpret_cast<uint2*>(p);
+                q[0] = make_uint2(pack4(R[0], G[0], B[0], R[1]), pack4(G[1], B[1], R[2], G[2]));
+                q[1] = make_uint2(pack4(B[2], R[3], G[3], B[3]), pack4(R[4], G[4], B[4], R[5]));
+                q[2] = make_uint2(pack4(G[5], B[5], R[6], G[6]), pack4(B[6], R[7], G[7], B[7]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if (x0 + c < W) {
+                        p[3 * c] = (uint8_t)R[c];
+                        p[3 * c + 1] = (uint8_t)G[c];
+                        p[3 * c + 2] = (uint8_t)B[c];
+                    }
+            }
+        }
+    }
+}
+
+template <int HS, int VS>
+__global__ __launch_bounds__(kThreads) void luma_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
+{
+    __shared__ __attribute__((aligned(16))) char lds[4 * kLdsWaveBytes];
+    const WorkUnit u = units[blockIdx.x];
+    const DecodeImage& im = images[u.image];
+    if (im.flags & kFlagExactMul32)
+        luma_color_body<true, HS, VS>(im, u, lds);
+    else
+        luma_color_body<false, HS, VS>(im, u, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: generic colour stage for layouts the fused kernel does not cover (4:1:1, 4:1:0, ...): every component is in a
+// plane already; libjpeg upsamples those by plain replication (jdsample.c int_upsample).  One thread = one pixel.
+// mode 0 of the unit table is reused: block_base = first pixel row, comp unused.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void generic_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
+{
+    const WorkUnit u = units[blockIdx.x];
+    const DecodeImage& im = images[u.image];
+    const int W = im.width, H = im.height;
+    const int y = u.block_base;
+    if (y >= H) return;
+    const int fmt = im.out_format;
+    const bool planar = fmt == kOutPlanarRGB || fmt == kOutPlanarBGR;
+    const bool bgr = fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR;
+    for (int x = threadIdx.x; x < W; x += kThreads) {
+        int s[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int cc = im.ncomp == 1 ? 0 : c;
+            int sx = x * im.h[cc] / im.hmax, sy = y * im.v[cc] / im.vmax;
+            s[c] = im.plane[cc][(size_t)sy * im.plane_pitch[cc] + sx];
+        }
+        int R, G, B;
+        if (im.color_model == 1) {
+            int rr = (s[2] * 91881 + (32768 - 128 * 91881)) >> 16;
+            int bb = (s[1] * 116130 + (32768 - 128 * 116130)) >> 16;
+            int gg = (s[1] * -22554 + s[2] * -46802 + (32768 + 128 * 22554 + 128 * 46802)) >> 16;
+            R = min(max(s[0] + rr, 0), 255);
+            G = min(max(s[0] + gg, 0), 255);
+            B = min(max(s[0] + bb, 0), 255);
+        } else {
+            R = s[0];
+            G = s[1];
+            B = s[2];
+        }
+        if (bgr) {
+            int t = R;
+            R = B;
+            B = t;
+        }
+        if (planar) {
+            im.out[0][(size_t)y * im.out_pitch[0] + x] = (uint8_t)R;
+            im.out[1][(size_t)y * im.out_pitch[1] + x] = (uint8_t)G;
+            im.out[2][(size_t)y * im.out_pitch[2] + x] = (uint8_t)B;
+        } else {
+            uint8_t* p = im.out[0] + (size_t)y * im.out_pitch[0] + (size_t)x * 3;
+            p[0] = (uint8_t)R;
+            p[1] = (uint8_t)G;
+            p[2] = (uint8_t)B;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_idct_plane(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    hipLaunchKernelGGL(idct_plane_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    return (int)hipGetLastError();
+}
+
+int launch_luma_color(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (hs == 0)
+        hipLaunchKernelGGL((luma_color_kernel<0, 0>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+    else if (hs == 1 && vs == 1)
+        hipLaunchKernelGGL((luma_color_kernel<1, 1>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+    else if (hs == 2 && vs == 1)
+        hipLaunchKernelGGL((luma_color_kernel<2, 1>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+    else if (hs == 2 && vs == 2)
+        hipLaunchKernelGGL((luma_color_kernel<2, 2>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+    else if (hs == 1 && vs == 2)
+        hipLaunchKernelGGL((luma_color_kernel<1, 2>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+    else
+        return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    hipLaunchKernelGGL(generic_color_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    return (int)hipGetLastError();
+}
+
+}  // namespace hipjpeg

@@ -1,0 +1,361 @@
+// decoder_core.cpp -- see decoder_core.h
+#include "decoder_core.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "decode_kernels.h"
+#include "entropy_decode.h"
+
+namespace hipjpeg {
+
+namespace {
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+hipjpegStatus_t status_from_parse(ParseStatus s)
+{
+    switch (s) {
+    case kParseOk: return HIPJPEG_STATUS_SUCCESS;
+    case kParseUnsupported: return HIPJPEG_STATUS_UNSUPPORTED;
+    case kParseTruncated: return HIPJPEG_STATUS_TRUNCATED;
+    default: return HIPJPEG_STATUS_BAD_JPEG;
+    }
+}
+
+// Same classification the framework's parser applies (reference src/parsers/jpeg.cpp:70-114).
+hipjpegChromaSubsampling_t classify_subsampling(const FrameInfo& f)
+{
+    if (f.ncomp == 1) return HIPJPEG_CSS_GRAY;
+    if (f.ncomp != 3) return HIPJPEG_CSS_UNKNOWN;
+    int yh = f.comp[0].h, yv = f.comp[0].v, uh = f.comp[1].h, uv = f.comp[1].v, vh = f.comp[2].h, vv = f.comp[2].v;
+    int minh = std::min(yh, std::min(uh, vh)), minv = std::min(yv, std::min(uv, vv));
+    if (minh == 0 || minv == 0) return HIPJPEG_CSS_UNKNOWN;
+    if (yh % minh || uh % minh || vh % minh || yv % minv || uv % minv || vv % minv) return HIPJPEG_CSS_UNKNOWN;
+    yh /= minh; uh /= minh; vh /= minh;
+    yv /= minv; uv /= minv; vv /= minv;
+    if (uh != vh || uv != vv || uh != 1 || uv != 1) return HIPJPEG_CSS_UNKNOWN;
+    if (yh == 1 && yv == 1) return HIPJPEG_CSS_444;
+    if (yh == 2 && yv == 1) return HIPJPEG_CSS_422;
+    if (yh == 2 && yv == 2) return HIPJPEG_CSS_420;
+    if (yh == 1 && yv == 2) return HIPJPEG_CSS_440;
+    if (yh == 4 && yv == 1) return HIPJPEG_CSS_411;
+    if (yh == 4 && yv == 2) return HIPJPEG_CSS_410;
+    if (yh == 2 && yv == 4) return HIPJPEG_CSS_410V;
+    return HIPJPEG_CSS_UNKNOWN;
+}
+
+// ---------------------------------------------------------------- Buffer
+hipjpegStatus_t Buffer::reserve(size_t bytes)
+{
+    if (bytes <= cap_) return HIPJPEG_STATUS_SUCCESS;
+    release();
+    size_t want = align_up(bytes + bytes / 8, 1 << 20);  // headroom so a slightly bigger next batch does not reallocate
+    void* p = nullptr;
+    if (kind_ == kDevice && hooks_ && hooks_->device_malloc) {
+        if (hooks_->device_malloc(hooks_->device_ctx, &p, want, nullptr) != 0 || !p) return HIPJPEG_STATUS_ALLOC_FAILED;
+        custom_ = true;
+    } else if (kind_ == kPinned && hooks_ && hooks_->pinned_malloc) {
+        if (hooks_->pinned_malloc(hooks_->pinned_ctx, &p, want, nullptr) != 0 || !p) return HIPJPEG_STATUS_ALLOC_FAILED;
+        custom_ = true;
+    } else {
+        hipError_t e = kind_ == kDevice ? hipMalloc(&p, want) : hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) return HIPJPEG_STATUS_ALLOC_FAILED;
+        custom_ = false;
+    }
+    ptr_ = static_cast<uint8_t*>(p);
+    cap_ = want;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+void Buffer::release()
+{
+    if (!ptr_) return;
+    if (custom_) {
+        if (kind_ == kDevice)
+            hooks_->device_free(hooks_->device_ctx, ptr_, cap_, nullptr);
+        else
+            hooks_->pinned_free(hooks_->pinned_ctx, ptr_, cap_, nullptr);
+    } else if (kind_ == kDevice) {
+        (void)hipFree(ptr_);
+    } else {
+        (void)hipHostFree(ptr_);
+    }
+    ptr_ = nullptr;
+    cap_ = 0;
+}
+
+// ---------------------------------------------------------------- DecodeBatch
+DecodeBatch::DecodeBatch(int device_id, const MemoryHooks* hooks)
+    : device_id_(device_id), hooks_(hooks), pinned_(Buffer::kPinned, hooks), device_(Buffer::kDevice, hooks), planes_(Buffer::kDevice, hooks)
+{
+}
+
+DecodeBatch::~DecodeBatch()
+{
+    if (done_event_) {
+        if (in_flight_) (void)hipEventSynchronize((hipEvent_t)done_event_);
+        (void)hipEventDestroy((hipEvent_t)done_event_);
+    }
+}
+
+namespace {
+
+// Decide which kernels handle this frame.  Returns false when the layout is outside the decoder's scope.
+bool choose_variant(const FrameInfo& f, OutFormat fmt, bool fancy, int* variant)
+{
+    if (f.color == ColorModel::CMYK || f.color == ColorModel::YCCK) return false;
+    if (f.ncomp != 1 && f.ncomp != 3) return false;
+    for (int c = 0; c < f.ncomp; c++)
+        if (f.hmax % f.comp[c].h || f.vmax % f.comp[c].v) return false;  // fractional upsampling: libjpeg refuses too
+    if (fmt == kOutPlanarYUV) {
+        *variant = -2;
+        return true;
+    }
+    if (fmt == kOutY) {
+        // libjpeg JCS_GRAYSCALE from YCbCr/gray = the luma plane; from an RGB-model JPEG it is a weighted sum (not done here)
+        if (f.color == ColorModel::RGB) return false;
+        if (f.comp[0].h != f.hmax || f.comp[0].v != f.vmax) return false;
+        *variant = -2;
+        return true;
+    }
+    if (f.ncomp == 1) {
+        *variant = kVarGray;
+        return true;
+    }
+    const int fx1 = f.hmax / f.comp[1].h, fy1 = f.vmax / f.comp[1].v, fx2 = f.hmax / f.comp[2].h, fy2 = f.vmax / f.comp[2].v;
+    const bool luma_full = f.comp[0].h == f.hmax && f.comp[0].v == f.vmax;
+    if (luma_full && fx1 == fx2 && fy1 == fy2 && fx1 <= 2 && fy1 <= 2) {
+        *variant = fx1 == 1 ? (fy1 == 1 ? kVar11 : kVar12) : (fy1 == 1 ? kVar21 : kVar22);
+        return true;
+    }
+    // Generic path = replication only.  Make sure libjpeg would replicate as well (jdsample.c jinit_upsampler).
+    for (int c = 0; c < f.ncomp; c++) {
+        int fx = f.hmax / f.comp[c].h, fy = f.vmax / f.comp[c].v;
+        bool triangle = fancy && ((fx == 2 && fy == 1 && f.comp[c].samp_w > 2) || (fx == 2 && fy == 2 && f.comp[c].samp_w > 2) ||
+                                  (fx == 1 && fy == 2));
+        if (triangle) return false;
+    }
+    *variant = -1;
+    return true;
+}
+
+}  // namespace
+
+hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
+                                  hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses)
+{
+    if (n < 0 || (n > 0 && (!data || !lengths || !outputs))) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if ((int)format < 0 || (int)format > (int)HIPJPEG_OUTPUT_YUV_PLANAR) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    finalized_ = false;
+    images_.assign(n, PlannedImage());
+    desc_.assign(n, DecodeImage());
+    const OutFormat fmt = (OutFormat)format;
+    const bool fancy = (flags & HIPJPEG_FLAG_FANCY_UPSAMPLING) != 0;
+
+    size_t max_units = 0, coef_total = 0, plane_total = 0;
+    std::vector<size_t> plane_off((size_t)n * 4, (size_t)-1);
+    coef_bytes_ = output_bytes_ = 0;
+    for (int i = 0; i < n; i++) {
+        PlannedImage& im = images_[i];
+        im.data = data[i];
+        im.size = lengths[i];
+        im.status = status_from_parse(parse_jpeg(data[i], lengths[i], &im.frame));
+        if (im.status == HIPJPEG_STATUS_SUCCESS && !choose_variant(im.frame, fmt, fancy, &im.variant)) im.status = HIPJPEG_STATUS_UNSUPPORTED;
+        const FrameInfo& f = im.frame;
+        const int nplanes_out = (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR || fmt == kOutY) ? 1 : 3;
+        if (im.status == HIPJPEG_STATUS_SUCCESS) {
+            for (int p = 0; p < (fmt == kOutPlanarYUV ? f.ncomp : nplanes_out); p++)
+                if (!outputs[i].plane[p]) im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
+        }
+        if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
+
+        DecodeImage& d = desc_[i];
+        memset(&d, 0, sizeof d);
+        d.width = (uint16_t)f.width;
+        d.height = (uint16_t)f.height;
+        d.ncomp = (uint8_t)f.ncomp;
+        d.hmax = (uint8_t)f.hmax;
+        d.vmax = (uint8_t)f.vmax;
+        d.color_model = (uint8_t)f.color;
+        d.out_format = (uint8_t)fmt;
+        d.flags = fancy ? kFlagFancyUpsampling : 0;
+        for (int p = 0; p < 3; p++) {
+            d.out[p] = static_cast<uint8_t*>(outputs[i].plane[p]);
+            d.out_pitch[p] = outputs[i].pitch[p];
+        }
+        for (int c = 0; c < f.ncomp; c++) {
+            const Component& k = f.comp[c];
+            d.blocks_w[c] = (uint16_t)k.blocks_w;
+            d.blocks_h[c] = (uint16_t)k.blocks_h;
+            d.samp_w[c] = (uint16_t)k.samp_w;
+            d.samp_h[c] = (uint16_t)k.samp_h;
+            d.h[c] = (uint8_t)k.h;
+            d.v[c] = (uint8_t)k.v;
+            for (int j = 0; j < 64; j++) d.qt[c][(j & 7) * 8 + (j >> 3)] = f.qtab[c][j];  // natural -> column-major
+            const size_t nblk = (size_t)k.blocks_w * k.blocks_h;
+            im.coef_offset[c] = coef_total;
+            coef_total += nblk * 128;
+            const size_t units = (nblk + kBlocksPerUnit - 1) / kBlocksPerUnit;
+            // which components go through an intermediate plane
+            bool needs_plane = (im.variant == -1) || (im.variant >= kVar11 && c > 0);
+            bool to_output = (im.variant == -2) && (fmt == kOutPlanarYUV || c == 0);
+            if (needs_plane) {
+                d.plane_pitch[c] = (uint32_t)align_up((size_t)k.blocks_w * 8 + 16, 16);
+                plane_off[(size_t)i * 4 + c] = plane_total;
+                plane_total += align_up((size_t)d.plane_pitch[c] * k.blocks_h * 8 + 16, 256);
+            }
+            if (needs_plane || to_output) max_units += units;
+            if (c == 0 && im.variant >= 0) max_units += units;
+        }
+        if (im.variant == -1) max_units += (size_t)f.height;
+        coef_bytes_ += f.total_blocks() * 128;
+        if (fmt == kOutPlanarYUV) {
+            for (int c = 0; c < f.ncomp; c++) output_bytes_ += (uint64_t)f.comp[c].samp_w * f.comp[c].samp_h;
+        } else {
+            output_bytes_ += (uint64_t)f.width * f.height * (fmt == kOutY ? 1 : 3);
+        }
+    }
+
+    desc_offset_ = 0;
+    units_offset_ = align_up(desc_offset_ + sizeof(DecodeImage) * (size_t)n, 256);
+    coef_offset_ = align_up(units_offset_ + sizeof(WorkUnit) * max_units, 256);
+    staging_bytes_ = coef_offset_ + coef_total;
+    plane_bytes_ = plane_total;
+
+    if (hipSetDevice(device_id_) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
+    // the previous use of these buffers (H2D copy + kernels) must have drained before they are rewritten
+    if (in_flight_) {
+        if (hipEventSynchronize((hipEvent_t)done_event_) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        in_flight_ = false;
+    }
+    hipjpegStatus_t st;
+    if ((st = pinned_.reserve(staging_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    if ((st = device_.reserve(staging_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    if ((st = planes_.reserve(plane_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+
+    for (int i = 0; i < n; i++) {
+        if (images_[i].status != HIPJPEG_STATUS_SUCCESS) continue;
+        DecodeImage& d = desc_[i];
+        for (int c = 0; c < images_[i].frame.ncomp; c++) {
+            images_[i].coef_offset[c] += coef_offset_;
+            d.coef[c] = reinterpret_cast<const int16_t*>(device_.data() + images_[i].coef_offset[c]);
+            if (plane_off[(size_t)i * 4 + c] != (size_t)-1) d.plane[c] = planes_.data() + plane_off[(size_t)i * 4 + c];
+        }
+    }
+    if (statuses)
+        for (int i = 0; i < n; i++) statuses[i] = images_[i].status;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+void DecodeBatch::entropy_stage(int i)
+{
+    PlannedImage& im = images_[i];
+    if (im.status != HIPJPEG_STATUS_SUCCESS) return;
+    int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int c = 0; c < im.frame.ncomp; c++) coef[c] = reinterpret_cast<int16_t*>(pinned_.data() + im.coef_offset[c]);
+    EntropyStatus es = decode_coefficients(im.data, im.size, im.frame, coef, im.coef_or);
+    switch (es) {
+    case kEntropyOk: break;
+    case kEntropyTruncated: im.status = HIPJPEG_STATUS_TRUNCATED; break;
+    case kEntropyMissingTable: im.status = HIPJPEG_STATUS_BAD_JPEG; break;
+    default: im.status = HIPJPEG_STATUS_CORRUPT; break;
+    }
+}
+
+void DecodeBatch::finalize(hipjpegStatus_t* statuses)
+{
+    plane_units_.clear();
+    generic_units_.clear();
+    for (auto& v : luma_units_) v.clear();
+    const int n = (int)images_.size();
+    for (int i = 0; i < n; i++) {
+        PlannedImage& im = images_[i];
+        if (statuses) statuses[i] = im.status;
+        if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
+        const FrameInfo& f = im.frame;
+        DecodeImage& d = desc_[i];
+        // 24-bit multipliers in IDCT pass 1 need every dequantized value (and sums of four of them) inside 24 signed bits
+        bool exact32 = false;
+        for (int c = 0; c < f.ncomp; c++) {
+            uint32_t maxq = 0;
+            for (int j = 0; j < 64; j++) maxq = std::max<uint32_t>(maxq, f.qtab[c][j]);
+            if ((uint64_t)im.coef_or[c] * maxq >= (1u << 21)) exact32 = true;
+        }
+        if (exact32) d.flags |= kFlagExactMul32;
+        const OutFormat fmt = (OutFormat)d.out_format;
+        for (int c = 0; c < f.ncomp; c++) {
+            const uint32_t nblk = (uint32_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+            bool needs_plane = (im.variant == -1) || (im.variant >= kVar11 && c > 0);
+            bool to_output = (im.variant == -2) && (fmt == kOutPlanarYUV || c == 0);
+            if (needs_plane || to_output) {
+                uint32_t mode = to_output ? (uint32_t)(kToOutput | (c << 8)) : (uint32_t)kToPlane;
+                for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) plane_units_.push_back(WorkUnit{(uint32_t)i, b, (uint32_t)c, mode});
+            }
+        }
+        if (im.variant >= 0) {
+            const uint32_t nblk = (uint32_t)f.comp[0].blocks_w * f.comp[0].blocks_h;
+            for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) luma_units_[im.variant].push_back(WorkUnit{(uint32_t)i, b, 0u, 0u});
+        } else if (im.variant == -1) {
+            for (int y = 0; y < f.height; y++) generic_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});
+        }
+    }
+    // write descriptors + unit tables into the staging area
+    uint8_t* base = pinned_.data();
+    if (n) memcpy(base + desc_offset_, desc_.data(), sizeof(DecodeImage) * (size_t)n);
+    size_t off = units_offset_;
+    auto put = [&](const std::vector<WorkUnit>& v, size_t* where) {
+        *where = off;
+        if (!v.empty()) memcpy(base + off, v.data(), v.size() * sizeof(WorkUnit));
+        off += v.size() * sizeof(WorkUnit);
+    };
+    put(plane_units_, &unit_off_plane_);
+    for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[k], &unit_off_luma_[k]);
+    put(generic_units_, &unit_off_generic_);
+    finalized_ = true;
+}
+
+hipjpegStatus_t DecodeBatch::transfer(void* stream)
+{
+    if (!finalized_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if (staging_bytes_ == 0) return HIPJPEG_STATUS_SUCCESS;
+    hipError_t e = hipMemcpyAsync(device_.data(), pinned_.data(), staging_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? HIPJPEG_STATUS_SUCCESS : HIPJPEG_STATUS_HIP_ERROR;
+}
+
+hipjpegStatus_t DecodeBatch::launch(void* stream)
+{
+    if (!finalized_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    const DecodeImage* dimg = reinterpret_cast<const DecodeImage*>(device_.data() + desc_offset_);
+    auto units_at = [&](size_t off) { return reinterpret_cast<const WorkUnit*>(device_.data() + off); };
+    static const int hs[kNumLumaVariants] = {0, 1, 2, 2, 1}, vs[kNumLumaVariants] = {0, 1, 1, 2, 2};
+    int rc = launch_idct_plane(dimg, units_at(unit_off_plane_), (int)plane_units_.size(), stream);
+    for (int k = 0; k < kNumLumaVariants && rc == 0; k++)
+        rc = launch_luma_color(hs[k], vs[k], dimg, units_at(unit_off_luma_[k]), (int)luma_units_[k].size(), stream);
+    if (rc == 0) rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
+    if (rc != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (!done_event_) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        done_event_ = ev;
+    }
+    if (hipEventRecord((hipEvent_t)done_event_, (hipStream_t)stream) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    in_flight_ = true;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+void DecodeBatch::stats(int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes) const
+{
+    if (num_units) {
+        num_units[0] = (int32_t)plane_units_.size();
+        num_units[1] = 0;
+        for (const auto& v : luma_units_) num_units[1] += (int32_t)v.size();
+        num_units[2] = (int32_t)generic_units_.size();
+    }
+    if (coef_bytes) *coef_bytes = coef_bytes_;
+    if (output_bytes) *output_bytes = output_bytes_;
+}
+
+}  // namespace hipjpeg

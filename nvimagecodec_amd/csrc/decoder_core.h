@@ -1,0 +1,101 @@
+// decoder_core.h -- host-side planning, staging and launch of one decode batch.
+//
+// A DecodeBatch owns: a pinned staging area [DecodeImage[] | WorkUnit tables | coefficient blocks], its device
+// mirror (same offsets, one hipMemcpyAsync), and a device-only arena for intermediate chroma planes.  It is the
+// MI355X counterpart of the reference's per-thread {pinned buffer, device buffer, stream} resources
+// (extensions/nvjpeg/cuda_decoder.h:54-75), but sized for a whole batch so the device stage is one launch per kernel.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/hipjpeg.h"
+#include "device_layout.h"
+#include "jpeg_syntax.h"
+
+namespace hipjpeg {
+
+// Custom allocation hooks (the plugin forwards nvimgcodecDeviceAllocator_t / nvimgcodecPinnedAllocator_t here).
+struct MemoryHooks {
+    int (*device_malloc)(void* ctx, void** ptr, size_t size, void* stream) = nullptr;
+    int (*device_free)(void* ctx, void* ptr, size_t size, void* stream) = nullptr;
+    void* device_ctx = nullptr;
+    int (*pinned_malloc)(void* ctx, void** ptr, size_t size, void* stream) = nullptr;
+    int (*pinned_free)(void* ctx, void* ptr, size_t size, void* stream) = nullptr;
+    void* pinned_ctx = nullptr;
+};
+
+class Buffer {
+public:
+    enum Kind { kDevice, kPinned };
+    Buffer(Kind kind, const MemoryHooks* hooks) : kind_(kind), hooks_(hooks) {}
+    ~Buffer() { release(); }
+    Buffer(const Buffer&) = delete;
+    Buffer& operator=(const Buffer&) = delete;
+    // grow-only; contents are NOT preserved
+    hipjpegStatus_t reserve(size_t bytes);
+    void release();
+    uint8_t* data() const { return ptr_; }
+    size_t capacity() const { return cap_; }
+
+private:
+    Kind kind_;
+    const MemoryHooks* hooks_;
+    uint8_t* ptr_ = nullptr;
+    size_t cap_ = 0;
+    bool custom_ = false;
+};
+
+enum KernelVariant { kVarGray = 0, kVar11 = 1, kVar21 = 2, kVar22 = 3, kVar12 = 4, kNumLumaVariants = 5 };
+
+struct PlannedImage {
+    FrameInfo frame;
+    hipjpegStatus_t status = HIPJPEG_STATUS_SUCCESS;
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+    size_t coef_offset[4] = {0, 0, 0, 0};  // byte offset of component c inside the staging area
+    int variant = -1;                      // KernelVariant, or -1 = generic colour path, -2 = planes-to-output only
+    uint32_t coef_or[4] = {0, 0, 0, 0};    // OR of |coefficient| per component (from the entropy stage)
+};
+
+class DecodeBatch {
+public:
+    DecodeBatch(int device_id, const MemoryHooks* hooks);
+    ~DecodeBatch();
+
+    // Phase 0: parse headers, choose kernels, lay out staging memory.  Per-image problems land in statuses[i].
+    hipjpegStatus_t plan(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
+                         hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses);
+    // Phase 1: entropy-decode image i into the pinned staging area.  Thread-safe for distinct i.
+    void entropy_stage(int i);
+    // Phase 1b: after every entropy_stage returned: final per-image flags, drop failed images from the unit tables.
+    void finalize(hipjpegStatus_t* statuses);
+    // Phase 2: one async H2D copy of descriptors + coefficients.
+    hipjpegStatus_t transfer(void* stream);
+    // Phase 3: kernel launches.
+    hipjpegStatus_t launch(void* stream);
+
+    int size() const { return (int)images_.size(); }
+    const PlannedImage& image(int i) const { return images_[i]; }
+    void stats(int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes) const;
+
+private:
+    int device_id_;
+    const MemoryHooks* hooks_;
+    Buffer pinned_, device_, planes_;
+    std::vector<PlannedImage> images_;
+    std::vector<DecodeImage> desc_;  // host copy (device pointers inside)
+    std::vector<WorkUnit> plane_units_, luma_units_[kNumLumaVariants], generic_units_;
+    size_t desc_offset_ = 0, units_offset_ = 0, coef_offset_ = 0, staging_bytes_ = 0, plane_bytes_ = 0;
+    size_t unit_off_plane_ = 0, unit_off_luma_[kNumLumaVariants] = {0}, unit_off_generic_ = 0;
+    uint64_t coef_bytes_ = 0, output_bytes_ = 0;
+    bool finalized_ = false;
+    void* done_event_ = nullptr;  // hipEvent_t recorded after the last launch that reads this batch's buffers
+    bool in_flight_ = false;
+};
+
+// status helpers
+hipjpegStatus_t status_from_parse(ParseStatus s);
+hipjpegChromaSubsampling_t classify_subsampling(const FrameInfo& f);
+
+}  // namespace hipjpeg

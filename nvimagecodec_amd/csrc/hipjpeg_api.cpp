@@ -1,0 +1,167 @@
+// hipjpeg_api.cpp -- the C-ABI declared in include/hipjpeg.h (decode side).
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "../../include/hipjpeg.h"
+#include "decoder_core.h"
+#include "entropy_decode.h"
+#include "thread_pool.h"
+
+using namespace hipjpeg;
+
+struct hipjpegHandle {
+    int device_id = 0;
+    MemoryHooks hooks;
+    std::unique_ptr<ForkJoinPool> pool;
+    // two batches, used alternately: the host stage of batch k+1 can fill its pinned area while the device is still
+    // consuming batch k (same idea as the reference's two pinned pages per thread, cuda_decoder.h:50-53)
+    std::unique_ptr<DecodeBatch> batches[2];
+    int current = 0;
+    DecodeBatch& cur() { return *batches[current]; }
+};
+
+extern "C" {
+
+const char* hipjpegStatusString(hipjpegStatus_t s)
+{
+    switch (s) {
+    case HIPJPEG_STATUS_SUCCESS: return "success";
+    case HIPJPEG_STATUS_INVALID_ARGUMENT: return "invalid argument";
+    case HIPJPEG_STATUS_BAD_JPEG: return "not a JPEG or malformed marker segment";
+    case HIPJPEG_STATUS_UNSUPPORTED: return "JPEG feature outside this decoder's scope";
+    case HIPJPEG_STATUS_TRUNCATED: return "entropy-coded data ends early";
+    case HIPJPEG_STATUS_CORRUPT: return "corrupt entropy-coded data";
+    case HIPJPEG_STATUS_ALLOC_FAILED: return "memory allocation failed";
+    case HIPJPEG_STATUS_HIP_ERROR: return "HIP runtime error";
+    case HIPJPEG_STATUS_NO_DEVICE: return "no usable HIP device";
+    case HIPJPEG_STATUS_BUFFER_TOO_SMALL: return "buffer too small";
+    }
+    return "unknown status";
+}
+
+int hipjpegVersion(void) { return 100; }
+
+hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t length, hipjpegImageInfo_t* info)
+{
+    if (!data || !info) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    FrameInfo f;
+    ParseStatus ps = parse_jpeg(data, length, &f, /*headers_only=*/false);
+    memset(info, 0, sizeof *info);
+    info->sof_marker = f.sof;
+    if (ps != kParseOk) return status_from_parse(ps);
+    info->width = f.width;
+    info->height = f.height;
+    info->num_components = f.ncomp;
+    info->color_model = (int)f.color;
+    info->subsampling = classify_subsampling(f);
+    info->restart_interval = f.scans.empty() ? 0 : f.scans[0].restart_interval;
+    info->num_scans = (int)f.scans.size();
+    for (int c = 0; c < f.ncomp; c++) {
+        info->h[c] = f.comp[c].h;
+        info->v[c] = f.comp[c].v;
+        info->blocks_w[c] = f.comp[c].blocks_w;
+        info->blocks_h[c] = f.comp[c].blocks_h;
+        info->samp_w[c] = f.comp[c].samp_w;
+        info->samp_h[c] = f.comp[c].samp_h;
+    }
+    info->coef_bytes = f.total_blocks() * 128;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegEntropyDecodeHost(const uint8_t* data, size_t length, int16_t* coef, size_t coef_capacity_bytes,
+                                         uint64_t comp_offsets[4], uint16_t qtables[256])
+{
+    if (!data || !coef) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    FrameInfo f;
+    ParseStatus ps = parse_jpeg(data, length, &f);
+    if (ps != kParseOk) return status_from_parse(ps);
+    if (f.total_blocks() * 128 > coef_capacity_bytes) return HIPJPEG_STATUS_BUFFER_TOO_SMALL;
+    int16_t* ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t off = 0;
+    for (int c = 0; c < f.ncomp; c++) {
+        ptr[c] = coef + off;
+        if (comp_offsets) comp_offsets[c] = off;
+        off += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 64;
+        if (qtables)
+            for (int j = 0; j < 64; j++) qtables[c * 64 + (j & 7) * 8 + (j >> 3)] = f.qtab[c][j];
+    }
+    switch (decode_coefficients(data, length, f, ptr)) {
+    case kEntropyOk: return HIPJPEG_STATUS_SUCCESS;
+    case kEntropyTruncated: return HIPJPEG_STATUS_TRUNCATED;
+    case kEntropyMissingTable: return HIPJPEG_STATUS_BAD_JPEG;
+    default: return HIPJPEG_STATUS_CORRUPT;
+    }
+}
+
+hipjpegStatus_t hipjpegCreate(hipjpegHandle_t* handle, int device_id, int num_host_threads)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    *handle = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return HIPJPEG_STATUS_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    hipjpegHandle* h = new (std::nothrow) hipjpegHandle();
+    if (!h) return HIPJPEG_STATUS_ALLOC_FAILED;
+    h->device_id = device_id;
+    h->pool.reset(new ForkJoinPool(num_host_threads));
+    h->batches[0].reset(new DecodeBatch(device_id, &h->hooks));
+    h->batches[1].reset(new DecodeBatch(device_id, &h->hooks));
+    *handle = h;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegDestroy(hipjpegHandle_t handle)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    (void)hipSetDevice(handle->device_id);
+    delete handle;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
+                                       const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags,
+                                       hipjpegStatus_t* statuses)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    handle->current ^= 1;
+    DecodeBatch& b = handle->cur();
+    hipjpegStatus_t st = b.plan(data, lengths, batch_size, outputs, format, flags, statuses);
+    if (st != HIPJPEG_STATUS_SUCCESS) return st;
+    handle->pool->parallel_for(batch_size, [&](int i, int) { b.entropy_stage(i); });
+    b.finalize(statuses);
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegDecodeBatchTransfer(hipjpegHandle_t handle, void* stream)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    return handle->cur().transfer(stream);
+}
+
+hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, void* stream)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    return handle->cur().launch(stream);
+}
+
+hipjpegStatus_t hipjpegDecodeBatchStats(hipjpegHandle_t handle, int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    handle->cur().stats(num_units, coef_bytes, output_bytes);
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegDecodeBatch(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
+                                   const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
+                                   void* stream)
+{
+    hipjpegStatus_t st = hipjpegDecodeBatchHost(handle, data, lengths, batch_size, outputs, format, flags, statuses);
+    if (st != HIPJPEG_STATUS_SUCCESS) return st;
+    if ((st = hipjpegDecodeBatchTransfer(handle, stream)) != HIPJPEG_STATUS_SUCCESS) return st;
+    return hipjpegDecodeBatchDevice(handle, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// thread_pool.h -- minimal fork/join worker pool for the host entropy stage of the batched C API.
+// (The nvImageCodec plugin path does not use it: there the framework's executor supplies the threads,
+//  nvimgcodecExecutorDesc_t, reference include/nvimgcodec.h:800-828.)
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace hipjpeg {
+
+class ForkJoinPool {
+public:
+    explicit ForkJoinPool(int num_threads)
+    {
+        if (num_threads <= 0) num_threads = (int)std::thread::hardware_concurrency();
+        if (num_threads <= 0) num_threads = 1;
+        nthreads_ = num_threads;
+        // the calling thread participates, so spawn nthreads-1 helpers
+        for (int t = 1; t < nthreads_; t++) workers_.emplace_back([this, t] { worker_loop(t); });
+    }
+    ~ForkJoinPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            generation_++;
+        }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    int num_threads() const { return nthreads_; }
+
+    // Runs fn(index, thread_id) for index in [0, n); indices are handed out dynamically.  Blocks until done.
+    void parallel_for(int n, const std::function<void(int, int)>& fn)
+    {
+        if (n <= 0) return;
+        if (nthreads_ == 1 || n == 1) {
+            for (int i = 0; i < n; i++) fn(i, 0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            job_n_ = n;
+            next_.store(0);
+            pending_ = nthreads_ - 1;
+            generation_++;
+        }
+        cv_.notify_all();
+        run_indices(fn, n, 0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void run_indices(const std::function<void(int, int)>& fn, int n, int tid)
+    {
+        for (;;) {
+            int i = next_.fetch_add(1);
+            if (i >= n) break;
+            fn(i, tid);
+        }
+    }
+    void worker_loop(int tid)
+    {
+        unsigned seen = 0;
+        for (;;) {
+            const std::function<void(int, int)>* job;
+            int n;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+                job = job_;
+                n = job_n_;
+            }
+            if (job) run_indices(*job, n, tid);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+
+    int nthreads_ = 1;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int, int)>* job_ = nullptr;
+    int job_n_ = 0, pending_ = 0;
+    unsigned generation_ = 0;
+    bool stop_ = false;
+    std::atomic<int> next_{0};
+};
+
+}  // namespace hipjpeg

@@ -1,0 +1,171 @@
+"""Thin Python front-end of the hipjpeg C-ABI (include/hipjpeg.h).  torch is used only as the owner of device
+memory and streams; every pixel is produced by the HIP kernels in libhipjpeg_ext.so."""
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+
+_FORMATS = {"rgb": N.OUTPUT_RGBI, "bgr": N.OUTPUT_BGRI, "rgb_planar": N.OUTPUT_RGB_PLANAR, "bgr_planar": N.OUTPUT_BGR_PLANAR,
+            "y": N.OUTPUT_Y, "yuv_planar": N.OUTPUT_YUV_PLANAR}
+
+
+def _as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+def get_image_info(data):
+    a = _as_u8(data)
+    info = N.ImageInfo()
+    st = N.load().hipjpegGetImageInfo(a.ctypes.data, a.size, ctypes.byref(info))
+    if st:
+        raise N.HipJpegError(st, "hipjpegGetImageInfo")
+    nc = info.num_components
+    d = {k: getattr(info, k) for k in ("width", "height", "num_components", "sof_marker", "color_model", "subsampling",
+                                        "restart_interval", "num_scans", "coef_bytes")}
+    for k in ("h", "v", "blocks_w", "blocks_h", "samp_w", "samp_h"):
+        d[k] = list(getattr(info, k))[:nc]
+    return d
+
+
+def entropy_decode_host(data):
+    """Host stage only (no GPU).  Returns (coefs, qtables): per component int16 [blocks_h, blocks_w, 64] and uint16[64],
+    both converted back to NATURAL (row-major) order for easy comparison with the oracle."""
+    a = _as_u8(data)
+    info = get_image_info(a)
+    buf = np.zeros(info["coef_bytes"] // 2, dtype=np.int16)
+    offs = (ctypes.c_uint64 * 4)()
+    qt = np.zeros(256, dtype=np.uint16)
+    st = N.load().hipjpegEntropyDecodeHost(a.ctypes.data, a.size, buf.ctypes.data, buf.nbytes, ctypes.addressof(offs), qt.ctypes.data)
+    if st:
+        raise N.HipJpegError(st, "hipjpegEntropyDecodeHost")
+    coefs, qts = [], []
+    for c in range(info["num_components"]):
+        n = info["blocks_w"][c] * info["blocks_h"][c]
+        blk = buf[offs[c]: offs[c] + n * 64].reshape(info["blocks_h"][c], info["blocks_w"][c], 8, 8)
+        coefs.append(np.ascontiguousarray(blk.transpose(0, 1, 3, 2)).reshape(info["blocks_h"][c], info["blocks_w"][c], 64))
+        qts.append(np.ascontiguousarray(qt[c * 64:(c + 1) * 64].reshape(8, 8).T).reshape(64))
+    return coefs, qts
+
+
+class BatchDecoder:
+    """hipjpegCreate / hipjpegDecodeBatch* on one device."""
+
+    def __init__(self, device=0, num_threads=0):
+        import torch
+        self._torch = torch
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        st = N.load().hipjpegCreate(ctypes.byref(self._h), self.device, int(num_threads))
+        if st:
+            raise N.HipJpegError(st, "hipjpegCreate")
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            N.load().hipjpegDestroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- output allocation mirrors python/decoder.cpp:179-225 of the reference: I_RGB u8, row_stride = w*3
+    def allocate_outputs(self, jpegs, fmt="rgb"):
+        torch = self._torch
+        dev = torch.device("cuda", self.device)
+        outs = []
+        for j in jpegs:
+            try:
+                info = get_image_info(j)
+            except N.HipJpegError:
+                outs.append(None)
+                continue
+            h, w = info["height"], info["width"]
+            if fmt in ("rgb", "bgr"):
+                outs.append(torch.empty((h, w, 3), dtype=torch.uint8, device=dev))
+            elif fmt in ("rgb_planar", "bgr_planar"):
+                outs.append(torch.empty((3, h, w), dtype=torch.uint8, device=dev))
+            elif fmt == "y":
+                outs.append(torch.empty((h, w), dtype=torch.uint8, device=dev))
+            else:
+                outs.append([torch.empty((info["samp_h"][c], info["samp_w"][c]), dtype=torch.uint8, device=dev)
+                             for c in range(info["num_components"])])
+        return outs
+
+    def _marshal(self, jpegs, outs, fmt):
+        n = len(jpegs)
+        arrs = [_as_u8(j) for j in jpegs]
+        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (ctypes.c_size_t * n)(*[a.size for a in arrs])
+        O = (N.Output * n)()
+        for i, o in enumerate(outs):
+            if o is None:
+                continue
+            if fmt in ("rgb", "bgr"):
+                O[i].plane[0] = o.data_ptr()
+                O[i].pitch[0] = o.stride(0)
+            elif fmt in ("rgb_planar", "bgr_planar"):
+                for p in range(3):
+                    O[i].plane[p] = o[p].data_ptr()
+                    O[i].pitch[p] = o.stride(1)
+            elif fmt == "y":
+                O[i].plane[0] = o.data_ptr()
+                O[i].pitch[0] = o.stride(0)
+            else:
+                for p, t in enumerate(o):
+                    O[i].plane[p] = t.data_ptr()
+                    O[i].pitch[p] = t.stride(0)
+        statuses = (ctypes.c_int * n)()
+        self._keep = (arrs, ptrs, lens, O, outs)  # keep host inputs alive until the next call
+        return ptrs, lens, O, statuses
+
+    def _stream_ptr(self, stream):
+        torch = self._torch
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def decode(self, jpegs, fmt="rgb", fancy=True, outs=None, stream=None, check=True):
+        """Full pipeline.  Returns (outputs, statuses)."""
+        if outs is None:
+            outs = self.allocate_outputs(jpegs, fmt)
+        ptrs, lens, O, statuses = self._marshal(jpegs, outs, fmt)
+        flags = N.FLAG_FANCY_UPSAMPLING if fancy else 0
+        st = N.load().hipjpegDecodeBatch(self._h, ptrs, lens, len(jpegs), O, _FORMATS[fmt], flags, statuses, self._stream_ptr(stream))
+        if st:
+            raise N.HipJpegError(st, "hipjpegDecodeBatch")
+        statuses = list(statuses)
+        if check:
+            for i, s in enumerate(statuses):
+                if s:
+                    raise N.HipJpegError(s, f"image {i}")
+        return outs, statuses
+
+    # -- the three phases separately (bench.py times device_stage with coefficients resident in HBM)
+    def host_stage(self, jpegs, outs, fmt="rgb", fancy=True):
+        ptrs, lens, O, statuses = self._marshal(jpegs, outs, fmt)
+        flags = N.FLAG_FANCY_UPSAMPLING if fancy else 0
+        st = N.load().hipjpegDecodeBatchHost(self._h, ptrs, lens, len(jpegs), O, _FORMATS[fmt], flags, statuses)
+        if st:
+            raise N.HipJpegError(st, "hipjpegDecodeBatchHost")
+        return list(statuses)
+
+    def transfer(self, stream=None):
+        st = N.load().hipjpegDecodeBatchTransfer(self._h, self._stream_ptr(stream))
+        if st:
+            raise N.HipJpegError(st, "hipjpegDecodeBatchTransfer")
+
+    def device_stage(self, stream=None):
+        st = N.load().hipjpegDecodeBatchDevice(self._h, self._stream_ptr(stream))
+        if st:
+            raise N.HipJpegError(st, "hipjpegDecodeBatchDevice")
+
+    def stats(self):
+        units = (ctypes.c_int32 * 3)()
+        cb, ob = ctypes.c_uint64(), ctypes.c_uint64()
+        N.load().hipjpegDecodeBatchStats(self._h, ctypes.addressof(units), ctypes.byref(cb), ctypes.byref(ob))
+        return dict(units=list(units), coef_bytes=cb.value, output_bytes=ob.value)

@@ -1,0 +1,80 @@
+"""Host logic (no GPU): the product's marker parser + Huffman entropy stage (nvimagecodec_amd/csrc/jpeg_syntax.cpp,
+entropy_decode.cpp, reached through the C-ABI hipjpegGetImageInfo / hipjpegEntropyDecodeHost) against the oracle's
+independently written entropy decoder, on every golden bitstream.  Integer work: exact equality."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, load_decode_case
+from nvimagecodec_amd import _native as N
+from nvimagecodec_amd import lowlevel
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _f:
+    _M = json.load(_f)
+
+
+@pytest.mark.parametrize("entry", _M["decode"], ids=lambda e: e["name"])
+def test_entropy_stage_matches_oracle(entry):
+    jpeg, _ = load_decode_case(entry)
+    info = lowlevel.get_image_info(jpeg)
+    oinfo = oracle.read_info(jpeg)
+    assert (info["width"], info["height"], info["num_components"], info["sof_marker"]) == (
+        oinfo["width"], oinfo["height"], oinfo["ncomp"], oinfo["sof"])
+    assert info["blocks_w"] == oinfo["bw"] and info["blocks_h"] == oinfo["bh"]
+    assert info["samp_w"] == oinfo["dw"] and info["samp_h"] == oinfo["dh"]
+    assert info["restart_interval"] == oinfo["restart_interval"]
+    coefs, qts = lowlevel.entropy_decode_host(jpeg)
+    ocoefs, oqts = oracle.decode_coefficients(jpeg)
+    for c in range(info["num_components"]):
+        assert np.array_equal(qts[c], oqts[c])
+        assert np.array_equal(coefs[c], ocoefs[c]), f"component {c}"
+
+
+def test_subsampling_classification():
+    names = {"444": 0, "422": 1, "420": 2, "440": 3, "411": 4, "410": 5, "gray": 6}
+    seen = set()
+    for e in _M["decode"]:
+        if e["sub"] in seen:
+            continue
+        seen.add(e["sub"])
+        jpeg, _ = load_decode_case(e)
+        assert lowlevel.get_image_info(jpeg)["subsampling"] == names[e["sub"]], e["name"]
+    assert seen == set(names)
+
+
+def test_error_statuses():
+    with pytest.raises(N.HipJpegError) as ei:
+        lowlevel.get_image_info(b"\x89PNG\r\n\x1a\n" + b"\0" * 32)
+    assert ei.value.status == 2  # BAD_JPEG
+    jpeg, _ = load_decode_case(next(e for e in _M["decode"] if e["name"] == "s64x48_420_base_q90"))
+    with pytest.raises(N.HipJpegError) as ei:
+        lowlevel.entropy_decode_host(jpeg[: len(jpeg) * 2 // 3])
+    assert ei.value.status in (4, 5)  # TRUNCATED / CORRUPT
+    # flip bytes in the entropy-coded segment: must fail cleanly or decode to *something*, never crash
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        b = bytearray(jpeg)
+        for k in rng.integers(len(b) // 2, len(b) - 2, size=4):
+            b[k] = int(rng.integers(0, 256))
+        try:
+            lowlevel.entropy_decode_host(bytes(b))
+        except N.HipJpegError:
+            pass
+
+
+def test_arithmetic_and_12bit_are_unsupported():
+    jpeg, _ = load_decode_case(next(e for e in _M["decode"] if e["name"] == "s64x48_420_base_q90"))
+    b = bytearray(jpeg)
+    i = b.find(b"\xff\xc0")
+    b[i + 1] = 0xC9  # SOF9: arithmetic coding
+    with pytest.raises(N.HipJpegError) as ei:
+        lowlevel.get_image_info(bytes(b))
+    assert ei.value.status == 3
+    b = bytearray(jpeg)
+    b[i + 4] = 12  # sample precision
+    with pytest.raises(N.HipJpegError) as ei:
+        lowlevel.get_image_info(bytes(b))
+    assert ei.value.status == 3
