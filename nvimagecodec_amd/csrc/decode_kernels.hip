@@ -145,24 +145,24 @@ template <bool EXACT>
 __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int comp = u.comp;
-    const int bw = im.blocks_w[comp], nblocks = bw * im.blocks_h[comp];
+    const DecodeComponent& cd = im.comp[u.comp];
+    const int bw = cd.blocks_w, nblocks = bw * cd.blocks_h;
     const int wave_first = u.block_base + wave * 64;
     u32x4 cols[8];
-    fetch_block(im.coef[comp], wave_first, nblocks, lds + wave * kLdsWaveBytes, lane, cols);
+    fetch_block(cd.coef, wave_first, nblocks, lds + wave * kLdsWaveBytes, lane, cols);
     const int b = wave_first + lane;
     if (b >= nblocks) return;
     int ws[8][8];
-    dequant_column_pass<EXACT>(cols, im.qt[comp], ws);
+    dequant_column_pass<EXACT>(cols, cd.qt, ws);
 
     const int by = b / bw, bx = b - by * bw;
     const bool to_out = (u.mode & 0xFF) == kToOutput;
     const int op = u.mode >> 8;
-    uint8_t* dst = to_out ? im.out[op] : im.plane[comp];
-    const unsigned pitch = to_out ? im.out_pitch[op] : im.plane_pitch[comp];
+    uint8_t* dst = to_out ? im.out[op] : cd.plane;
+    const unsigned pitch = to_out ? im.out_pitch[op] : cd.plane_pitch;
     // kToPlane: every allocated block is written; kToOutput: crop to the true component size
-    const int lim_w = to_out ? im.samp_w[comp] : bw * 8;
-    const int lim_h = to_out ? im.samp_h[comp] : im.blocks_h[comp] * 8;
+    const int lim_w = to_out ? cd.samp_w : bw * 8;
+    const int lim_h = to_out ? cd.samp_h : cd.blocks_h * 8;
     const int x0 = bx * 8, y0 = by * 8;
     if (x0 >= lim_w) return;
     uint8_t* p = dst + (size_t)y0 * pitch + x0;
@@ -284,10 +284,10 @@ template <bool EXACT, int HS, int VS>
 __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bw = im.blocks_w[0], nblocks = bw * im.blocks_h[0];
+    const int bw = im.comp[0].blocks_w, nblocks = bw * im.comp[0].blocks_h;
     const int wave_first = u.block_base + wave * 64;
     u32x4 cols[8];
-    fetch_block(im.coef[0], wave_first, nblocks, lds + wave * kLdsWaveBytes, lane, cols);
+    fetch_block(im.comp[0].coef, wave_first, nblocks, lds + wave * kLdsWaveBytes, lane, cols);
     const int b = wave_first + lane;
     if (b >= nblocks) return;
     const int by = b / bw, bx = b - by * bw;
@@ -301,17 +301,17 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     unsigned long long cbw[NR], crw[NR];
     bool fancy = false;
     if constexpr (HS != 0) {
-        const int dw = im.samp_w[1], dh = im.samp_h[1];
+        const int dw = im.comp[1].samp_w, dh = im.comp[1].samp_h;
         // libjpeg picks the triangle filters only when do_fancy_upsampling and (for h2v1/h2v2) downsampled_width > 2
         fancy = (im.flags & kFlagFancyUpsampling) && (HS == 1 || dw > 2);
         const int wx = HS == 2 ? 4 * bx - 1 : 8 * bx;
         const int wy = VS == 2 ? 4 * by - 1 : 8 * by;
-        load_chroma_window<NR, NW>(im.plane[1], im.plane_pitch[1], dw, dh, wx, wy, cbw);
-        load_chroma_window<NR, NW>(im.plane[2], im.plane_pitch[2], dw, dh, wx, wy, crw);
+        load_chroma_window<NR, NW>(im.comp[1].plane, im.comp[1].plane_pitch, dw, dh, wx, wy, cbw);
+        load_chroma_window<NR, NW>(im.comp[2].plane, im.comp[2].plane_pitch, dw, dh, wx, wy, crw);
     }
 
     int ws[8][8];
-    dequant_column_pass<EXACT>(cols, im.qt[0], ws);
+    dequant_column_pass<EXACT>(cols, im.comp[0].qt, ws);
 
     const int fmt = im.out_format;
     const bool planar = fmt == kOutPlanarRGB || fmt == kOutPlanarBGR;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void luma_color_kernel(const DecodeImage*
 // ------------------------------------------------------------------------------------------------
 // K3: generic colour stage for layouts the fused kernel does not cover (4:1:1, 4:1:0, ...): every component is in a
 // plane already; libjpeg upsamples those by plain replication (jdsample.c int_upsample).  One thread = one pixel.
-// mode 0 of the unit table is reused: block_base = first pixel row, comp unused.
+// The unit table is reused: block_base = pixel row, comp unused.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void generic_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
@@ -436,14 +436,18 @@ __global__ __launch_bounds__(kThreads) void generic_color_kernel(const DecodeIma
     const int fmt = im.out_format;
     const bool planar = fmt == kOutPlanarRGB || fmt == kOutPlanarBGR;
     const bool bgr = fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR;
+    // Only three-component images take this path (gray goes through luma_color_kernel<0,0>), so the component
+    // index is a compile-time constant everywhere below.
+    const int hmax = im.hmax, vmax = im.vmax;
+    const uint8_t* row0 = im.comp[0].plane + (size_t)(y * im.comp[0].v / vmax) * im.comp[0].plane_pitch;
+    const uint8_t* row1 = im.comp[1].plane + (size_t)(y * im.comp[1].v / vmax) * im.comp[1].plane_pitch;
+    const uint8_t* row2 = im.comp[2].plane + (size_t)(y * im.comp[2].v / vmax) * im.comp[2].plane_pitch;
+    const int h0 = im.comp[0].h, h1 = im.comp[1].h, h2 = im.comp[2].h;
     for (int x = threadIdx.x; x < W; x += kThreads) {
         int s[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            int cc = im.ncomp == 1 ? 0 : c;
-            int sx = x * im.h[cc] / im.hmax, sy = y * im.v[cc] / im.vmax;
-            s[c] = im.plane[cc][(size_t)sy * im.plane_pitch[cc] + sx];
-        }
+        s[0] = row0[x * h0 / hmax];
+        s[1] = row1[x * h1 / hmax];
+        s[2] = row2[x * h2 / hmax];
         int R, G, B;
         if (im.color_model == 1) {
             int rr = (s[2] * 91881 + (32768 - 128 * 91881)) >> 16;

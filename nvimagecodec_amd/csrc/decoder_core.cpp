@@ -4,6 +4,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "decode_kernels.h"
@@ -174,13 +176,13 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
 
         DecodeImage& d = desc_[i];
         memset(&d, 0, sizeof d);
-        d.width = (uint16_t)f.width;
-        d.height = (uint16_t)f.height;
-        d.ncomp = (uint8_t)f.ncomp;
-        d.hmax = (uint8_t)f.hmax;
-        d.vmax = (uint8_t)f.vmax;
-        d.color_model = (uint8_t)f.color;
-        d.out_format = (uint8_t)fmt;
+        d.width = (uint32_t)f.width;
+        d.height = (uint32_t)f.height;
+        d.ncomp = (uint32_t)f.ncomp;
+        d.hmax = (uint32_t)f.hmax;
+        d.vmax = (uint32_t)f.vmax;
+        d.color_model = (uint32_t)f.color;
+        d.out_format = (uint32_t)fmt;
         d.flags = fancy ? kFlagFancyUpsampling : 0;
         for (int p = 0; p < 3; p++) {
             d.out[p] = static_cast<uint8_t*>(outputs[i].plane[p]);
@@ -188,13 +190,14 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
         }
         for (int c = 0; c < f.ncomp; c++) {
             const Component& k = f.comp[c];
-            d.blocks_w[c] = (uint16_t)k.blocks_w;
-            d.blocks_h[c] = (uint16_t)k.blocks_h;
-            d.samp_w[c] = (uint16_t)k.samp_w;
-            d.samp_h[c] = (uint16_t)k.samp_h;
-            d.h[c] = (uint8_t)k.h;
-            d.v[c] = (uint8_t)k.v;
-            for (int j = 0; j < 64; j++) d.qt[c][(j & 7) * 8 + (j >> 3)] = f.qtab[c][j];  // natural -> column-major
+            DecodeComponent& dc = d.comp[c];
+            dc.blocks_w = (uint16_t)k.blocks_w;
+            dc.blocks_h = (uint16_t)k.blocks_h;
+            dc.samp_w = (uint16_t)k.samp_w;
+            dc.samp_h = (uint16_t)k.samp_h;
+            dc.h = (uint16_t)k.h;
+            dc.v = (uint16_t)k.v;
+            for (int j = 0; j < 64; j++) dc.qt[(j & 7) * 8 + (j >> 3)] = f.qtab[c][j];  // natural -> column-major
             const size_t nblk = (size_t)k.blocks_w * k.blocks_h;
             im.coef_offset[c] = coef_total;
             coef_total += nblk * 128;
@@ -203,9 +206,9 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
             bool needs_plane = (im.variant == -1) || (im.variant >= kVar11 && c > 0);
             bool to_output = (im.variant == -2) && (fmt == kOutPlanarYUV || c == 0);
             if (needs_plane) {
-                d.plane_pitch[c] = (uint32_t)align_up((size_t)k.blocks_w * 8 + 16, 16);
+                dc.plane_pitch = (uint32_t)align_up((size_t)k.blocks_w * 8 + 16, 16);
                 plane_off[(size_t)i * 4 + c] = plane_total;
-                plane_total += align_up((size_t)d.plane_pitch[c] * k.blocks_h * 8 + 16, 256);
+                plane_total += align_up((size_t)dc.plane_pitch * k.blocks_h * 8 + 16, 256);
             }
             if (needs_plane || to_output) max_units += units;
             if (c == 0 && im.variant >= 0) max_units += units;
@@ -241,8 +244,8 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
         DecodeImage& d = desc_[i];
         for (int c = 0; c < images_[i].frame.ncomp; c++) {
             images_[i].coef_offset[c] += coef_offset_;
-            d.coef[c] = reinterpret_cast<const int16_t*>(device_.data() + images_[i].coef_offset[c]);
-            if (plane_off[(size_t)i * 4 + c] != (size_t)-1) d.plane[c] = planes_.data() + plane_off[(size_t)i * 4 + c];
+            d.comp[c].coef = reinterpret_cast<const int16_t*>(device_.data() + images_[i].coef_offset[c]);
+            if (plane_off[(size_t)i * 4 + c] != (size_t)-1) d.comp[c].plane = planes_.data() + plane_off[(size_t)i * 4 + c];
         }
     }
     if (statuses)
@@ -331,10 +334,34 @@ hipjpegStatus_t DecodeBatch::launch(void* stream)
     const DecodeImage* dimg = reinterpret_cast<const DecodeImage*>(device_.data() + desc_offset_);
     auto units_at = [&](size_t off) { return reinterpret_cast<const WorkUnit*>(device_.data() + off); };
     static const int hs[kNumLumaVariants] = {0, 1, 2, 2, 1}, vs[kNumLumaVariants] = {0, 1, 1, 2, 2};
+    // HIPJPEG_DEBUG_SYNC=1: synchronise after every launch and report which kernel failed (debug aid only)
+    static const bool debug_sync = getenv("HIPJPEG_DEBUG_SYNC") != nullptr;
+    auto check = [&](const char* what, int n) {
+        if (!debug_sync) return;
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        fprintf(stderr, "[hipjpeg] %s units=%d -> %s\n", what, n, hipGetErrorString(e));
+    };
+    if (debug_sync) {
+        for (size_t i = 0; i < images_.size(); i++) {
+            const DecodeImage& d = desc_[i];
+            fprintf(stderr, "[hipjpeg] img %zu st=%d var=%d %dx%d ncomp=%d hmax=%d vmax=%d coef=%p,%p,%p plane=%p,%p,%p pitch=%u,%u,%u out=%p opitch=%u\n",
+                    i, (int)images_[i].status, images_[i].variant, (int)d.width, (int)d.height, (int)d.ncomp, (int)d.hmax, (int)d.vmax,
+                    (const void*)d.comp[0].coef, (const void*)d.comp[1].coef, (const void*)d.comp[2].coef, (void*)d.comp[0].plane,
+                    (void*)d.comp[1].plane, (void*)d.comp[2].plane, d.comp[0].plane_pitch, d.comp[1].plane_pitch, d.comp[2].plane_pitch,
+                    (void*)d.out[0], d.out_pitch[0]);
+        }
+        fprintf(stderr, "[hipjpeg] device=%p+%zu planes=%p+%zu unit offs plane=%zu generic=%zu coef_off=%zu staging=%zu\n", (void*)device_.data(),
+                device_.capacity(), (void*)planes_.data(), planes_.capacity(), unit_off_plane_, unit_off_generic_, coef_offset_, staging_bytes_);
+        check("transfer", 0);
+    }
     int rc = launch_idct_plane(dimg, units_at(unit_off_plane_), (int)plane_units_.size(), stream);
-    for (int k = 0; k < kNumLumaVariants && rc == 0; k++)
+    check("idct_plane", (int)plane_units_.size());
+    for (int k = 0; k < kNumLumaVariants && rc == 0; k++) {
         rc = launch_luma_color(hs[k], vs[k], dimg, units_at(unit_off_luma_[k]), (int)luma_units_[k].size(), stream);
+        check("luma_color", (int)luma_units_[k].size());
+    }
     if (rc == 0) rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
+    check("generic_color", (int)generic_units_.size());
     if (rc != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (!done_event_) {
         hipEvent_t ev;

@@ -28,19 +28,27 @@ enum ImageFlags : uint8_t {
     kFlagExactMul32 = 2,       // coefficient range too wide for 24-bit multiplies in IDCT pass 1
 };
 
-struct DecodeImage {
-    const int16_t* coef[4];
-    uint8_t* plane[4];  // intermediate component planes (may be null)
-    uint8_t* out[4];    // output planes; interleaved formats use out[0] only
-    uint32_t plane_pitch[4];
+// Per-component part of the descriptor.  Kept as one aligned record per component (rather than parallel arrays inside
+// DecodeImage) so that a kernel indexing it with a run-time component number computes ONE 16-byte-aligned base and then
+// uses constant offsets: hipcc otherwise folds byte-array indices into scalar-load base addresses, and an unaligned
+// s_load base reads the wrong dwords on gfx950.
+struct alignas(16) DecodeComponent {
+    const int16_t* coef;  // coefficient blocks
+    uint8_t* plane;       // intermediate plane (may be null)
+    uint32_t plane_pitch;
+    uint16_t blocks_w, blocks_h;  // MCU-padded block grid
+    uint16_t samp_w, samp_h;      // true component size in samples
+    uint16_t h, v;                // sampling factors
+    uint16_t qt[64];              // column-major like the coefficients
+};
+
+struct alignas(16) DecodeImage {
+    DecodeComponent comp[4];
+    uint8_t* out[4];  // output planes; interleaved formats use out[0] only
     uint32_t out_pitch[4];
-    uint16_t qt[4][64];  // per component, column-major like the coefficients
-    uint16_t width, height;
-    uint16_t blocks_w[4], blocks_h[4];
-    uint16_t samp_w[4], samp_h[4];
-    uint8_t ncomp, hmax, vmax, color_model;  // color_model: hipjpeg::ColorModel
-    uint8_t h[4], v[4];
-    uint8_t out_format, flags, pad0, pad1;
+    uint32_t width, height;
+    uint32_t ncomp, hmax, vmax, color_model;  // color_model: hipjpeg::ColorModel
+    uint32_t out_format, flags;
 };
 
 // One workgroup's worth of work: 256 consecutive blocks (raster order) of one component of one image.
