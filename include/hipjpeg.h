@@ -117,6 +117,9 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const
                                                    hipjpegStatus_t* statuses);
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchTransfer(hipjpegHandle_t handle, void* stream);
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, void* stream);
+/* One kernel family of the device stage at a time (0 = idct_plane, 1 = luma_color, 2 = generic_color), so a caller can
+ * bracket each with events.  hipjpegDecodeBatchDevice == all three in this order. */
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handle, int which, void* stream);
 /* Launch statistics of the prepared batch: workgroups per kernel (idct_plane, luma_color, generic). */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchStats(hipjpegHandle_t handle, int32_t num_units[3], uint64_t* coef_bytes,
                                                     uint64_t* output_bytes);

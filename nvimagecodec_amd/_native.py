@@ -53,6 +53,7 @@ def load():
     L.hipjpegDecodeBatchHost.argtypes = [vp, vp, vp, i32, vp, i32, ctypes.c_uint, vp]
     L.hipjpegDecodeBatchTransfer.argtypes = [vp, vp]
     L.hipjpegDecodeBatchDevice.argtypes = [vp, vp]
+    L.hipjpegDecodeBatchDeviceKernel.argtypes = [vp, i32, vp]
     L.hipjpegDecodeBatchStats.argtypes = [vp, vp, vp, vp]
     _lib = L
     return L

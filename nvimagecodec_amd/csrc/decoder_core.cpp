@@ -328,7 +328,7 @@ hipjpegStatus_t DecodeBatch::transfer(void* stream)
     return e == hipSuccess ? HIPJPEG_STATUS_SUCCESS : HIPJPEG_STATUS_HIP_ERROR;
 }
 
-hipjpegStatus_t DecodeBatch::launch(void* stream)
+hipjpegStatus_t DecodeBatch::launch(void* stream, int which)
 {
     if (!finalized_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     const DecodeImage* dimg = reinterpret_cast<const DecodeImage*>(device_.data() + desc_offset_);
@@ -354,14 +354,19 @@ hipjpegStatus_t DecodeBatch::launch(void* stream)
                 device_.capacity(), (void*)planes_.data(), planes_.capacity(), unit_off_plane_, unit_off_generic_, coef_offset_, staging_bytes_);
         check("transfer", 0);
     }
-    int rc = launch_idct_plane(dimg, units_at(unit_off_plane_), (int)plane_units_.size(), stream);
-    check("idct_plane", (int)plane_units_.size());
-    for (int k = 0; k < kNumLumaVariants && rc == 0; k++) {
+    int rc = 0;
+    if (which < 0 || which == 0) {
+        rc = launch_idct_plane(dimg, units_at(unit_off_plane_), (int)plane_units_.size(), stream);
+        check("idct_plane", (int)plane_units_.size());
+    }
+    for (int k = 0; k < kNumLumaVariants && rc == 0 && (which < 0 || which == 1); k++) {
         rc = launch_luma_color(hs[k], vs[k], dimg, units_at(unit_off_luma_[k]), (int)luma_units_[k].size(), stream);
         check("luma_color", (int)luma_units_[k].size());
     }
-    if (rc == 0) rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
-    check("generic_color", (int)generic_units_.size());
+    if (rc == 0 && (which < 0 || which == 2)) {
+        rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
+        check("generic_color", (int)generic_units_.size());
+    }
     if (rc != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (!done_event_) {
         hipEvent_t ev;

@@ -72,8 +72,8 @@ public:
     void finalize(hipjpegStatus_t* statuses);
     // Phase 2: one async H2D copy of descriptors + coefficients.
     hipjpegStatus_t transfer(void* stream);
-    // Phase 3: kernel launches.
-    hipjpegStatus_t launch(void* stream);
+    // Phase 3: kernel launches.  which = -1: all; 0 idct_plane, 1 luma_color (every variant), 2 generic_color.
+    hipjpegStatus_t launch(void* stream, int which = -1);
 
     int size() const { return (int)images_.size(); }
     const PlannedImage& image(int i) const { return images_[i]; }

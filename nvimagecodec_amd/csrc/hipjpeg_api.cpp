@@ -147,6 +147,12 @@ hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, void* stream)
     return handle->cur().launch(stream);
 }
 
+hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handle, int which, void* stream)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    return handle->cur().launch(stream, which);
+}
+
 hipjpegStatus_t hipjpegDecodeBatchStats(hipjpegHandle_t handle, int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes)
 {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;

@@ -159,8 +159,12 @@ class BatchDecoder:
         if st:
             raise N.HipJpegError(st, "hipjpegDecodeBatchTransfer")
 
-    def device_stage(self, stream=None):
-        st = N.load().hipjpegDecodeBatchDevice(self._h, self._stream_ptr(stream))
+    def device_stage(self, stream=None, which=None):
+        """which=None: all kernels; 0 idct_plane, 1 luma_color, 2 generic_color."""
+        if which is None:
+            st = N.load().hipjpegDecodeBatchDevice(self._h, self._stream_ptr(stream))
+        else:
+            st = N.load().hipjpegDecodeBatchDeviceKernel(self._h, int(which), self._stream_ptr(stream))
         if st:
             raise N.HipJpegError(st, "hipjpegDecodeBatchDevice")
 
