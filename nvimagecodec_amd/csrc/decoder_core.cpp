@@ -147,14 +147,14 @@ bool choose_variant(const FrameInfo& f, OutFormat fmt, bool fancy, int* variant)
 }  // namespace
 
 hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
-                                  hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses)
+                                  hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
+                                  const hipjpegOutputFormat_t* formats)
 {
     if (n < 0 || (n > 0 && (!data || !lengths || !outputs))) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     if ((int)format < 0 || (int)format > (int)HIPJPEG_OUTPUT_YUV_PLANAR) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     finalized_ = false;
     images_.assign(n, PlannedImage());
     desc_.assign(n, DecodeImage());
-    const OutFormat fmt = (OutFormat)format;
     const bool fancy = (flags & HIPJPEG_FLAG_FANCY_UPSAMPLING) != 0;
 
     size_t max_units = 0, coef_total = 0, plane_total = 0;
@@ -164,7 +164,12 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
         PlannedImage& im = images_[i];
         im.data = data[i];
         im.size = lengths[i];
-        im.status = status_from_parse(parse_jpeg(data[i], lengths[i], &im.frame));
+        if (formats && ((int)formats[i] < 0 || (int)formats[i] > (int)HIPJPEG_OUTPUT_YUV_PLANAR)) {
+            im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
+            continue;
+        }
+        const OutFormat fmt = (OutFormat)(formats ? formats[i] : format);
+        im.status = data[i] ? status_from_parse(parse_jpeg(data[i], lengths[i], &im.frame)) : HIPJPEG_STATUS_INVALID_ARGUMENT;
         if (im.status == HIPJPEG_STATUS_SUCCESS && !choose_variant(im.frame, fmt, fancy, &im.variant)) im.status = HIPJPEG_STATUS_UNSUPPORTED;
         const FrameInfo& f = im.frame;
         const int nplanes_out = (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR || fmt == kOutY) ? 1 : 3;

@@ -64,8 +64,10 @@ public:
     ~DecodeBatch();
 
     // Phase 0: parse headers, choose kernels, lay out staging memory.  Per-image problems land in statuses[i].
+    // `formats` (optional) gives one output format per image; otherwise `format` applies to all.
     hipjpegStatus_t plan(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
-                         hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses);
+                         hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
+                         const hipjpegOutputFormat_t* formats = nullptr);
     // Phase 1: entropy-decode image i into the pinned staging area.  Thread-safe for distinct i.
     void entropy_stage(int i);
     // Phase 1b: after every entropy_stage returned: final per-image flags, drop failed images from the unit tables.

@@ -1,0 +1,472 @@
+// plugin_decoder.cpp -- the nvImageCodec decoder plugin ("hipjpeg_decoder") of this extension.
+//
+// Fills the nvimgcodecDecoderDesc_t function table (ABI: include/nvimgcodec_abi.h; reference include/nvimgcodec.h:1150-1209)
+// so that ImageGenericDecoder / DecoderWorker dispatch to it exactly as they do to the reference's nvjpeg CUDA decoder
+// (extensions/nvjpeg/cuda_decoder.cpp).  Behavioural contract mirrored from there:
+//   * create() refuses NVIMGCODEC_DEVICE_CPU_ONLY (cuda_decoder.cpp:272-273), honours the user's allocators (:221-237)
+//   * canDecode() fills every status; acceptance rules follow cuda_decoder.cpp:52-122 minus what this decoder hands
+//     to the fallback chain (CMYK/YCCK, ROI, EXIF rotation)
+//   * decode() is asynchronous and calls imageReady exactly once per sample; the user's stream is ordered after our
+//     work with an event before imageReady(SUCCESS) (cuda_decoder.cpp:552-558)
+// What is different by design: the reference issues one nvJPEG device call per image from per-thread streams; here the
+// executor threads only run the Huffman host stage, and the last one to finish issues ONE H2D copy and ONE launch per
+// kernel for the whole batch (two batch pages alternate so the next batch's host stage overlaps the GPU).
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "decoder_core.h"
+#include "plugin_common.h"
+#include "plugin_objects.h"
+
+namespace hipjpeg_ext {
+
+using hipjpeg::DecodeBatch;
+using hipjpeg::MemoryHooks;
+
+namespace {
+
+nvimgcodecProcessingStatus_t to_processing_status(hipjpegStatus_t s)
+{
+    switch (s) {
+    case HIPJPEG_STATUS_SUCCESS: return NVIMGCODEC_PROCESSING_STATUS_SUCCESS;
+    case HIPJPEG_STATUS_UNSUPPORTED: return NVIMGCODEC_PROCESSING_STATUS_CODESTREAM_UNSUPPORTED;
+    case HIPJPEG_STATUS_BAD_JPEG:
+    case HIPJPEG_STATUS_TRUNCATED:
+    case HIPJPEG_STATUS_CORRUPT: return NVIMGCODEC_PROCESSING_STATUS_IMAGE_CORRUPTED;
+    default: return NVIMGCODEC_PROCESSING_STATUS_FAIL;
+    }
+}
+
+// nvimgcodecSampleFormat_t -> our output layout (reference extensions/nvjpeg/type_convert.cpp:19-41)
+bool map_sample_format(nvimgcodecSampleFormat_t f, hipjpegOutputFormat_t* out)
+{
+    switch (f) {
+    case NVIMGCODEC_SAMPLEFORMAT_P_UNCHANGED: *out = HIPJPEG_OUTPUT_YUV_PLANAR; return true;
+    case NVIMGCODEC_SAMPLEFORMAT_I_UNCHANGED: *out = HIPJPEG_OUTPUT_RGBI; return true;
+    case NVIMGCODEC_SAMPLEFORMAT_P_RGB: *out = HIPJPEG_OUTPUT_RGB_PLANAR; return true;
+    case NVIMGCODEC_SAMPLEFORMAT_I_RGB: *out = HIPJPEG_OUTPUT_RGBI; return true;
+    case NVIMGCODEC_SAMPLEFORMAT_P_BGR: *out = HIPJPEG_OUTPUT_BGR_PLANAR; return true;
+    case NVIMGCODEC_SAMPLEFORMAT_I_BGR: *out = HIPJPEG_OUTPUT_BGRI; return true;
+    case NVIMGCODEC_SAMPLEFORMAT_P_Y: *out = HIPJPEG_OUTPUT_Y; return true;
+    case NVIMGCODEC_SAMPLEFORMAT_P_YUV: *out = HIPJPEG_OUTPUT_YUV_PLANAR; return true;
+    default: return false;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ Decoder object
+class HipJpegDecoder {
+public:
+    HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgcodecExecutionParams_t* ep, const char* options);
+    ~HipJpegDecoder();
+    bool ok() const { return ok_; }
+
+    nvimgcodecStatus_t canDecode(nvimgcodecProcessingStatus_t* status, nvimgcodecCodeStreamDesc_t** code_streams,
+                                 nvimgcodecImageDesc_t** images, int batch_size, const nvimgcodecDecodeParams_t* params);
+    nvimgcodecStatus_t decode(nvimgcodecCodeStreamDesc_t** code_streams, nvimgcodecImageDesc_t** images, int batch_size,
+                              const nvimgcodecDecodeParams_t* params);
+
+private:
+    struct Sample {
+        nvimgcodecCodeStreamDesc_t* code_stream = nullptr;
+        nvimgcodecImageDesc_t* image = nullptr;
+        void* user_stream = nullptr;
+        const uint8_t* data = nullptr;
+        size_t size = 0;
+        void* mapped = nullptr;           // non-null if io_stream->map succeeded (must be unmapped)
+        std::vector<uint8_t> owned;       // bitstream copy when map() is not available
+        nvimgcodecProcessingStatus_t early_status = NVIMGCODEC_PROCESSING_STATUS_SUCCESS;  // set when the sample is rejected before planning
+    };
+    struct Job {
+        explicit Job(int device, const MemoryHooks* hooks) : batch(device, hooks) {}
+        DecodeBatch batch;
+        std::vector<Sample> samples;
+        std::vector<hipjpegStatus_t> statuses;
+        std::atomic<int> remaining{0};
+        std::mutex m;
+        std::condition_variable cv;
+        bool busy = false;
+        HipJpegDecoder* owner = nullptr;
+        hipEvent_t event = nullptr;
+    };
+
+    void single_can_decode(nvimgcodecProcessingStatus_t* status, nvimgcodecCodeStreamDesc_t* cs, nvimgcodecImageDesc_t* image,
+                           const nvimgcodecDecodeParams_t* params);
+    static void host_task(int tid, int sample_idx, void* ctx);
+    void finish(Job* job);
+    void release_inputs(Job* job);
+
+    const nvimgcodecFrameworkDesc_t* fw_;
+    const nvimgcodecExecutionParams_t* ep_;
+    MemoryHooks hooks_;
+    bool fancy_ = true;  // same default as the reference plugins (nvjpeg_utils.cpp:46, libjpeg_turbo_decoder.cpp:253)
+    bool ok_ = false;
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    std::unique_ptr<Job> jobs_[2];
+    int next_job_ = 0;
+    std::mutex decode_mutex_;  // decode() may be entered from the framework's worker thread and from a fallback re-dispatch
+};
+
+HipJpegDecoder::HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgcodecExecutionParams_t* ep, const char* options)
+    : fw_(fw), ep_(ep), device_(ep->device_id)
+{
+    for_each_option(options, kDecoderId, [&](const std::string& key, const std::string& value) {
+        std::istringstream v(value);
+        if (key == "fancy_upsampling") v >> fancy_;
+    });
+    if (ep->device_allocator && ep->device_allocator->device_malloc && ep->device_allocator->device_free) {
+        hooks_.device_malloc = reinterpret_cast<int (*)(void*, void**, size_t, void*)>(ep->device_allocator->device_malloc);
+        hooks_.device_free = reinterpret_cast<int (*)(void*, void*, size_t, void*)>(ep->device_allocator->device_free);
+        hooks_.device_ctx = ep->device_allocator->device_ctx;
+    }
+    if (ep->pinned_allocator && ep->pinned_allocator->pinned_malloc && ep->pinned_allocator->pinned_free) {
+        hooks_.pinned_malloc = reinterpret_cast<int (*)(void*, void**, size_t, void*)>(ep->pinned_allocator->pinned_malloc);
+        hooks_.pinned_free = reinterpret_cast<int (*)(void*, void*, size_t, void*)>(ep->pinned_allocator->pinned_free);
+        hooks_.pinned_ctx = ep->pinned_allocator->pinned_ctx;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_ < 0 || device_ >= count) {
+        HJ_LOG_ERROR(fw_, kDecoderId, "no usable HIP device " << device_ << " (found " << count << ")");
+        return;
+    }
+    if (hipSetDevice(device_) != hipSuccess || hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) {
+        HJ_LOG_ERROR(fw_, kDecoderId, "could not create a HIP stream on device " << device_);
+        return;
+    }
+    for (auto& j : jobs_) {
+        j.reset(new Job(device_, &hooks_));
+        j->owner = this;
+        if (hipEventCreateWithFlags(&j->event, hipEventDisableTiming) != hipSuccess) return;
+    }
+    ok_ = true;
+}
+
+HipJpegDecoder::~HipJpegDecoder()
+{
+    for (auto& j : jobs_) {
+        if (!j) continue;
+        std::unique_lock<std::mutex> lk(j->m);
+        j->cv.wait(lk, [&] { return !j->busy; });
+    }
+    if (stream_) {
+        (void)hipSetDevice(device_);
+        (void)hipStreamSynchronize(stream_);
+    }
+    for (auto& j : jobs_) {
+        if (j && j->event) (void)hipEventDestroy(j->event);
+        j.reset();
+    }
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void HipJpegDecoder::single_can_decode(nvimgcodecProcessingStatus_t* status, nvimgcodecCodeStreamDesc_t* cs, nvimgcodecImageDesc_t* image,
+                                       const nvimgcodecDecodeParams_t* params)
+{
+    *status = NVIMGCODEC_PROCESSING_STATUS_SUCCESS;
+    nvimgcodecJpegImageInfo_t jpeg_info{NVIMGCODEC_STRUCTURE_TYPE_JPEG_IMAGE_INFO, sizeof(nvimgcodecJpegImageInfo_t), nullptr,
+                                        NVIMGCODEC_JPEG_ENCODING_UNKNOWN};
+    nvimgcodecImageInfo_t cs_info;
+    memset(&cs_info, 0, sizeof cs_info);
+    cs_info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+    cs_info.struct_size = sizeof cs_info;
+    cs_info.struct_next = &jpeg_info;
+    if (cs->getImageInfo(cs->instance, &cs_info) != NVIMGCODEC_STATUS_SUCCESS) {
+        *status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+        return;
+    }
+    if (strcmp(cs_info.codec_name, "jpeg") != 0) {
+        *status = NVIMGCODEC_PROCESSING_STATUS_CODEC_UNSUPPORTED;
+        return;
+    }
+    const nvimgcodecJpegImageInfo_t* ji = find_in_chain<nvimgcodecJpegImageInfo_t>(cs_info.struct_next, NVIMGCODEC_STRUCTURE_TYPE_JPEG_IMAGE_INFO);
+    if (ji && ji->encoding != NVIMGCODEC_JPEG_ENCODING_UNKNOWN && ji->encoding != NVIMGCODEC_JPEG_ENCODING_BASELINE_DCT &&
+        ji->encoding != NVIMGCODEC_JPEG_ENCODING_EXTENDED_SEQUENTIAL_DCT_HUFFMAN && ji->encoding != NVIMGCODEC_JPEG_ENCODING_PROGRESSIVE_DCT_HUFFMAN) {
+        *status = NVIMGCODEC_PROCESSING_STATUS_ENCODING_UNSUPPORTED;
+        return;
+    }
+    // four-component streams (CMYK / YCCK) and 12-bit streams belong to another decoder in the chain
+    if (cs_info.color_spec == NVIMGCODEC_COLORSPEC_CMYK || cs_info.color_spec == NVIMGCODEC_COLORSPEC_YCCK ||
+        (cs_info.num_planes > 0 && cs_info.plane_info[0].sample_type != NVIMGCODEC_SAMPLE_DATA_TYPE_UINT8)) {
+        *status = NVIMGCODEC_PROCESSING_STATUS_CODESTREAM_UNSUPPORTED;
+        return;
+    }
+    if (cs_info.chroma_subsampling == NVIMGCODEC_SAMPLING_UNSUPPORTED) *status |= NVIMGCODEC_PROCESSING_STATUS_SAMPLING_UNSUPPORTED;
+
+    nvimgcodecImageInfo_t info;
+    memset(&info, 0, sizeof info);
+    info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+    info.struct_size = sizeof info;
+    if (image->getImageInfo(image->instance, &info) != NVIMGCODEC_STATUS_SUCCESS) {
+        *status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+        return;
+    }
+    switch (info.color_spec) {
+    case NVIMGCODEC_COLORSPEC_UNCHANGED:
+    case NVIMGCODEC_COLORSPEC_SRGB:
+    case NVIMGCODEC_COLORSPEC_GRAY:
+    case NVIMGCODEC_COLORSPEC_SYCC: break;
+    default: *status |= NVIMGCODEC_PROCESSING_STATUS_COLOR_SPEC_UNSUPPORTED;
+    }
+    hipjpegOutputFormat_t fmt;
+    if (!map_sample_format(info.sample_format, &fmt)) {
+        *status |= NVIMGCODEC_PROCESSING_STATUS_SAMPLE_FORMAT_UNSUPPORTED;
+    } else {
+        const bool interleaved = fmt == HIPJPEG_OUTPUT_RGBI || fmt == HIPJPEG_OUTPUT_BGRI;
+        const bool planar_rgb = fmt == HIPJPEG_OUTPUT_RGB_PLANAR || fmt == HIPJPEG_OUTPUT_BGR_PLANAR;
+        if (interleaved) {
+            if (info.num_planes != 1) *status |= NVIMGCODEC_PROCESSING_STATUS_NUM_PLANES_UNSUPPORTED;
+            if (info.plane_info[0].num_channels != 3) *status |= NVIMGCODEC_PROCESSING_STATUS_NUM_CHANNELS_UNSUPPORTED;
+        } else if (planar_rgb) {
+            if (info.num_planes != 3) *status |= NVIMGCODEC_PROCESSING_STATUS_NUM_PLANES_UNSUPPORTED;
+        } else if (fmt == HIPJPEG_OUTPUT_Y) {
+            if (info.num_planes != 1) *status |= NVIMGCODEC_PROCESSING_STATUS_NUM_PLANES_UNSUPPORTED;
+            if (info.plane_info[0].num_channels != 1) *status |= NVIMGCODEC_PROCESSING_STATUS_NUM_CHANNELS_UNSUPPORTED;
+        } else if (info.num_planes != cs_info.num_planes) {
+            *status |= NVIMGCODEC_PROCESSING_STATUS_NUM_PLANES_UNSUPPORTED;
+        }
+    }
+    for (uint32_t p = 0; p < info.num_planes && p < NVIMGCODEC_MAX_NUM_PLANES; ++p)
+        if (info.plane_info[p].sample_type != NVIMGCODEC_SAMPLE_DATA_TYPE_UINT8) *status |= NVIMGCODEC_PROCESSING_STATUS_SAMPLE_TYPE_UNSUPPORTED;
+    // Not implemented in-kernel yet: region of interest and EXIF rotation.  Reporting them here sends the sample to the
+    // next decoder in the priority chain (reference src/decoder_worker.cpp:275-296).
+    if (params->enable_roi && info.region.ndim > 0) *status |= NVIMGCODEC_PROCESSING_STATUS_ROI_UNSUPPORTED;
+    if (params->apply_exif_orientation && (info.orientation.rotated != 0 || info.orientation.flip_x || info.orientation.flip_y))
+        *status |= NVIMGCODEC_PROCESSING_STATUS_ORIENTATION_UNSUPPORTED;
+}
+
+nvimgcodecStatus_t HipJpegDecoder::canDecode(nvimgcodecProcessingStatus_t* status, nvimgcodecCodeStreamDesc_t** code_streams,
+                                             nvimgcodecImageDesc_t** images, int batch_size, const nvimgcodecDecodeParams_t* params)
+{
+    if (!status || !code_streams || !images || !params) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
+    for (int i = 0; i < batch_size; i++) {
+        if (!code_streams[i] || !images[i]) {
+            status[i] = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+            continue;
+        }
+        single_can_decode(&status[i], code_streams[i], images[i], params);
+    }
+    return NVIMGCODEC_STATUS_SUCCESS;
+}
+
+void HipJpegDecoder::release_inputs(Job* job)
+{
+    for (Sample& s : job->samples) {
+        if (s.mapped) {
+            nvimgcodecIoStreamDesc_t* io = s.code_stream->io_stream;
+            io->unmap(io->instance, s.mapped, s.size);
+            s.mapped = nullptr;
+        }
+    }
+}
+
+void HipJpegDecoder::host_task(int /*tid*/, int sample_idx, void* ctx)
+{
+    Job* job = static_cast<Job*>(ctx);
+    job->batch.entropy_stage(sample_idx);
+    if (job->remaining.fetch_sub(1) == 1) job->owner->finish(job);
+}
+
+// Runs on whichever thread finished the last host task of the batch.
+void HipJpegDecoder::finish(Job* job)
+{
+    const int n = (int)job->samples.size();
+    bool gpu_ok = hipSetDevice(device_) == hipSuccess;
+    job->batch.finalize(job->statuses.data());
+    if (gpu_ok) gpu_ok = job->batch.transfer(stream_) == HIPJPEG_STATUS_SUCCESS;
+    if (gpu_ok) gpu_ok = job->batch.launch(stream_) == HIPJPEG_STATUS_SUCCESS;
+    if (gpu_ok) gpu_ok = hipEventRecord(job->event, stream_) == hipSuccess;
+    release_inputs(job);
+    for (int i = 0; i < n; i++) {
+        Sample& s = job->samples[i];
+        nvimgcodecProcessingStatus_t ps = s.early_status;
+        if (ps == NVIMGCODEC_PROCESSING_STATUS_SUCCESS) {
+            ps = gpu_ok ? to_processing_status(job->statuses[i]) : (nvimgcodecProcessingStatus_t)NVIMGCODEC_PROCESSING_STATUS_FAIL;
+            // the consumer's stream must not run ahead of the decode (reference cuda_decoder.cpp:552-556)
+            if (ps == NVIMGCODEC_PROCESSING_STATUS_SUCCESS &&
+                hipStreamWaitEvent((hipStream_t)s.user_stream, job->event, 0) != hipSuccess)
+                ps = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+        }
+        if (ps != NVIMGCODEC_PROCESSING_STATUS_SUCCESS)
+            HJ_LOG_WARNING(fw_, kDecoderId, "sample " << i << " not decoded, processing status 0x" << std::hex << ps);
+        s.image->imageReady(s.image->instance, ps);
+    }
+    {
+        std::lock_guard<std::mutex> lk(job->m);
+        job->busy = false;
+    }
+    job->cv.notify_all();
+}
+
+nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_streams, nvimgcodecImageDesc_t** images, int batch_size,
+                                          const nvimgcodecDecodeParams_t* params)
+{
+    if (!code_streams || !images || !params) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
+    if (batch_size < 1) return NVIMGCODEC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> serial(decode_mutex_);
+    Job* job = jobs_[next_job_].get();
+    next_job_ ^= 1;
+    {
+        std::unique_lock<std::mutex> lk(job->m);
+        job->cv.wait(lk, [&] { return !job->busy; });
+        job->busy = true;
+    }
+    const int n = batch_size;
+    job->samples.assign(n, Sample());
+    job->statuses.assign(n, HIPJPEG_STATUS_SUCCESS);
+    std::vector<const uint8_t*> data(n, nullptr);
+    std::vector<size_t> sizes(n, 0);
+    std::vector<hipjpegOutput_t> outs(n);
+    std::vector<hipjpegOutputFormat_t> formats(n, HIPJPEG_OUTPUT_RGBI);
+    memset(outs.data(), 0, sizeof(hipjpegOutput_t) * n);
+
+    for (int i = 0; i < n; i++) {
+        Sample& s = job->samples[i];
+        s.code_stream = code_streams[i];
+        s.image = images[i];
+        nvimgcodecImageInfo_t info;
+        memset(&info, 0, sizeof info);
+        info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+        info.struct_size = sizeof info;
+        if (s.image->getImageInfo(s.image->instance, &info) != NVIMGCODEC_STATUS_SUCCESS) {
+            s.early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+            continue;
+        }
+        s.user_stream = info.cuda_stream;
+        if (info.buffer_kind != NVIMGCODEC_IMAGE_BUFFER_KIND_STRIDED_DEVICE || !info.buffer) {
+            // the framework bounces host buffers for GPU backends (reference src/work.h:144-169); a host pointer here is a caller bug
+            s.early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+            continue;
+        }
+        if (!map_sample_format(info.sample_format, &formats[i])) {
+            s.early_status = NVIMGCODEC_PROCESSING_STATUS_SAMPLE_FORMAT_UNSUPPORTED;
+            continue;
+        }
+        // planes are laid out back to back inside `buffer` (reference cuda_decoder.cpp:532-538)
+        uint8_t* p = static_cast<uint8_t*>(info.buffer);
+        for (uint32_t pl = 0; pl < info.num_planes && pl < 3; pl++) {
+            outs[i].plane[pl] = p;
+            outs[i].pitch[pl] = (uint32_t)info.plane_info[pl].row_stride;
+            p += info.plane_info[pl].row_stride * info.plane_info[pl].height;
+        }
+        // bitstream: zero-copy map when the stream offers it, else read into our own buffer (cuda_decoder.cpp:480-500)
+        nvimgcodecIoStreamDesc_t* io = s.code_stream->io_stream;
+        size_t size = 0;
+        if (io->size(io->instance, &size) != NVIMGCODEC_STATUS_SUCCESS || size == 0) {
+            s.early_status = NVIMGCODEC_PROCESSING_STATUS_IMAGE_CORRUPTED;
+            continue;
+        }
+        void* mapped = nullptr;
+        if (io->map(io->instance, &mapped, 0, size) == NVIMGCODEC_STATUS_SUCCESS && mapped) {
+            s.mapped = mapped;
+            s.data = static_cast<const uint8_t*>(mapped);
+        } else {
+            s.owned.resize(size);
+            size_t got = 0;
+            io->seek(io->instance, 0, SEEK_SET);
+            if (io->read(io->instance, &got, s.owned.data(), size) != NVIMGCODEC_STATUS_SUCCESS || got != size) {
+                s.early_status = NVIMGCODEC_PROCESSING_STATUS_IMAGE_CORRUPTED;
+                continue;
+            }
+            s.data = s.owned.data();
+        }
+        s.size = size;
+        data[i] = s.data;
+        sizes[i] = size;
+    }
+
+    bool planned = hipSetDevice(device_) == hipSuccess &&
+                   job->batch.plan(data.data(), sizes.data(), n, outs.data(), HIPJPEG_OUTPUT_RGBI, fancy_ ? HIPJPEG_FLAG_FANCY_UPSAMPLING : 0u,
+                                   job->statuses.data(), formats.data()) == HIPJPEG_STATUS_SUCCESS;
+    if (!planned) {
+        // batch-level failure: every sample is reported failed and an error code is returned (cuda_decoder.cpp:602-608)
+        release_inputs(job);
+        for (int i = 0; i < n; i++) images[i]->imageReady(images[i]->instance, NVIMGCODEC_PROCESSING_STATUS_FAIL);
+        {
+            std::lock_guard<std::mutex> lk(job->m);
+            job->busy = false;
+        }
+        job->cv.notify_all();
+        HJ_LOG_ERROR(fw_, kDecoderId, "could not plan the decode batch on device " << device_);
+        return NVIMGCODEC_STATUS_EXTENSION_EXECUTION_FAILED;
+    }
+
+    job->remaining.store(n);
+    nvimgcodecExecutorDesc_t* ex = ep_->executor;
+    if (n == 1 || !ex) {
+        for (int i = 0; i < n; i++) host_task(0, i, job);  // single image: run inline like the reference (:565-566)
+    } else {
+        for (int i = 0; i < n; i++) {
+            if (ex->launch(ex->instance, device_, i, job, &HipJpegDecoder::host_task) != NVIMGCODEC_STATUS_SUCCESS) host_task(0, i, job);
+        }
+    }
+    return NVIMGCODEC_STATUS_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------ plugin (factory) object
+HipJpegDecoderPlugin::HipJpegDecoderPlugin(const nvimgcodecFrameworkDesc_t* framework)
+    : desc_{NVIMGCODEC_STRUCTURE_TYPE_DECODER_DESC, sizeof(nvimgcodecDecoderDesc_t), nullptr, this, kDecoderId, "jpeg",
+            NVIMGCODEC_BACKEND_KIND_HYBRID_CPU_GPU, static_create, static_destroy, static_can_decode, static_decode},
+      framework_(framework)
+{
+}
+
+nvimgcodecStatus_t HipJpegDecoderPlugin::static_create(void* instance, nvimgcodecDecoder_t* decoder, const nvimgcodecExecutionParams_t* exec_params,
+                                                       const char* options)
+{
+    try {
+        if (!instance || !decoder || !exec_params) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
+        auto* self = static_cast<HipJpegDecoderPlugin*>(instance);
+        if (exec_params->device_id == NVIMGCODEC_DEVICE_CPU_ONLY) return NVIMGCODEC_STATUS_INVALID_PARAMETER;
+        std::unique_ptr<HipJpegDecoder> d(new HipJpegDecoder(self->framework_, exec_params, options));
+        if (!d->ok()) return NVIMGCODEC_STATUS_EXTENSION_CUDA_CALL_ERROR;  // no silent CPU fallback: without a GPU this decoder does not exist
+        *decoder = reinterpret_cast<nvimgcodecDecoder_t>(d.release());
+        return NVIMGCODEC_STATUS_SUCCESS;
+    } catch (...) {
+        return NVIMGCODEC_STATUS_EXTENSION_INTERNAL_ERROR;
+    }
+}
+
+nvimgcodecStatus_t HipJpegDecoderPlugin::static_destroy(nvimgcodecDecoder_t decoder)
+{
+    try {
+        if (!decoder) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
+        delete reinterpret_cast<HipJpegDecoder*>(decoder);
+        return NVIMGCODEC_STATUS_SUCCESS;
+    } catch (...) {
+        return NVIMGCODEC_STATUS_EXTENSION_INTERNAL_ERROR;
+    }
+}
+
+nvimgcodecStatus_t HipJpegDecoderPlugin::static_can_decode(nvimgcodecDecoder_t decoder, nvimgcodecProcessingStatus_t* status,
+                                                           nvimgcodecCodeStreamDesc_t** code_streams, nvimgcodecImageDesc_t** images, int batch_size,
+                                                           const nvimgcodecDecodeParams_t* params)
+{
+    try {
+        if (!decoder) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
+        return reinterpret_cast<HipJpegDecoder*>(decoder)->canDecode(status, code_streams, images, batch_size, params);
+    } catch (...) {
+        return NVIMGCODEC_STATUS_EXTENSION_INTERNAL_ERROR;
+    }
+}
+
+nvimgcodecStatus_t HipJpegDecoderPlugin::static_decode(nvimgcodecDecoder_t decoder, nvimgcodecCodeStreamDesc_t** code_streams,
+                                                       nvimgcodecImageDesc_t** images, int batch_size, const nvimgcodecDecodeParams_t* params)
+{
+    try {
+        if (!decoder) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
+        return reinterpret_cast<HipJpegDecoder*>(decoder)->decode(code_streams, images, batch_size, params);
+    } catch (...) {
+        // never let an exception cross the C boundary; nothing was scheduled if we got here before the launch loop
+        return NVIMGCODEC_STATUS_EXTENSION_INTERNAL_ERROR;
+    }
+}
+
+}  // namespace hipjpeg_ext

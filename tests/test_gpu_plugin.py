@@ -1,0 +1,237 @@
+"""GPU tests of the drop-in boundary: the same pixels, but reached the way an nvImageCodec application reaches them --
+nvimgcodecInstanceCreate -> code streams -> images -> nvimgcodecDecoderDecode -> priority chain -> hipjpeg_decoder plugin
+(function table of include/nvimgcodec_abi.h).  Bit-exact against the golden vectors / oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, load_decode_case
+from fake_plugin import FakeDecoderPlugin
+from nvimagecodec_amd import _native
+from nvimagecodec_amd import abi as A
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _f:
+    _M = json.load(_f)
+
+
+def _case(name):
+    return load_decode_case(next(e for e in _M["decode"] if e["name"] == name))
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_python_decoder_mirror_decodes_goldens(torch_mod):
+    from nvimagecodec_amd import api
+    names = ["s50x37_420_base_q90", "s33x65_422_prog_q50", "s64x48_444_base_q90", "r130x70_420_prog_rst7", "c1_640x480_444_base_q90",
+             "c2_1920x1080_420_base_q90", "o64x48_411_base_q90"]
+    cases = [_case(n) for n in names]
+    with api.Decoder(max_num_cpu_threads=4) as dec:
+        imgs = dec.decode([c[0] for c in cases])
+        torch_mod.cuda.synchronize()
+        for n, (jpeg, rgb), im in zip(names, cases, imgs):
+            assert im is not None, n
+            assert im.buffer_kind == api.ImageBufferKind.STRIDED_DEVICE and im.dtype == np.uint8
+            got = im.cpu()
+            ref = rgb if rgb is not None else oracle.decode(jpeg)
+            assert got.shape == ref.shape
+            assert np.array_equal(np.asarray(got._array), ref), n
+            assert im.__cuda_array_interface__["shape"] == ref.shape
+        # single bytes object -> single Image; gray request -> P_Y
+        one = dec.decode(cases[0][0], params=api.DecodeParams(color_spec=api.ColorSpec.GRAY))
+        torch_mod.cuda.synchronize()
+        assert np.array_equal(one.cpu()._array[:, :, 0], oracle.decode(cases[0][0], oracle.FMT_GRAY))
+        # garbage in a batch: that entry is None, neighbours fine
+        res = dec.decode([cases[1][0], b"garbage", cases[2][0]])
+        assert res[1] is None and res[0] is not None and res[2] is not None
+
+
+def test_read_from_file_uses_read_fallback(torch_mod, tmp_path):
+    """File streams return NULL from map() (reference src/io_stream.h:170) so the plugin must read() the bitstream."""
+    from nvimagecodec_amd import api
+    jpeg, rgb = _case("r130x70_444_base_rst1")
+    p = tmp_path / "x.jpg"
+    p.write_bytes(jpeg)
+    with api.Decoder() as dec:
+        im = dec.read(str(p))
+        torch_mod.cuda.synchronize()
+        assert np.array_equal(im.cpu()._array, rgb)
+
+
+def _c_api_decode(lib, inst, dec, jpeg, h, w, fmt, planes, channels, buffer_ptr, pitch, kind, stream=0, params=None):
+    arr = np.frombuffer(jpeg, dtype=np.uint8)
+    cs = C.c_void_p()
+    assert lib.nvimgcodecCodeStreamCreateFromHostMem(inst, C.byref(cs), arr.ctypes.data, arr.size) == 0
+    info = A.init(A.ImageInfo, A.ST_IMAGE_INFO, sample_format=fmt, color_spec=A.COLORSPEC_SRGB, num_planes=planes, buffer=buffer_ptr,
+                  buffer_size=pitch * h * planes, buffer_kind=kind, cuda_stream=stream)
+    for p in range(planes):
+        pi = info.plane_info[p]
+        pi.width, pi.height, pi.row_stride, pi.num_channels, pi.sample_type = w, h, pitch, channels, A.SAMPLE_DATA_TYPE_UINT8
+    im = C.c_void_p()
+    assert lib.nvimgcodecImageCreate(inst, C.byref(im), C.byref(info)) == 0
+    dp = params or A.init(A.DecodeParams, A.ST_DECODE_PARAMS)
+    fut = C.c_void_p()
+    assert lib.nvimgcodecDecoderDecode(dec, (C.c_void_p * 1)(cs), (C.c_void_p * 1)(im), 1, C.byref(dp), C.byref(fut)) == 0
+    assert lib.nvimgcodecFutureWaitForAll(fut) == 0
+    st = (C.c_uint32 * 1)()
+    n = C.c_size_t()
+    lib.nvimgcodecFutureGetProcessingStatus(fut, st, C.byref(n))
+    lib.nvimgcodecFutureDestroy(fut)
+    lib.nvimgcodecImageDestroy(im)
+    lib.nvimgcodecCodeStreamDestroy(cs)
+    return st[0]
+
+
+def _setup(lib, extra_plugins=(), device_id=0, backends=None, allocators=None):
+    ci = A.init(A.InstanceCreateInfo, A.ST_INSTANCE_CREATE_INFO, load_builtin_modules=1, load_extension_modules=1)
+    inst = C.c_void_p()
+    assert lib.nvimgcodecInstanceCreate(C.byref(inst), C.byref(ci)) == 0
+    for p in extra_plugins:
+        assert lib.nvimgcodecExtensionCreate(inst, None, C.byref(p.ext_desc)) == 0
+    ep = A.init(A.ExecutionParams, A.ST_EXECUTION_PARAMS, device_id=device_id, max_num_cpu_threads=2)
+    if allocators:
+        ep.device_allocator, ep.pinned_allocator = C.pointer(allocators[0]), C.pointer(allocators[1])
+    dec = C.c_void_p()
+    assert lib.nvimgcodecDecoderCreate(inst, C.byref(dec), C.byref(ep), b"") == 0
+    return inst, dec
+
+
+def test_host_output_buffer_is_bounced(torch_mod):
+    """A host output buffer with a GPU backend: the framework decodes into a device bounce buffer and copies back
+    (reference src/work.h:144-190)."""
+    lib = A.bind(_native.load())
+    inst, dec = _setup(lib)
+    jpeg, rgb = _case("s50x37_420_base_q90")
+    buf = np.zeros((37, 50, 3), dtype=np.uint8)
+    st = _c_api_decode(lib, inst, dec, jpeg, 37, 50, A.SAMPLEFORMAT_I_RGB, 1, 3, buf.ctypes.data, 150, A.BUFFER_KIND_STRIDED_HOST)
+    assert st == A.PS_SUCCESS
+    assert np.array_equal(buf, rgb)
+    lib.nvimgcodecDecoderDestroy(dec)
+    lib.nvimgcodecInstanceDestroy(inst)
+
+
+def test_planar_bgr_and_user_stream(torch_mod):
+    torch = torch_mod
+    lib = A.bind(_native.load())
+    inst, dec = _setup(lib)
+    jpeg, rgb = _case("r130x70_420_base_rst7")
+    side = torch.cuda.Stream()
+    out = torch.zeros((3, 70, 130), dtype=torch.uint8, device="cuda")
+    st = _c_api_decode(lib, inst, dec, jpeg, 70, 130, A.SAMPLEFORMAT_P_BGR, 3, 1, out.data_ptr(), 130, A.BUFFER_KIND_STRIDED_DEVICE,
+                       stream=side.cuda_stream)
+    assert st == A.PS_SUCCESS
+    # the plugin made `side` wait for the decode (cuda_decoder.cpp:552-556): work queued on it afterwards sees the pixels
+    with torch.cuda.stream(side):
+        copy = out.clone()
+    side.synchronize()
+    assert np.array_equal(copy.cpu().numpy(), rgb[:, :, ::-1].transpose(2, 0, 1))
+    lib.nvimgcodecDecoderDestroy(dec)
+    lib.nvimgcodecInstanceDestroy(inst)
+
+
+def test_unsupported_requests_fall_back_to_next_decoder(torch_mod):
+    """ROI and CMYK-coloured requests are outside the HIP decoder: canDecode says so and the chain moves on, exactly like
+    nvjpeg -> libjpeg_turbo in the reference."""
+    torch = torch_mod
+    lib = A.bind(_native.load())
+    cpu = FakeDecoderPlugin("cpu_fallback", priority=A.PRIORITY_NORMAL, fill=0x42)
+    inst, dec = _setup(lib, extra_plugins=[cpu])
+    jpeg, rgb = _case("s64x48_420_base_q90")
+    arr = np.frombuffer(jpeg, dtype=np.uint8)
+    cs = C.c_void_p()
+    assert lib.nvimgcodecCodeStreamCreateFromHostMem(inst, C.byref(cs), arr.ctypes.data, arr.size) == 0
+    buf = np.zeros((24, 32, 3), dtype=np.uint8)
+    info = A.init(A.ImageInfo, A.ST_IMAGE_INFO, sample_format=A.SAMPLEFORMAT_I_RGB, color_spec=A.COLORSPEC_SRGB, num_planes=1,
+                  buffer=buf.ctypes.data, buffer_size=buf.nbytes, buffer_kind=A.BUFFER_KIND_STRIDED_HOST)
+    pi = info.plane_info[0]
+    pi.width, pi.height, pi.row_stride, pi.num_channels, pi.sample_type = 32, 24, 96, 3, A.SAMPLE_DATA_TYPE_UINT8
+    info.region.ndim = 2
+    info.region.start[0], info.region.start[1], info.region.end[0], info.region.end[1] = 8, 16, 32, 48
+    im = C.c_void_p()
+    assert lib.nvimgcodecImageCreate(inst, C.byref(im), C.byref(info)) == 0
+    dp = A.init(A.DecodeParams, A.ST_DECODE_PARAMS, enable_roi=1)
+    fut = C.c_void_p()
+    assert lib.nvimgcodecDecoderDecode(dec, (C.c_void_p * 1)(cs), (C.c_void_p * 1)(im), 1, C.byref(dp), C.byref(fut)) == 0
+    lib.nvimgcodecFutureWaitForAll(fut)
+    st = (C.c_uint32 * 1)()
+    n = C.c_size_t()
+    lib.nvimgcodecFutureGetProcessingStatus(fut, st, C.byref(n))
+    lib.nvimgcodecFutureDestroy(fut)
+    assert st[0] == A.PS_SUCCESS and buf.flat[0] == 0x42 and cpu.count("decode") == 1
+    # canDecode API says the same thing when the format is forced
+    out = (C.c_uint32 * 1)()
+    lib.nvimgcodecImageDestroy(im)
+    lib.nvimgcodecCodeStreamDestroy(cs)
+    lib.nvimgcodecDecoderDestroy(dec)
+    lib.nvimgcodecInstanceDestroy(inst)
+
+
+def test_cpu_only_device_is_refused_and_custom_allocators_are_used(torch_mod):
+    torch = torch_mod
+    lib = A.bind(_native.load())
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipHostFree.argtypes = [C.c_void_p]
+    calls = {"dev": 0, "pin": 0, "devfree": 0, "pinfree": 0}
+
+    def dmalloc(ctx, pp, size, stream):
+        calls["dev"] += 1
+        return hip.hipMalloc(pp, size)
+
+    def dfree(ctx, p, size, stream):
+        calls["devfree"] += 1
+        return hip.hipFree(p)
+
+    def pmalloc(ctx, pp, size, stream):
+        calls["pin"] += 1
+        return hip.hipHostMalloc(pp, size, 0)
+
+    def pfree(ctx, p, size, stream):
+        calls["pinfree"] += 1
+        return hip.hipHostFree(p)
+
+    cbs = [A.DeviceMalloc(dmalloc), A.DeviceFree(dfree), A.DeviceMalloc(pmalloc), A.DeviceFree(pfree)]
+    da = A.init(A.DeviceAllocator, A.ST_DEVICE_ALLOCATOR, device_malloc=cbs[0], device_free=cbs[1])
+    pa = A.init(A.PinnedAllocator, A.ST_PINNED_ALLOCATOR, pinned_malloc=cbs[2], pinned_free=cbs[3])
+    inst, dec = _setup(lib, allocators=(da, pa))
+    jpeg, rgb = _case("s64x48_444_base_q90")
+    out = torch.zeros((48, 64, 3), dtype=torch.uint8, device="cuda")
+    st = _c_api_decode(lib, inst, dec, jpeg, 48, 64, A.SAMPLEFORMAT_I_RGB, 1, 3, out.data_ptr(), 192, A.BUFFER_KIND_STRIDED_DEVICE)
+    torch.cuda.synchronize()
+    assert st == A.PS_SUCCESS and np.array_equal(out.cpu().numpy(), rgb)
+    assert calls["dev"] >= 1 and calls["pin"] >= 1
+    lib.nvimgcodecDecoderDestroy(dec)
+    assert calls["devfree"] == calls["dev"] and calls["pinfree"] == calls["pin"]
+    lib.nvimgcodecInstanceDestroy(inst)
+    # device_id = CPU_ONLY: a GPU plugin must refuse to be created (cuda_decoder.cpp:272-273); nothing else registered -> no decoder
+    inst, dec = _setup(lib, device_id=A.DEVICE_CPU_ONLY)
+    buf = np.zeros((48, 64, 3), dtype=np.uint8)
+    st = _c_api_decode(lib, inst, dec, jpeg, 48, 64, A.SAMPLEFORMAT_I_RGB, 1, 3, buf.ctypes.data, 192, A.BUFFER_KIND_STRIDED_HOST)
+    assert st != A.PS_SUCCESS
+    lib.nvimgcodecDecoderDestroy(dec)
+    lib.nvimgcodecInstanceDestroy(inst)
+
+
+def test_many_batches_back_to_back_reuse_pages(torch_mod):
+    """Alternating batch pages + executor threads: 6 consecutive batches of 24 mixed images stay bit-exact."""
+    from nvimagecodec_amd import api
+    entries = [e for e in _M["decode"] if e["pixels"]][:24]
+    cases = [load_decode_case(e) for e in entries]
+    with api.Decoder(max_num_cpu_threads=6) as dec:
+        for rep in range(6):
+            imgs = dec.decode([c[0] for c in cases])
+            torch_mod.cuda.synchronize()
+            for e, c, im in zip(entries, cases, imgs):
+                assert np.array_equal(im.cpu()._array, c[1]), (rep, e["name"])
