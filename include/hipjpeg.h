@@ -124,6 +124,44 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handl
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchStats(hipjpegHandle_t handle, int32_t num_units[3], uint64_t* coef_bytes,
                                                     uint64_t* output_bytes);
 
+/* ---- encode: RGB -> baseline JPEG (replaces nvjpegEncodeImage + nvjpegEncodeRetrieveBitstream,
+ *      reference extensions/nvjpeg/cuda_encoder.cpp:336-388) ---- */
+typedef struct {
+    const void* plane[3]; /* device pointers; interleaved / gray input uses plane[0] only */
+    uint32_t pitch[3];
+    int32_t width, height;
+} hipjpegEncodeInput_t;
+
+typedef struct {
+    int32_t quality;           /* 1..100, libjpeg quality scaling of the Annex-K tables */
+    int32_t subsampling;       /* hipjpegChromaSubsampling_t of the OUTPUT stream (GRAY = single component) */
+    int32_t input_format;      /* HIPJPEG_OUTPUT_RGBI / BGRI / RGB_PLANAR / BGR_PLANAR / Y (gray plane) */
+    int32_t restart_interval;  /* MCUs per restart interval, 0 = none */
+    int32_t optimized_huffman; /* 0 = Annex-K tables, 1 = per-image optimal tables (two-pass) */
+} hipjpegEncodeParams_t;
+
+/* Device stage only: colour conversion + downsampling + FDCT + quantization for the whole batch (asynchronous). */
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchDevice(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs,
+                                                     const hipjpegEncodeParams_t* params, int batch_size, hipjpegStatus_t* statuses, void* stream);
+/* Re-launch the kernel of the prepared batch (bench.py times this). */
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchRelaunch(hipjpegHandle_t handle, void* stream);
+/* D2H of the quantized coefficients, then Huffman coding + marker writing on the host thread pool (blocking). */
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchHost(hipjpegHandle_t handle, hipjpegStatus_t* statuses);
+/* Both of the above. */
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatch(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
+                                               int batch_size, hipjpegStatus_t* statuses, void* stream);
+/* Bitstream of image i of the last encoded batch; valid until the next encode call on this handle. */
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeGetBitstream(hipjpegHandle_t handle, int index, const uint8_t** data, size_t* length);
+/* Quantized coefficients of (image, component) after hipjpegEncodeBatchHost: zigzag-ordered int16[64] blocks over the
+ * MCU-padded grid (only the real_w x real_h area is defined).  For tests and for callers with their own entropy coder. */
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeGetCoefficients(hipjpegHandle_t handle, int index, int component, const int16_t** coef,
+                                                         int32_t grid[4] /* blocks_w, blocks_h, real_w, real_h */);
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchStats(hipjpegHandle_t handle, int32_t* num_units, uint64_t* pixel_bytes, uint64_t* coef_bytes);
+/* Host-only: entropy-code given coefficient grids (zigzag order, MCU-padded grids as above) into a JFIF file.
+ * Returns HIPJPEG_STATUS_BUFFER_TOO_SMALL with *length = needed size if capacity is insufficient. */
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeFromCoefficientsHost(int32_t width, int32_t height, const hipjpegEncodeParams_t* params,
+                                                              const int16_t* const coef[3], uint8_t* out, size_t capacity, size_t* length);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,17 @@ class ImageInfo(ctypes.Structure):
         ("samp_w", ctypes.c_int32 * 4), ("samp_h", ctypes.c_int32 * 4), ("coef_bytes", ctypes.c_uint64)]
 
 
+class EncodeInput(ctypes.Structure):
+    _fields_ = [("plane", ctypes.c_void_p * 3), ("pitch", ctypes.c_uint32 * 3), ("width", ctypes.c_int32), ("height", ctypes.c_int32)]
+
+
+class EncodeParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("quality", "subsampling", "input_format", "restart_interval", "optimized_huffman")]
+
+
+CSS = {"444": 0, "422": 1, "420": 2, "440": 3, "411": 4, "410": 5, "gray": 6}
+
+
 class Output(ctypes.Structure):
     _fields_ = [("plane", ctypes.c_void_p * 3), ("pitch", ctypes.c_uint32 * 3)]
 
@@ -55,5 +66,13 @@ def load():
     L.hipjpegDecodeBatchDevice.argtypes = [vp, vp]
     L.hipjpegDecodeBatchDeviceKernel.argtypes = [vp, i32, vp]
     L.hipjpegDecodeBatchStats.argtypes = [vp, vp, vp, vp]
+    L.hipjpegEncodeBatchDevice.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.hipjpegEncodeBatchRelaunch.argtypes = [vp, vp]
+    L.hipjpegEncodeBatchHost.argtypes = [vp, vp]
+    L.hipjpegEncodeBatch.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.hipjpegEncodeGetBitstream.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.hipjpegEncodeGetCoefficients.argtypes = [vp, i32, i32, ctypes.POINTER(vp), vp]
+    L.hipjpegEncodeBatchStats.argtypes = [vp, vp, vp, vp]
+    L.hipjpegEncodeFromCoefficientsHost.argtypes = [i32, i32, ctypes.POINTER(EncodeParams), vp, vp, sz, ctypes.POINTER(sz)]
     _lib = L
     return L

@@ -1,0 +1,57 @@
+// encoder_core.h -- host-side planning, launch and entropy stage of one encode batch
+// (counterpart of decoder_core.h; reference flow extensions/nvjpeg/cuda_encoder.cpp:284-396).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/hipjpeg.h"
+#include "decoder_core.h"
+#include "encode_layout.h"
+#include "entropy_encode.h"
+
+namespace hipjpeg {
+
+struct PlannedEncode {
+    hipjpegStatus_t status = HIPJPEG_STATUS_SUCCESS;
+    EncodeGeometry geom;
+    hipjpegEncodeParams_t params{};
+    uint16_t qlum[64], qchr[64];
+    size_t coef_offset[3] = {0, 0, 0};  // byte offsets inside the coefficient area
+    std::vector<uint8_t> bitstream;
+};
+
+class EncodeBatch {
+public:
+    EncodeBatch(int device_id, const MemoryHooks* hooks);
+    ~EncodeBatch();
+    // Parse params, lay out device memory, upload descriptors and launch the forward kernel (asynchronous on `stream`).
+    hipjpegStatus_t device_stage(const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params, int n, hipjpegStatus_t* statuses,
+                                 void* stream);
+    hipjpegStatus_t relaunch(void* stream);
+    // Coefficients D2H (on the stream used by device_stage), wait, then Huffman + markers for image i.
+    hipjpegStatus_t fetch_coefficients();
+    void entropy_stage(int i);
+    int size() const { return (int)images_.size(); }
+    PlannedEncode& image(int i) { return images_[i]; }
+    const int16_t* host_coef(int i, int c) const;
+    int num_units() const { return (int)units_.size(); }
+    uint64_t pixel_bytes() const { return pixel_bytes_; }
+    uint64_t coef_bytes() const { return coef_bytes_; }
+
+private:
+    int device_id_;
+    Buffer pinned_desc_, device_, pinned_coef_;
+    std::vector<PlannedEncode> images_;
+    std::vector<EncodeImage> desc_;
+    std::vector<EncodeUnit> units_;
+    size_t units_offset_ = 0, coef_offset_ = 0, desc_bytes_ = 0, coef_total_ = 0;
+    uint64_t pixel_bytes_ = 0, coef_bytes_ = 0;
+    void* stream_ = nullptr;
+    void* event_ = nullptr;
+    bool launched_ = false, fetched_ = false;
+};
+
+hipjpegStatus_t subsampling_factors(int subsampling, int* ncomp, int* hs, int* vs);
+
+}  // namespace hipjpeg

@@ -1,0 +1,35 @@
+// entropy_encode.h -- host-side baseline Huffman coder + JFIF marker writer for the encode path
+// (the part of nvjpegEncodeImage / nvjpegEncodeRetrieveBitstream that stays on the CPU; reference call sites
+// extensions/nvjpeg/cuda_encoder.cpp:336-381).  Bitstream conventions follow libjpeg (jcmarker.c / jchuff.c / jccoefct.c)
+// so that, with the Annex-K tables, the output is byte-identical to libjpeg-turbo's for the same coefficients.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace hipjpeg {
+
+struct EncodeGeometry {
+    int width = 0, height = 0, ncomp = 3;
+    int hs = 2, vs = 2;                   // luma sampling factors; chroma components are 1x1
+    int blocks_w[3] = {0, 0, 0}, blocks_h[3] = {0, 0, 0};  // MCU-padded grid
+    int real_w[3] = {0, 0, 0}, real_h[3] = {0, 0, 0};      // width_in_blocks / height_in_blocks
+    int mcus_x = 0, mcus_y = 0;
+};
+
+// jcparam.c jpeg_set_quality(force_baseline): Annex-K tables scaled by quality, natural order.
+void quality_tables(int quality, uint16_t lum[64], uint16_t chr[64]);
+// Fills the grid fields from width/height/ncomp/hs/vs.
+void compute_geometry(EncodeGeometry* g);
+
+struct EntropyEncodeOptions {
+    int restart_interval = 0;     // in MCUs, 0 = none
+    bool optimized_huffman = false;  // two-pass optimal tables (jchuff.c jpeg_gen_optimal_table); default = Annex-K tables
+};
+
+// coef[c]: zigzag-ordered int16[64] blocks over the MCU-padded grid; only the real_w x real_h area is read.
+// Appends a complete JFIF file to `out`.
+void encode_jfif(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const int16_t* const coef[3],
+                 const EntropyEncodeOptions& opt, std::vector<uint8_t>* out);
+
+}  // namespace hipjpeg

@@ -4,9 +4,11 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <vector>
 
 #include "../../include/hipjpeg.h"
 #include "decoder_core.h"
+#include "encoder_core.h"
 #include "entropy_decode.h"
 #include "thread_pool.h"
 
@@ -21,6 +23,7 @@ struct hipjpegHandle {
     std::unique_ptr<DecodeBatch> batches[2];
     int current = 0;
     DecodeBatch& cur() { return *batches[current]; }
+    std::unique_ptr<EncodeBatch> encode;
 };
 
 extern "C" {
@@ -109,6 +112,7 @@ hipjpegStatus_t hipjpegCreate(hipjpegHandle_t* handle, int device_id, int num_ho
     h->pool.reset(new ForkJoinPool(num_host_threads));
     h->batches[0].reset(new DecodeBatch(device_id, &h->hooks));
     h->batches[1].reset(new DecodeBatch(device_id, &h->hooks));
+    h->encode.reset(new EncodeBatch(device_id, &h->hooks));
     *handle = h;
     return HIPJPEG_STATUS_SUCCESS;
 }
@@ -168,6 +172,100 @@ hipjpegStatus_t hipjpegDecodeBatch(hipjpegHandle_t handle, const uint8_t* const*
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     if ((st = hipjpegDecodeBatchTransfer(handle, stream)) != HIPJPEG_STATUS_SUCCESS) return st;
     return hipjpegDecodeBatchDevice(handle, stream);
+}
+
+// ---------------------------------------------------------------- encode
+hipjpegStatus_t hipjpegEncodeBatchDevice(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
+                                         int batch_size, hipjpegStatus_t* statuses, void* stream)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    return handle->encode->device_stage(inputs, params, batch_size, statuses, stream);
+}
+
+hipjpegStatus_t hipjpegEncodeBatchRelaunch(hipjpegHandle_t handle, void* stream)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    return handle->encode->relaunch(stream);
+}
+
+hipjpegStatus_t hipjpegEncodeBatchHost(hipjpegHandle_t handle, hipjpegStatus_t* statuses)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    EncodeBatch& b = *handle->encode;
+    hipjpegStatus_t st = b.fetch_coefficients();
+    if (st != HIPJPEG_STATUS_SUCCESS) return st;
+    handle->pool->parallel_for(b.size(), [&](int i, int) { b.entropy_stage(i); });
+    if (statuses)
+        for (int i = 0; i < b.size(); i++) statuses[i] = b.image(i).status;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegEncodeBatch(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
+                                   int batch_size, hipjpegStatus_t* statuses, void* stream)
+{
+    hipjpegStatus_t st = hipjpegEncodeBatchDevice(handle, inputs, params, batch_size, statuses, stream);
+    if (st != HIPJPEG_STATUS_SUCCESS) return st;
+    return hipjpegEncodeBatchHost(handle, statuses);
+}
+
+hipjpegStatus_t hipjpegEncodeGetBitstream(hipjpegHandle_t handle, int index, const uint8_t** data, size_t* length)
+{
+    if (!handle || !data || !length || index < 0 || index >= handle->encode->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    PlannedEncode& im = handle->encode->image(index);
+    if (im.status != HIPJPEG_STATUS_SUCCESS) return im.status;
+    *data = im.bitstream.data();
+    *length = im.bitstream.size();
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegEncodeGetCoefficients(hipjpegHandle_t handle, int index, int component, const int16_t** coef, int32_t grid[4])
+{
+    if (!handle || !coef || !grid || index < 0 || index >= handle->encode->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    PlannedEncode& im = handle->encode->image(index);
+    if (im.status != HIPJPEG_STATUS_SUCCESS) return im.status;
+    if (component < 0 || component >= im.geom.ncomp) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    hipjpegStatus_t st = handle->encode->fetch_coefficients();
+    if (st != HIPJPEG_STATUS_SUCCESS) return st;
+    *coef = handle->encode->host_coef(index, component);
+    grid[0] = im.geom.blocks_w[component];
+    grid[1] = im.geom.blocks_h[component];
+    grid[2] = im.geom.real_w[component];
+    grid[3] = im.geom.real_h[component];
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegEncodeBatchStats(hipjpegHandle_t handle, int32_t* num_units, uint64_t* pixel_bytes, uint64_t* coef_bytes)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if (num_units) *num_units = handle->encode->num_units();
+    if (pixel_bytes) *pixel_bytes = handle->encode->pixel_bytes();
+    if (coef_bytes) *coef_bytes = handle->encode->coef_bytes();
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegEncodeFromCoefficientsHost(int32_t width, int32_t height, const hipjpegEncodeParams_t* params, const int16_t* const coef[3],
+                                                  uint8_t* out, size_t capacity, size_t* length)
+{
+    if (!params || !coef || !length || width < 1 || height < 1 || width > 65535 || height > 65535) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    EncodeGeometry g;
+    g.width = width;
+    g.height = height;
+    hipjpegStatus_t st = subsampling_factors(params->subsampling, &g.ncomp, &g.hs, &g.vs);
+    if (st != HIPJPEG_STATUS_SUCCESS) return st;
+    compute_geometry(&g);
+    for (int c = 0; c < g.ncomp; c++)
+        if (!coef[c]) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    uint16_t ql[64], qc[64];
+    quality_tables(params->quality, ql, qc);
+    EntropyEncodeOptions opt;
+    opt.restart_interval = params->restart_interval;
+    opt.optimized_huffman = params->optimized_huffman != 0;
+    std::vector<uint8_t> bytes;
+    encode_jfif(g, ql, qc, coef, opt, &bytes);
+    *length = bytes.size();
+    if (!out || capacity < bytes.size()) return HIPJPEG_STATUS_BUFFER_TOO_SMALL;
+    memcpy(out, bytes.data(), bytes.size());
+    return HIPJPEG_STATUS_SUCCESS;
 }
 
 }  // extern "C"

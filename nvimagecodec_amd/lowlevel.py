@@ -173,3 +173,145 @@ class BatchDecoder:
         cb, ob = ctypes.c_uint64(), ctypes.c_uint64()
         N.load().hipjpegDecodeBatchStats(self._h, ctypes.addressof(units), ctypes.byref(cb), ctypes.byref(ob))
         return dict(units=list(units), coef_bytes=cb.value, output_bytes=ob.value)
+
+
+# ---------------------------------------------------------------------------------------------- encode
+_ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42,
+                    49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
+_IN_FORMATS = {"rgb": N.OUTPUT_RGBI, "bgr": N.OUTPUT_BGRI, "rgb_planar": N.OUTPUT_RGB_PLANAR, "bgr_planar": N.OUTPUT_BGR_PLANAR, "gray": N.OUTPUT_Y}
+
+
+def _enc_params(subsampling, quality, input_format="rgb", restart_interval=0, optimized_huffman=False):
+    return N.EncodeParams(int(quality), N.CSS[subsampling], _IN_FORMATS[input_format], int(restart_interval), int(bool(optimized_huffman)))
+
+
+def encode_from_coefficients_host(width, height, coefs_natural, subsampling="420", quality=90, restart_interval=0, optimized_huffman=False):
+    """Host-only entropy coding (no GPU).  coefs_natural: per component int16 [blocks_h, blocks_w, 64] in natural order over the
+    MCU-padded grid (what oracle.forward returns); converted to the zigzag layout the C-ABI takes."""
+    zz = [np.ascontiguousarray(c[:, :, _ZIGZAG]) for c in coefs_natural]
+    ptrs = (ctypes.c_void_p * 3)(*([z.ctypes.data for z in zz] + [None] * (3 - len(zz))))
+    p = _enc_params(subsampling, quality, "rgb", restart_interval, optimized_huffman)
+    cap = width * height * 3 + 65536
+    out = np.zeros(cap, dtype=np.uint8)
+    n = ctypes.c_size_t()
+    st = N.load().hipjpegEncodeFromCoefficientsHost(width, height, ctypes.byref(p), ptrs, out.ctypes.data, cap, ctypes.byref(n))
+    if st:
+        raise N.HipJpegError(st, "hipjpegEncodeFromCoefficientsHost")
+    return out[: n.value].tobytes()
+
+
+class BatchEncoder:
+    """hipjpegEncodeBatch* on one device; inputs are torch CUDA uint8 tensors ([H, W, 3] interleaved, [3, H, W] planar or [H, W] gray)."""
+
+    def __init__(self, device=0, num_threads=0):
+        import torch
+        self._torch = torch
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        st = N.load().hipjpegCreate(ctypes.byref(self._h), self.device, int(num_threads))
+        if st:
+            raise N.HipJpegError(st, "hipjpegCreate")
+        self._keep = None
+        self._n = 0
+
+    def close(self):
+        if self._h:
+            N.load().hipjpegDestroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream_ptr(self, stream):
+        s = stream if stream is not None else self._torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def _marshal(self, images, subsampling, quality, input_format, restart_interval, optimized_huffman):
+        n = len(images)
+        I = (N.EncodeInput * n)()
+        P = (N.EncodeParams * n)()
+        subs = subsampling if isinstance(subsampling, (list, tuple)) else [subsampling] * n
+        quals = quality if isinstance(quality, (list, tuple)) else [quality] * n
+        for i, t in enumerate(images):
+            fmt = input_format
+            if fmt in ("rgb", "bgr"):
+                h, w = t.shape[0], t.shape[1]
+                I[i].plane[0] = t.data_ptr()
+                I[i].pitch[0] = t.stride(0)
+            elif fmt == "gray":
+                h, w = t.shape
+                I[i].plane[0] = t.data_ptr()
+                I[i].pitch[0] = t.stride(0)
+            else:
+                h, w = t.shape[1], t.shape[2]
+                for p in range(3):
+                    I[i].plane[p] = t[p].data_ptr()
+                    I[i].pitch[p] = t.stride(1)
+            I[i].width, I[i].height = w, h
+            P[i] = _enc_params(subs[i], quals[i], fmt, restart_interval, optimized_huffman)
+        self._keep = (images, I, P)
+        self._n = n
+        return I, P
+
+    def device_stage(self, images, subsampling="420", quality=90, input_format="rgb", restart_interval=0, optimized_huffman=False, stream=None):
+        I, P = self._marshal(images, subsampling, quality, input_format, restart_interval, optimized_huffman)
+        st_arr = (ctypes.c_int * self._n)()
+        st = N.load().hipjpegEncodeBatchDevice(self._h, I, P, self._n, st_arr, self._stream_ptr(stream))
+        if st:
+            raise N.HipJpegError(st, "hipjpegEncodeBatchDevice")
+        return list(st_arr)
+
+    def relaunch(self, stream=None):
+        st = N.load().hipjpegEncodeBatchRelaunch(self._h, self._stream_ptr(stream))
+        if st:
+            raise N.HipJpegError(st, "hipjpegEncodeBatchRelaunch")
+
+    def host_stage(self):
+        st_arr = (ctypes.c_int * self._n)()
+        st = N.load().hipjpegEncodeBatchHost(self._h, st_arr)
+        if st:
+            raise N.HipJpegError(st, "hipjpegEncodeBatchHost")
+        return list(st_arr)
+
+    def bitstreams(self):
+        out = []
+        for i in range(self._n):
+            p, n = ctypes.c_void_p(), ctypes.c_size_t()
+            st = N.load().hipjpegEncodeGetBitstream(self._h, i, ctypes.byref(p), ctypes.byref(n))
+            out.append(ctypes.string_at(p, n.value) if st == 0 else None)
+        return out
+
+    def coefficients(self, index):
+        """Quantized coefficients of image `index`, per component int16 [real_h, real_w, 64] in NATURAL order."""
+        res = []
+        c = 0
+        while True:
+            p = ctypes.c_void_p()
+            grid = (ctypes.c_int32 * 4)()
+            st = N.load().hipjpegEncodeGetCoefficients(self._h, index, c, ctypes.byref(p), ctypes.addressof(grid))
+            if st:
+                break
+            bw, bh, rw, rh = list(grid)
+            a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int16)), shape=(bh, bw, 64))
+            nat = np.zeros((rh, rw, 64), dtype=np.int16)
+            nat[:, :, _ZIGZAG] = a[:rh, :rw, :]
+            res.append(nat)
+            c += 1
+        return res
+
+    def encode(self, images, subsampling="420", quality=90, input_format="rgb", restart_interval=0, optimized_huffman=False, stream=None):
+        st = self.device_stage(images, subsampling, quality, input_format, restart_interval, optimized_huffman, stream)
+        st = self.host_stage()
+        for i, s in enumerate(st):
+            if s:
+                raise N.HipJpegError(s, f"image {i}")
+        return self.bitstreams()
+
+    def stats(self):
+        u = ctypes.c_int32()
+        pb, cb = ctypes.c_uint64(), ctypes.c_uint64()
+        N.load().hipjpegEncodeBatchStats(self._h, ctypes.byref(u), ctypes.byref(pb), ctypes.byref(cb))
+        return dict(units=u.value, pixel_bytes=pb.value, coef_bytes=cb.value)
