@@ -335,3 +335,125 @@ class Decoder(_ExecMixin):
             lib.nvimgcodecImageDestroy(images[i])
             lib.nvimgcodecCodeStreamDestroy(streams[i])
         return results
+
+
+class Encoder(_ExecMixin):
+    """nvimgcodec.Encoder (python/encoder.cpp:136-179, 292-390) for JPEG output."""
+
+    def __init__(self, device_id=A.DEVICE_CURRENT, max_num_cpu_threads=0, backends=None, options=""):
+        import torch
+        self._torch = torch
+        lib, inst = _api()
+        if device_id == A.DEVICE_CURRENT:
+            device_id = torch.cuda.current_device() if torch.cuda.is_available() else A.DEVICE_CPU_ONLY
+        self.device_id = device_id
+        ep = self._make_exec_params(device_id, max_num_cpu_threads, backends)
+        self._h = C.c_void_p()
+        _check(lib.nvimgcodecEncoderCreate(inst, C.byref(self._h), C.byref(ep), options.encode()), "nvimgcodecEncoderCreate")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.nvimgcodecEncoderDestroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def write(self, file_names, images, codec="jpeg", params=None, cuda_stream=0):
+        single = isinstance(file_names, (str, bytes))
+        names = [file_names] if single else list(file_names)
+        imgs = [images] if single else list(images)
+        data = self.encode(imgs, codec, params, cuda_stream)
+        out = []
+        for n, d in zip(names, data):
+            if d is not None:
+                with open(n, "wb") as f:
+                    f.write(d)
+                out.append(n)
+            else:
+                out.append(None)
+        return out[0] if single else out
+
+    def encode(self, images, codec="jpeg", params=None, cuda_stream=0):
+        if codec.lstrip(".").lower() not in ("jpeg", "jpg"):
+            raise NvImgCodecError(f"codec {codec!r} is outside this extension (JPEG only)")
+        torch = self._torch
+        lib, inst = _api()
+        params = params or EncodeParams()
+        single = not isinstance(images, (list, tuple))
+        ilist = [as_image(i) for i in ([images] if single else images)]
+        n = len(ilist)
+        sinks, streams, handles, keep = [], [], [], []
+        stream_ptr = cuda_stream or torch.cuda.current_stream(self.device_id).cuda_stream
+
+        for im in ilist:
+            arr = im._array
+            if im.buffer_kind == ImageBufferKind.STRIDED_HOST:
+                arr = np.ascontiguousarray(arr)
+            h, w = arr.shape[0], arr.shape[1]
+            ch = arr.shape[2] if arr.ndim == 3 else 1
+            gray = ch == 1
+            if im.buffer_kind == ImageBufferKind.STRIDED_DEVICE:
+                ptr, pitch, kind = arr.data_ptr(), arr.stride(0), A.BUFFER_KIND_STRIDED_DEVICE
+            else:
+                ptr, pitch, kind = arr.ctypes.data, arr.strides[0], A.BUFFER_KIND_STRIDED_HOST
+            keep.append(arr)
+            css = A.SAMPLING_GRAY if gray else int(params.chroma_subsampling)
+            info = A.ImageInfo()
+            _fill_image_info(info, h, w, ch, A.SAMPLEFORMAT_P_Y if gray else A.SAMPLEFORMAT_I_RGB,
+                             A.COLORSPEC_GRAY if gray else A.COLORSPEC_SRGB, ptr, pitch, kind, stream_ptr, subsampling=css)
+            ih = C.c_void_p()
+            _check(lib.nvimgcodecImageCreate(inst, C.byref(ih), C.byref(info)), "nvimgcodecImageCreate")
+            # output stream description: codec name, target subsampling, JPEG encoding (baseline / progressive)
+            out_info = A.ImageInfo()
+            _fill_image_info(out_info, h, w, ch, info.sample_format, info.color_spec, None, 0, A.BUFFER_KIND_STRIDED_HOST, None, subsampling=css)
+            out_info.codec_name = b"jpeg"
+            ji = A.init(A.JpegImageInfo, A.ST_JPEG_IMAGE_INFO, encoding=A.JPEG_ENCODING_PROGRESSIVE_DCT_HUFFMAN if params.jpeg_params.progressive
+                        else A.JPEG_ENCODING_BASELINE_DCT)
+            out_info.struct_next = C.addressof(ji)
+            sink = {"buf": None}
+
+            def resize(ctx, size, sink=sink):
+                if sink["buf"] is None or size > len(sink["buf"]):
+                    nb = C.create_string_buffer(size)
+                    if sink["buf"] is not None:
+                        C.memmove(nb, sink["buf"], len(sink["buf"]))
+                    sink["buf"] = nb
+                sink["size"] = size
+                return C.addressof(sink["buf"])
+
+            cb = A.ResizeBufferFn(resize)
+            cs = C.c_void_p()
+            _check(lib.nvimgcodecCodeStreamCreateToHostMem(inst, C.byref(cs), None, cb, C.byref(out_info)), "nvimgcodecCodeStreamCreateToHostMem")
+            keep.append((cb, ji))
+            sinks.append(sink)
+            streams.append(cs)
+            handles.append(ih)
+
+        ep = A.init(A.EncodeParams, A.ST_ENCODE_PARAMS, quality=params.quality, target_psnr=params.target_psnr)
+        jp = A.init(A.JpegEncodeParams, A.ST_JPEG_ENCODE_PARAMS, optimized_huffman=int(params.jpeg_params.optimized_huffman))
+        ep.struct_next = C.addressof(jp)
+        fut = C.c_void_p()
+        _check(lib.nvimgcodecEncoderEncode(self._h, (C.c_void_p * n)(*handles), (C.c_void_p * n)(*streams), n, C.byref(ep), C.byref(fut)),
+               "nvimgcodecEncoderEncode")
+        _check(lib.nvimgcodecFutureWaitForAll(fut), "nvimgcodecFutureWaitForAll")
+        st = (C.c_uint32 * n)()
+        size = C.c_size_t()
+        lib.nvimgcodecFutureGetProcessingStatus(fut, st, C.byref(size))
+        lib.nvimgcodecFutureDestroy(fut)
+        res = []
+        for i in range(n):
+            ok = st[i] == A.PS_SUCCESS and sinks[i]["buf"] is not None
+            res.append(bytes(sinks[i]["buf"].raw[: sinks[i]["size"]]) if ok else None)
+            lib.nvimgcodecImageDestroy(handles[i])
+            lib.nvimgcodecCodeStreamDestroy(streams[i])
+        return res[0] if single else res

@@ -9,22 +9,28 @@
 namespace hipjpeg_ext {
 
 struct HipJpegExtension {
-    explicit HipJpegExtension(const nvimgcodecFrameworkDesc_t* fw) : framework(fw), decoder(fw)
+    explicit HipJpegExtension(const nvimgcodecFrameworkDesc_t* fw) : framework(fw), decoder(fw), encoder(fw)
     {
+        framework->registerEncoder(framework->instance, encoder.desc(), NVIMGCODEC_PRIORITY_HIGH);  // nvjpeg_ext.cpp:42
         // same slot in the priority chain as the reference's nvJPEG CUDA decoder (nvjpeg_ext.cpp:45):
         // ahead of libjpeg_turbo (NORMAL) and opencv (LOW), which stay available as fallbacks
         framework->registerDecoder(framework->instance, decoder.desc(), NVIMGCODEC_PRIORITY_HIGH);
     }
-    ~HipJpegExtension() { framework->unregisterDecoder(framework->instance, decoder.desc()); }
+    ~HipJpegExtension()
+    {
+        framework->unregisterEncoder(framework->instance, encoder.desc());
+        framework->unregisterDecoder(framework->instance, decoder.desc());
+    }
     const nvimgcodecFrameworkDesc_t* framework;  // valid until destroy()
     HipJpegDecoderPlugin decoder;
+    HipJpegEncoderPlugin encoder;
 };
 
 static nvimgcodecStatus_t extension_create(void* /*instance*/, nvimgcodecExtension_t* extension, const nvimgcodecFrameworkDesc_t* framework)
 {
     try {
         if (!extension || !framework) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
-        if (!framework->registerDecoder || !framework->unregisterDecoder) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
+        if (!framework->registerDecoder || !framework->unregisterDecoder || !framework->registerEncoder || !framework->unregisterEncoder) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
         HJ_LOG_TRACE(framework, kExtensionId, "extension_create");
         *extension = reinterpret_cast<nvimgcodecExtension_t>(new HipJpegExtension(framework));
         return NVIMGCODEC_STATUS_SUCCESS;

@@ -804,6 +804,20 @@ nvimgcodecStatus_t start_dispatch(CodecHandle* codec, const nvimgcodecCodeStream
     } else {
         disp->eparams = params ? *static_cast<const nvimgcodecEncodeParams_t*>(params)
                                : nvimgcodecEncodeParams_t{NVIMGCODEC_STRUCTURE_TYPE_ENCODE_PARAMS, sizeof(nvimgcodecEncodeParams_t), nullptr, 90.f, 0.f};
+        // the chained JPEG parameters are copied: encoding continues after this call returns
+        struct Head {
+            nvimgcodecStructureType_t t;
+            size_t s;
+            void* n;
+        };
+        void* chain = disp->eparams.struct_next;
+        disp->eparams.struct_next = nullptr;
+        for (Head* h = static_cast<Head*>(chain); h; h = static_cast<Head*>(h->n))
+            if (h->t == NVIMGCODEC_STRUCTURE_TYPE_JPEG_ENCODE_PARAMS) {
+                disp->jpeg_eparams = *reinterpret_cast<nvimgcodecJpegEncodeParams_t*>(h);
+                disp->jpeg_eparams.struct_next = nullptr;
+                disp->eparams.struct_next = &disp->jpeg_eparams;
+            }
     }
     disp->samples.resize((size_t)n);
     std::vector<size_t> all;

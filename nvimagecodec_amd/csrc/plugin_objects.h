@@ -24,4 +24,21 @@ private:
     const nvimgcodecFrameworkDesc_t* framework_;
 };
 
+class HipJpegEncoderPlugin {
+public:
+    explicit HipJpegEncoderPlugin(const nvimgcodecFrameworkDesc_t* framework);
+    const nvimgcodecEncoderDesc_t* desc() const { return &desc_; }
+
+private:
+    static nvimgcodecStatus_t static_create(void* instance, nvimgcodecEncoder_t* encoder, const nvimgcodecExecutionParams_t* exec_params,
+                                            const char* options);
+    static nvimgcodecStatus_t static_destroy(nvimgcodecEncoder_t encoder);
+    static nvimgcodecStatus_t static_can_encode(nvimgcodecEncoder_t encoder, nvimgcodecProcessingStatus_t* status, nvimgcodecImageDesc_t** images,
+                                                nvimgcodecCodeStreamDesc_t** code_streams, int batch_size, const nvimgcodecEncodeParams_t* params);
+    static nvimgcodecStatus_t static_encode(nvimgcodecEncoder_t encoder, nvimgcodecImageDesc_t** images, nvimgcodecCodeStreamDesc_t** code_streams,
+                                            int batch_size, const nvimgcodecEncodeParams_t* params);
+    nvimgcodecEncoderDesc_t desc_;
+    const nvimgcodecFrameworkDesc_t* framework_;
+};
+
 }  // namespace hipjpeg_ext

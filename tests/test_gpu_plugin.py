@@ -235,3 +235,48 @@ def test_many_batches_back_to_back_reuse_pages(torch_mod):
             torch_mod.cuda.synchronize()
             for e, c, im in zip(entries, cases, imgs):
                 assert np.array_equal(im.cpu()._array, c[1]), (rep, e["name"])
+
+
+def test_python_encoder_mirror_through_plugin(torch_mod):
+    """Encoder.encode -> nvimgcodecEncoderEncode -> hipjpeg_encoder plugin -> HIP kernel + host Huffman -> host-memory code stream.
+    Bitstream must equal the oracle's (== libjpeg-turbo's scan for these settings)."""
+    from nvimagecodec_amd import api
+    from nvimagecodec_amd.synth import synth_image
+    torch = torch_mod
+    imgs = [synth_image(w, h, seed=w) for (w, h) in ((64, 48), (131, 77), (640, 480))]
+    dev = [torch.from_numpy(i).cuda() for i in imgs]
+    with api.Encoder(max_num_cpu_threads=4) as enc:
+        for css, sub in ((api.ChromaSubsampling.CSS_420, "420"), (api.ChromaSubsampling.CSS_444, "444"), (api.ChromaSubsampling.CSS_422, "422")):
+            out = enc.encode([api.as_image(d) for d in dev], "jpeg", api.EncodeParams(quality=90, chroma_subsampling=css))
+            for im, b in zip(imgs, out):
+                assert b == oracle.encode(im, sub, 90), sub
+        # host-memory input goes through the framework's H2D bounce (reference src/work.h:192-232)
+        b = enc.encode(api.as_image(imgs[1]), ".jpg", api.EncodeParams(quality=75, chroma_subsampling=api.ChromaSubsampling.CSS_420))
+        assert b == oracle.encode(imgs[1], "420", 75)
+        # gray image -> single-component stream
+        g = np.ascontiguousarray(imgs[0][:, :, :1])
+        bg = enc.encode(api.as_image(torch.from_numpy(g).cuda()), "jpeg", api.EncodeParams(quality=90))
+        assert bg == oracle.encode(np.repeat(g, 3, axis=2), "gray", 90)
+        # optimized Huffman tables via the chained nvimgcodecJpegEncodeParams_t
+        bo = enc.encode(api.as_image(dev[2]), "jpeg", api.EncodeParams(quality=90, chroma_subsampling=api.ChromaSubsampling.CSS_420,
+                                                                       jpeg_encode_params=api.JpegEncodeParams(optimized_huffman=True)))
+        ref = oracle.encode(imgs[2], "420", 90)
+        assert len(bo) < len(ref)
+        assert all(np.array_equal(a, c) for a, c in zip(oracle.decode_coefficients(bo)[0], oracle.decode_coefficients(ref)[0]))
+        # progressive output is not produced by this encoder: no other encoder registered -> None
+        bp = enc.encode(api.as_image(dev[0]), "jpeg", api.EncodeParams(quality=90, jpeg_encode_params=api.JpegEncodeParams(progressive=True)))
+        assert bp is None
+
+
+def test_transcode_roundtrip_through_both_plugins(torch_mod, tmp_path):
+    """decode -> encode -> decode through the nvImageCodec API route (the nvimtrans use case, example/nvimtrans/main.cpp)."""
+    from nvimagecodec_amd import api
+    jpeg, rgb = _case("c1_640x480_444_base_q90")
+    with api.Decoder() as dec, api.Encoder() as enc:
+        img = dec.decode(jpeg)
+        path = tmp_path / "out.jpg"
+        assert enc.write(str(path), img, "jpeg", api.EncodeParams(quality=95, chroma_subsampling=api.ChromaSubsampling.CSS_420)) == str(path)
+        again = dec.read(str(path))
+        torch_mod.cuda.synchronize()
+        ref_rgb = oracle.decode(jpeg)
+        assert np.array_equal(again.cpu()._array, oracle.decode(oracle.encode(ref_rgb, "420", 95)))
