@@ -5,10 +5,12 @@
 
 namespace hipjpeg {
 
+// `exact` selects the 32-bit-multiplier build for images flagged kFlagExactMul32 (separate kernels keep the common
+// case's register count down).
 // K1: IDCT of component blocks into u8 planes.  One WorkUnit = 256 blocks.
-int launch_idct_plane(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+int launch_idct_plane(bool exact, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K2: fused luma IDCT + chroma upsample (factors hs x vs, 0 = no chroma) + colour conversion + store.
-int launch_luma_color(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+int launch_luma_color(bool exact, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K3: per-pixel colour stage from planes (replication upsampling) for uncommon sampling layouts.
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 

@@ -24,6 +24,9 @@ namespace hipjpeg {
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef HJ_MIN_WAVES
+#define HJ_MIN_WAVES 2
+#endif
 constexpr int kLdsBlockStride = 144;  // 128 B of coefficients + 16 B pad: ds_read_b128 at lane stride 144 B hits 64 distinct banks
 constexpr int kLdsWaveBytes = 64 * kLdsBlockStride;
 
@@ -108,10 +111,18 @@ __device__ __forceinline__ void fetch_block(const int16_t* __restrict__ comp_coe
     for (int k = 0; k < 8; k++) {
         int g = k * 64 + lane;
         u32x4 v = {0u, 0u, 0u, 0u};
+#ifdef HJ_ABLATE_COEF
+        if (g < nchunks) v = u32x4{(unsigned)g, 1u, 0u, 0u};
+#else
         if (g < nchunks) v = __builtin_nontemporal_load(src + g);
+#endif
         *reinterpret_cast<u32x4*>(lds_wave + (g >> 3) * kLdsBlockStride + (g & 7) * 16) = v;
     }
-    __syncthreads();
+    // Each wave reads back only what it wrote itself.  LDS operations of one wave execute in order, so no workgroup
+    // barrier is needed -- only a compiler-level fence so the reads are not hoisted above the writes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int c = 0; c < 8; c++) cols[c] = *reinterpret_cast<const u32x4*>(lds_wave + lane * kLdsBlockStride + c * 16);
 }
@@ -189,15 +200,12 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
     }
 }
 
-__global__ __launch_bounds__(kThreads) void idct_plane_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
+template <bool EXACT>
+__global__ __launch_bounds__(kThreads, HJ_MIN_WAVES) void idct_plane_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
     __shared__ __attribute__((aligned(16))) char lds[4 * kLdsWaveBytes];
     const WorkUnit u = units[blockIdx.x];
-    const DecodeImage& im = images[u.image];
-    if (im.flags & kFlagExactMul32)
-        idct_plane_body<true>(im, u, lds);
-    else
-        idct_plane_body<false>(im, u, lds);
+    idct_plane_body<EXACT>(images[u.image], u, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -220,7 +228,11 @@ __device__ __forceinline__ void load_chroma_window(const uint8_t* __restrict__ p
         const uint8_t* p = plane + (size_t)y * pitch + base;
         // planes are allocated with >= 16 bytes of slack per row, so an 8-byte read starting inside the row is in bounds
         unsigned long long v;
+#ifdef HJ_ABLATE_CHROMA
+        v = 0x8080808080808080ull + (unsigned long long)(uintptr_t)p;
+#else
         __builtin_memcpy(&v, p, 8);
+#endif
         rows[i] = v;
     }
     if (__builtin_amdgcn_ballot_w64(edge) != 0) {
@@ -280,145 +292,191 @@ __device__ __forceinline__ void upsample_row(unsigned long long near, unsigned l
     }
 }
 
+// Work unit of this kernel: a tile of 64 x 4 luma blocks -- block_base = first block column, comp = first block row;
+// wave w of the workgroup owns the 64 consecutive blocks of block row (comp + w).
+constexpr int kLumaTileW = 64, kLumaTileH = 4;
+constexpr int kOutRowBytes = 64 * 24;               // one pixel row of a wave's 64 blocks, interleaved RGB
+constexpr int kLdsLumaWaveBytes = 8 * kOutRowBytes;  // 12,288 B: first the coefficient staging (9,216 B), then the RGB tile
+
 template <bool EXACT, int HS, int VS>
 __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bw = im.comp[0].blocks_w, nblocks = bw * im.comp[0].blocks_h;
-    const int wave_first = u.block_base + wave * 64;
+    const int bw = im.comp[0].blocks_w, bh = im.comp[0].blocks_h;
+    const int bx0 = u.block_base, by = (int)u.comp + wave;
+    const int bx = bx0 + lane;
+    const int wave_first = by * bw + bx0;
+    char* lds_wave = lds + wave * kLdsLumaWaveBytes;
     u32x4 cols[8];
-    fetch_block(im.comp[0].coef, wave_first, nblocks, lds + wave * kLdsWaveBytes, lane, cols);
-    const int b = wave_first + lane;
-    if (b >= nblocks) return;
-    const int by = b / bw, bx = b - by * bw;
+    // the wave's blocks are contiguous in memory up to the end of the block row
+    fetch_block(im.comp[0].coef, wave_first, by < bh ? (by + 1) * bw : 0, lds_wave, lane, cols);
     const int x0 = bx * 8, y0 = by * 8;
     const int W = im.width, H = im.height;
-    if (x0 >= W || y0 >= H) return;  // block entirely inside MCU padding
-
-    // chroma window (issued before the IDCT so the loads fly while we compute)
-    constexpr int NW = HS == 2 ? 6 : 8;
-    constexpr int NR = (HS == 0) ? 1 : (VS == 2 ? 6 : 8);
-    unsigned long long cbw[NR], crw[NR];
-    bool fancy = false;
-    if constexpr (HS != 0) {
-        const int dw = im.comp[1].samp_w, dh = im.comp[1].samp_h;
-        // libjpeg picks the triangle filters only when do_fancy_upsampling and (for h2v1/h2v2) downsampled_width > 2
-        fancy = (im.flags & kFlagFancyUpsampling) && (HS == 1 || dw > 2);
-        const int wx = HS == 2 ? 4 * bx - 1 : 8 * bx;
-        const int wy = VS == 2 ? 4 * by - 1 : 8 * by;
-        load_chroma_window<NR, NW>(im.comp[1].plane, im.comp[1].plane_pitch, dw, dh, wx, wy, cbw);
-        load_chroma_window<NR, NW>(im.comp[2].plane, im.comp[2].plane_pitch, dw, dh, wx, wy, crw);
-    }
-
-    int ws[8][8];
-    dequant_column_pass<EXACT>(cols, im.comp[0].qt, ws);
+    const bool valid = bx < bw && by < bh && x0 < W && y0 < H;  // false: lane idles (block is MCU padding or outside the tile)
 
     const int fmt = im.out_format;
     const bool planar = fmt == kOutPlanarRGB || fmt == kOutPlanarBGR;
     const bool bgr = fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR;
     const bool ycc = im.color_model == 1;
     const bool full = x0 + 8 <= W;
+    // Interleaved output whose rows are 16-byte aligned goes through an LDS tile so that the wave emits 16 B per lane,
+    // fully coalesced: 12 store instructions per wave instead of 24 strided 8-byte ones per lane (store-issue bound).
+    const bool staged = !planar && ((((uintptr_t)im.out[0]) | im.out_pitch[0]) & 15) == 0;
+
+    if (valid) {
+        // chroma window (issued before the IDCT so the loads fly while we compute)
+        constexpr int NW = HS == 2 ? 6 : 8;
+        constexpr int NR = (HS == 0) ? 1 : (VS == 2 ? 6 : 8);
+        unsigned long long cbw[NR], crw[NR];
+        bool fancy = false;
+        if constexpr (HS != 0) {
+            const int dw = im.comp[1].samp_w, dh = im.comp[1].samp_h;
+            // libjpeg picks the triangle filters only when do_fancy_upsampling and (for h2v1/h2v2) downsampled_width > 2
+            fancy = (im.flags & kFlagFancyUpsampling) && (HS == 1 || dw > 2);
+            const int wx = HS == 2 ? 4 * bx - 1 : 8 * bx;
+            const int wy = VS == 2 ? 4 * by - 1 : 8 * by;
+            load_chroma_window<NR, NW>(im.comp[1].plane, im.comp[1].plane_pitch, dw, dh, wx, wy, cbw);
+            load_chroma_window<NR, NW>(im.comp[2].plane, im.comp[2].plane_pitch, dw, dh, wx, wy, crw);
+        }
+
+        int ws[8][8];
+        dequant_column_pass<EXACT>(cols, im.comp[0].qt, ws);
 
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        int d[8];
+        for (int r = 0; r < 8; r++) {
+            int d[8];
 #pragma unroll
-        for (int c = 0; c < 8; c++) d[c] = ws[r][c];
-        idct8<false, 18>(d);
-        if (y0 + r >= H) continue;
-        int R[8], G[8], B[8];
-        if constexpr (HS == 0) {
+            for (int c = 0; c < 8; c++) d[c] = ws[r][c];
+            idct8<false, 18>(d);
+            if (y0 + r >= H) continue;
+            int R[8], G[8], B[8];
+            if constexpr (HS == 0) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) R[c] = G[c] = B[c] = range_limit(d[c]);
-        } else {
-            int cb[8], cr[8];
-            int near, far;
-            if constexpr (VS == 2) {
-                near = 1 + (r >> 1);
-                far = (r & 1) ? near + 1 : near - 1;
+                for (int c = 0; c < 8; c++) R[c] = G[c] = B[c] = range_limit(d[c]);
             } else {
-                near = far = r;
+                int cb[8], cr[8];
+                int near, far;
+                if constexpr (VS == 2) {
+                    near = 1 + (r >> 1);
+                    far = (r & 1) ? near + 1 : near - 1;
+                } else {
+                    near = far = r;
+                }
+                upsample_row<HS, VS>(cbw[near], cbw[far], r, fancy, cb);
+                upsample_row<HS, VS>(crw[near], crw[far], r, fancy, cr);
+                if (ycc) {
+                    // jdcolor.c ycc_rgb_convert with SCALEBITS = 16; (x - 128) folded into the additive constants
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        int y = range_limit(d[c]);
+                        int rr = (__mul24(cr[c], 91881) + (32768 - 128 * 91881)) >> 16;
+                        int bb = (__mul24(cb[c], 116130) + (32768 - 128 * 116130)) >> 16;
+                        int gg = (__mul24(cb[c], -22554) + __mul24(cr[c], -46802) + (32768 + 128 * 22554 + 128 * 46802)) >> 16;
+                        R[c] = clamp255(y + rr);
+                        G[c] = clamp255(y + gg);
+                        B[c] = clamp255(y + bb);
+                    }
+                } else {
+                    // Adobe RGB JPEG: the three components already are R, G, B
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        R[c] = range_limit(d[c]);
+                        G[c] = cb[c];
+                        B[c] = cr[c];
+                    }
+                }
             }
-            upsample_row<HS, VS>(cbw[near], cbw[far], r, fancy, cb);
-            upsample_row<HS, VS>(crw[near], crw[far], r, fancy, cr);
-            if (ycc) {
-                // jdcolor.c ycc_rgb_convert with SCALEBITS = 16; (x - 128) folded into the additive constants
+            if (bgr) {
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
-                    int y = range_limit(d[c]);
-                    int rr = (__mul24(cr[c], 91881) + (32768 - 128 * 91881)) >> 16;
-                    int bb = (__mul24(cb[c], 116130) + (32768 - 128 * 116130)) >> 16;
-                    int gg = (__mul24(cb[c], -22554) + __mul24(cr[c], -46802) + (32768 + 128 * 22554 + 128 * 46802)) >> 16;
-                    R[c] = clamp255(y + rr);
-                    G[c] = clamp255(y + gg);
-                    B[c] = clamp255(y + bb);
+                    int t = R[c];
+                    R[c] = B[c];
+                    B[c] = t;
+                }
+            }
+            const int y = y0 + r;
+            if (planar) {
+                uint8_t* p0 = im.out[0] + (size_t)y * im.out_pitch[0] + x0;
+                uint8_t* p1 = im.out[1] + (size_t)y * im.out_pitch[1] + x0;
+                uint8_t* p2 = im.out[2] + (size_t)y * im.out_pitch[2] + x0;
+                if (full && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 7) == 0) {
+                    *reinterpret_cast<uint2*>(p0) = make_uint2(pack4(R[0], R[1], R[2], R[3]), pack4(R[4], R[5], R[6], R[7]));
+                    *reinterpret_cast<uint2*>(p1) = make_uint2(pack4(G[0], G[1], G[2], G[3]), pack4(G[4], G[5], G[6], G[7]));
+                    *reinterpret_cast<uint2*>(p2) = make_uint2(pack4(B[0], B[1], B[2], B[3]), pack4(B[4], B[5], B[6], B[7]));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; c++)
+                        if (x0 + c < W) {
+                            p0[c] = (uint8_t)R[c];
+                            p1[c] = (uint8_t)G[c];
+                            p2[c] = (uint8_t)B[c];
+                        }
                 }
             } else {
-                // Adobe RGB JPEG: the three components already are R, G, B
+                const uint2 q0 = make_uint2(pack4(R[0], G[0], B[0], R[1]), pack4(G[1], B[1], R[2], G[2]));
+                const uint2 q1 = make_uint2(pack4(B[2], R[3], G[3], B[3]), pack4(R[4], G[4], B[4], R[5]));
+                const uint2 q2 = make_uint2(pack4(G[5], B[5], R[6], G[6]), pack4(B[6], R[7], G[7], B[7]));
+                if (staged) {
+                    // 24-byte lane stride: the 16 lanes of a ds_write_b64 group land on 32 distinct banks
+                    uint2* t = reinterpret_cast<uint2*>(lds_wave + r * kOutRowBytes + lane * 24);
+                    t[0] = q0;
+                    t[1] = q1;
+                    t[2] = q2;
+                } else {
+                    uint8_t* p = im.out[0] + (size_t)y * im.out_pitch[0] + (size_t)x0 * 3;
+                    if (full && ((uintptr_t)p & 7) == 0) {
+                        uint2* q = reinterpret_cast<uint2*>(p);
+                        q[0] = q0;
+                        q[1] = q1;
+                        q[2] = q2;
+                    } else {
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    R[c] = range_limit(d[c]);
-                    G[c] = cb[c];
-                    B[c] = cr[c];
+                        for (int c = 0; c < 8; c++)
+                            if (x0 + c < W) {
+                                p[3 * c] = (uint8_t)R[c];
+                                p[3 * c + 1] = (uint8_t)G[c];
+                                p[3 * c + 2] = (uint8_t)B[c];
+                            }
+                    }
                 }
             }
         }
-        if (bgr) {
+    }
+
+    if (!staged || by >= bh || y0 >= H) return;  // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the wave's tile: rows y0..y0+7, bytes [bx0*24, bx0*24 + row_bytes) of each row
+    const int row_bytes = min(W - bx0 * 8, kLumaTileW * 8) * 3;
+    const int nrows = min(8, H - y0);
+    uint8_t* out_base = im.out[0] + (size_t)y0 * im.out_pitch[0] + (size_t)bx0 * 24;
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                int t = R[c];
-                R[c] = B[c];
-                B[c] = t;
-            }
-        }
-        const int y = y0 + r;
-        if (planar) {
-            uint8_t* p0 = im.out[0] + (size_t)y * im.out_pitch[0] + x0;
-            uint8_t* p1 = im.out[1] + (size_t)y * im.out_pitch[1] + x0;
-            uint8_t* p2 = im.out[2] + (size_t)y * im.out_pitch[2] + x0;
-            if (full && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 7) == 0) {
-                *reinterpret_cast<uint2*>(p0) = make_uint2(pack4(R[0], R[1], R[2], R[3]), pack4(R[4], R[5], R[6], R[7]));
-                *reinterpret_cast<uint2*>(p1) = make_uint2(pack4(G[0], G[1], G[2], G[3]), pack4(G[4], G[5], G[6], G[7]));
-                *reinterpret_cast<uint2*>(p2) = make_uint2(pack4(B[0], B[1], B[2], B[3]), pack4(B[4], B[5], B[6], B[7]));
+    for (int k = 0; k < 12; k++) {
+        const int g = k * 64 + lane;  // 16-byte chunk of the 8 x 1536 B tile
+        const int r = g / 96, off = (g - r * 96) * 16;
+        if (r < nrows && off < row_bytes) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds_wave + r * kOutRowBytes + off);
+            uint8_t* dst = out_base + (size_t)r * im.out_pitch[0] + off;
+            if (off + 16 <= row_bytes) {
+#ifdef HJ_ABLATE_STORE
+                if (v.x == 0x12345678u && v.y == 0x9abcdef0u)  // practically never: keeps the value live, drops the traffic
+#endif
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
             } else {
-#pragma unroll
-                for (int c = 0; c < 8; c++)
-                    if (x0 + c < W) {
-                        p0[c] = (uint8_t)R[c];
-                        p1[c] = (uint8_t)G[c];
-                        p2[c] = (uint8_t)B[c];
-                    }
-            }
-        } else {
-            uint8_t* p = im.out[0] + (size_t)y * im.out_pitch[0] + (size_t)x0 * 3;
-            if (full && ((uintptr_t)p & 7) == 0) {
-                uint2* q = reinterpret_cast<uint2*>(p);
-                q[0] = make_uint2(pack4(R[0], G[0], B[0], R[1]), pack4(G[1], B[1], R[2], G[2]));
-                q[1] = make_uint2(pack4(B[2], R[3], G[3], B[3]), pack4(R[4], G[4], B[4], R[5]));
-                q[2] = make_uint2(pack4(G[5], B[5], R[6], G[6]), pack4(B[6], R[7], G[7], B[7]));
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; c++)
-                    if (x0 + c < W) {
-                        p[3 * c] = (uint8_t)R[c];
-                        p[3 * c + 1] = (uint8_t)G[c];
-                        p[3 * c + 2] = (uint8_t)B[c];
-                    }
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                for (int j = 0; j < row_bytes - off; j++) dst[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
             }
         }
     }
 }
 
-template <int HS, int VS>
-__global__ __launch_bounds__(kThreads) void luma_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
+template <bool EXACT, int HS, int VS>
+__global__ __launch_bounds__(kThreads, HJ_MIN_WAVES) void luma_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
-    __shared__ __attribute__((aligned(16))) char lds[4 * kLdsWaveBytes];
+    __shared__ __attribute__((aligned(16))) char lds[4 * kLdsLumaWaveBytes];
     const WorkUnit u = units[blockIdx.x];
-    const DecodeImage& im = images[u.image];
-    if (im.flags & kFlagExactMul32)
-        luma_color_body<true, HS, VS>(im, u, lds);
-    else
-        luma_color_body<false, HS, VS>(im, u, lds);
+    luma_color_body<EXACT, HS, VS>(images[u.image], u, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,30 +539,39 @@ __global__ __launch_bounds__(kThreads) void generic_color_kernel(const DecodeIma
 
 }  // namespace
 
-int launch_idct_plane(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+int launch_idct_plane(bool exact, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
 {
     if (nunits <= 0) return 0;
-    hipLaunchKernelGGL(idct_plane_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    if (exact)
+        hipLaunchKernelGGL(idct_plane_kernel<true>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    else
+        hipLaunchKernelGGL(idct_plane_kernel<false>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
     return (int)hipGetLastError();
 }
 
-int launch_luma_color(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+template <bool EXACT>
+static int launch_luma_color_t(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, hipStream_t s)
 {
-    if (nunits <= 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
     if (hs == 0)
-        hipLaunchKernelGGL((luma_color_kernel<0, 0>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<EXACT, 0, 0>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 1 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<1, 1>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<EXACT, 1, 1>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<2, 1>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<EXACT, 2, 1>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<2, 2>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<EXACT, 2, 2>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 1 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<1, 2>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<EXACT, 1, 2>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else
         return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
+}
+
+int launch_luma_color(bool exact, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    return exact ? launch_luma_color_t<true>(hs, vs, images, units, nunits, (hipStream_t)stream)
+                 : launch_luma_color_t<false>(hs, vs, images, units, nunits, (hipStream_t)stream);
 }
 
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)

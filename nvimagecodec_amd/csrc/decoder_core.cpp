@@ -91,7 +91,7 @@ void Buffer::release()
 
 // ---------------------------------------------------------------- DecodeBatch
 DecodeBatch::DecodeBatch(int device_id, const MemoryHooks* hooks)
-    : device_id_(device_id), hooks_(hooks), pinned_(Buffer::kPinned, hooks), device_(Buffer::kDevice, hooks), planes_(Buffer::kDevice, hooks)
+    : device_id_(device_id), pinned_(Buffer::kPinned, hooks), device_(Buffer::kDevice, hooks), planes_(Buffer::kDevice, hooks)
 {
 }
 
@@ -216,7 +216,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
                 plane_total += align_up((size_t)dc.plane_pitch * k.blocks_h * 8 + 16, 256);
             }
             if (needs_plane || to_output) max_units += units;
-            if (c == 0 && im.variant >= 0) max_units += units;
+            if (c == 0 && im.variant >= 0) max_units += (size_t)((k.blocks_w + 63) / 64) * (size_t)((k.blocks_h + 3) / 4);  // luma tiles 64x4
         }
         if (im.variant == -1) max_units += (size_t)f.height;
         coef_bytes_ += f.total_blocks() * 128;
@@ -275,9 +275,11 @@ void DecodeBatch::entropy_stage(int i)
 
 void DecodeBatch::finalize(hipjpegStatus_t* statuses)
 {
-    plane_units_.clear();
     generic_units_.clear();
-    for (auto& v : luma_units_) v.clear();
+    for (int e = 0; e < 2; e++) {
+        plane_units_[e].clear();
+        for (auto& v : luma_units_[e]) v.clear();
+    }
     const int n = (int)images_.size();
     for (int i = 0; i < n; i++) {
         PlannedImage& im = images_[i];
@@ -300,12 +302,15 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             bool to_output = (im.variant == -2) && (fmt == kOutPlanarYUV || c == 0);
             if (needs_plane || to_output) {
                 uint32_t mode = to_output ? (uint32_t)(kToOutput | (c << 8)) : (uint32_t)kToPlane;
-                for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) plane_units_.push_back(WorkUnit{(uint32_t)i, b, (uint32_t)c, mode});
+                for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) plane_units_[exact32].push_back(WorkUnit{(uint32_t)i, b, (uint32_t)c, mode});
             }
         }
         if (im.variant >= 0) {
-            const uint32_t nblk = (uint32_t)f.comp[0].blocks_w * f.comp[0].blocks_h;
-            for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) luma_units_[im.variant].push_back(WorkUnit{(uint32_t)i, b, 0u, 0u});
+            // luma tiles: 64 blocks wide x 4 block rows (one block row per wave); rows that are pure MCU padding are skipped
+            const uint32_t real_rows = (uint32_t)(f.height + 7) / 8;
+            for (uint32_t by = 0; by < real_rows; by += 4)
+                for (uint32_t bx = 0; bx < (uint32_t)f.comp[0].blocks_w; bx += 64)
+                    luma_units_[exact32][im.variant].push_back(WorkUnit{(uint32_t)i, bx, by, 0u});
         } else if (im.variant == -1) {
             for (int y = 0; y < f.height; y++) generic_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});
         }
@@ -319,8 +324,10 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         if (!v.empty()) memcpy(base + off, v.data(), v.size() * sizeof(WorkUnit));
         off += v.size() * sizeof(WorkUnit);
     };
-    put(plane_units_, &unit_off_plane_);
-    for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[k], &unit_off_luma_[k]);
+    for (int e = 0; e < 2; e++) {
+        put(plane_units_[e], &unit_off_plane_[e]);
+        for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[e][k], &unit_off_luma_[e][k]);
+    }
     put(generic_units_, &unit_off_generic_);
     finalized_ = true;
 }
@@ -356,18 +363,19 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which)
                     (void*)d.out[0], d.out_pitch[0]);
         }
         fprintf(stderr, "[hipjpeg] device=%p+%zu planes=%p+%zu unit offs plane=%zu generic=%zu coef_off=%zu staging=%zu\n", (void*)device_.data(),
-                device_.capacity(), (void*)planes_.data(), planes_.capacity(), unit_off_plane_, unit_off_generic_, coef_offset_, staging_bytes_);
+                device_.capacity(), (void*)planes_.data(), planes_.capacity(), unit_off_plane_[0], unit_off_generic_, coef_offset_, staging_bytes_);
         check("transfer", 0);
     }
     int rc = 0;
-    if (which < 0 || which == 0) {
-        rc = launch_idct_plane(dimg, units_at(unit_off_plane_), (int)plane_units_.size(), stream);
-        check("idct_plane", (int)plane_units_.size());
+    for (int e = 0; e < 2 && rc == 0 && (which < 0 || which == 0); e++) {
+        rc = launch_idct_plane(e == 1, dimg, units_at(unit_off_plane_[e]), (int)plane_units_[e].size(), stream);
+        check("idct_plane", (int)plane_units_[e].size());
     }
-    for (int k = 0; k < kNumLumaVariants && rc == 0 && (which < 0 || which == 1); k++) {
-        rc = launch_luma_color(hs[k], vs[k], dimg, units_at(unit_off_luma_[k]), (int)luma_units_[k].size(), stream);
-        check("luma_color", (int)luma_units_[k].size());
-    }
+    for (int e = 0; e < 2; e++)
+        for (int k = 0; k < kNumLumaVariants && rc == 0 && (which < 0 || which == 1); k++) {
+            rc = launch_luma_color(e == 1, hs[k], vs[k], dimg, units_at(unit_off_luma_[e][k]), (int)luma_units_[e][k].size(), stream);
+            check("luma_color", (int)luma_units_[e][k].size());
+        }
     if (rc == 0 && (which < 0 || which == 2)) {
         rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
         check("generic_color", (int)generic_units_.size());
@@ -386,9 +394,10 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which)
 void DecodeBatch::stats(int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes) const
 {
     if (num_units) {
-        num_units[0] = (int32_t)plane_units_.size();
+        num_units[0] = (int32_t)(plane_units_[0].size() + plane_units_[1].size());
         num_units[1] = 0;
-        for (const auto& v : luma_units_) num_units[1] += (int32_t)v.size();
+        for (int e = 0; e < 2; e++)
+            for (const auto& v : luma_units_[e]) num_units[1] += (int32_t)v.size();
         num_units[2] = (int32_t)generic_units_.size();
     }
     if (coef_bytes) *coef_bytes = coef_bytes_;

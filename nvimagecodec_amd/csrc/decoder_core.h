@@ -83,13 +83,13 @@ public:
 
 private:
     int device_id_;
-    const MemoryHooks* hooks_;
     Buffer pinned_, device_, planes_;
     std::vector<PlannedImage> images_;
     std::vector<DecodeImage> desc_;  // host copy (device pointers inside)
-    std::vector<WorkUnit> plane_units_, luma_units_[kNumLumaVariants], generic_units_;
+    // index [0] = 24-bit multiplier kernels, [1] = exact 32-bit multiplier kernels
+    std::vector<WorkUnit> plane_units_[2], luma_units_[2][kNumLumaVariants], generic_units_;
     size_t desc_offset_ = 0, units_offset_ = 0, coef_offset_ = 0, staging_bytes_ = 0, plane_bytes_ = 0;
-    size_t unit_off_plane_ = 0, unit_off_luma_[kNumLumaVariants] = {0}, unit_off_generic_ = 0;
+    size_t unit_off_plane_[2] = {0, 0}, unit_off_luma_[2][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0;
     uint64_t coef_bytes_ = 0, output_bytes_ = 0;
     bool finalized_ = false;
     void* done_event_ = nullptr;  // hipEvent_t recorded after the last launch that reads this batch's buffers
