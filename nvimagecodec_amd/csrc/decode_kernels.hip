@@ -1,15 +1,21 @@
 // decode_kernels.hip -- gfx950 kernels of the JPEG decode device stage
 // (what nvjpegDecodeJpegDevice does for the reference: extensions/nvjpeg/cuda_decoder.cpp:546-549).
 //
-// Mapping to the machine (wave64, 256 CUs, 160 KB LDS/CU, no MFMA -- this is integer butterfly + byte work):
-//   * one LANE owns one 8x8 block: both 1-D passes of the ISLOW IDCT run in that lane's registers, so there is
-//     no cross-lane transpose at all and every lane is busy.
-//   * coefficient blocks are fetched from HBM with fully coalesced 16 B/lane loads (a wave reads 8 KB contiguous),
-//     staged through LDS with a 144-byte block stride (bank-conflict-free ds_read_b128), and each lane then pulls
-//     its own 128-byte block out of LDS.  Host code stores blocks column-major so one 16-byte chunk is one IDCT column.
-//   * idct_plane_kernel writes component planes (coalesced 8 B/lane rows); luma_color_kernel fuses the luma IDCT with
-//     chroma upsampling (libjpeg "fancy" triangle filters), YCbCr->RGB and the output store, so the big luma plane and
-//     the RGB image never make an extra HBM round trip.
+// Mapping to the machine (wave64, 256 CUs, 160 KB LDS/CU, no MFMA -- this is integer butterfly + byte work).
+// Profiling the first version (one lane per block, ~200 VGPRs, 2 waves/SIMD) showed it VALU-issue bound at ~4 cycles
+// per instruction even with every memory stream ablated, so the design goal here is register economy -> occupancy:
+//   * TWO LANES own one 8x8 block (lane pair 2k, 2k+1; p = lane & 1).  Lane p runs the column pass of columns
+//     4p..4p+3, then the pair swaps half of the workspace with one DPP move per value, and lane p runs the row pass of
+//     four rows.  The ISLOW butterfly is an exact integer-linear map followed by one rounding shift, and negating its
+//     odd-frequency inputs reverses its output order exactly (mod 2^32).  Lane 1 therefore multiplies odd rows by -q in
+//     the dequantizer (a second quant table prepared by the host) and gets its column results in the order 7..0: both
+//     lanes then "keep registers 0..3, send registers 4..7" -- no per-lane selects in the exchange.
+//   * coefficient blocks are fetched from HBM with fully coalesced 16 B/lane loads (a wave reads 4 KB contiguous), staged
+//     through LDS at a 144-byte block stride, and each lane pulls its four 16-byte column chunks back out.  The host
+//     stores blocks column-major so one chunk is one IDCT column.
+//   * idct_plane_kernel writes component planes; luma_color_kernel fuses the luma IDCT with chroma upsampling
+//     (libjpeg "fancy" triangle filters), YCbCr->RGB and the output store; interleaved RGB rows are staged in LDS and
+//     leave the wave as fully coalesced 16-byte stores.
 //   * work is described by WorkUnit tables so a batch of different-shaped images is ONE launch per kernel.
 //
 // Arithmetic is the integer arithmetic of libjpeg-turbo's jidctint.c / jdsample.c / jdcolor.c, restated; results are
@@ -25,10 +31,10 @@ namespace {
 
 constexpr int kThreads = 256;
 #ifndef HJ_MIN_WAVES
-#define HJ_MIN_WAVES 2
+#define HJ_MIN_WAVES 4
 #endif
-constexpr int kLdsBlockStride = 144;  // 128 B of coefficients + 16 B pad: ds_read_b128 at lane stride 144 B hits 64 distinct banks
-constexpr int kLdsWaveBytes = 64 * kLdsBlockStride;
+constexpr int kBlocksPerWave = 32;     // two lanes per block
+constexpr int kLdsBlockStride = 144;   // 128 B of coefficients + 16 B pad -> conflict-free ds_read_b128 at this lane stride
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
@@ -88,10 +94,10 @@ __device__ __forceinline__ void idct8(int (&d)[8])
     d[4] = (tmp13 - t0) >> SHIFT;
 }
 
-// libjpeg's post-IDCT range-limit table (jdmaster.c prepare_range_limit_table) as arithmetic:
-// index = v & 1023 read as a signed 10-bit number, +128, clamped to [0,255].
 __device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }  // v_med3_i32
 
+// libjpeg's post-IDCT range-limit table (jdmaster.c prepare_range_limit_table) as arithmetic:
+// index = v & 1023 read as a signed 10-bit number, +128, clamped to [0,255].
 __device__ __forceinline__ int range_limit(int v)
 {
     int s = __builtin_amdgcn_sbfe(v, 0, 10);
@@ -100,16 +106,27 @@ __device__ __forceinline__ int range_limit(int v)
 
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) { return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24); }
 
-// Coalesced HBM -> LDS staging of the 64 blocks a wave owns, then each lane reads back its own block.
-// cols[c] = the 16-byte column chunk c of this lane's block.
-__device__ __forceinline__ void fetch_block(const int16_t* __restrict__ comp_coef, int wave_first_block, int nblocks, char* lds_wave, int lane,
-                                            u32x4 (&cols)[8])
+// value held by the other lane of the pair (quad_perm [1,0,3,2])
+__device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS operations of one wave execute in order; only the compiler has to be kept from reordering across the hand-off
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Coalesced HBM -> LDS staging of the 32 blocks a wave owns (4 KB contiguous), then each lane reads back the four
+// 16-byte column chunks of its half block: columns 4p .. 4p+3 of block lane>>1.
+__device__ __forceinline__ void fetch_half_block(const int16_t* __restrict__ comp_coef, int wave_first_block, int block_limit, char* lds_wave,
+                                                 int lane, u32x4 (&cols)[4])
 {
     const u32x4* src = reinterpret_cast<const u32x4*>(comp_coef) + (size_t)wave_first_block * 8;
-    const int nchunks = min(64, nblocks - wave_first_block) * 8;  // valid 16-byte chunks for this wave (may be <= 0)
+    const int nchunks = min(kBlocksPerWave, block_limit - wave_first_block) * 8;  // valid 16-byte chunks (may be <= 0)
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        int g = k * 64 + lane;
+    for (int k = 0; k < 4; k++) {
+        const int g = k * 64 + lane;
         u32x4 v = {0u, 0u, 0u, 0u};
 #ifdef HJ_ABLATE_COEF
         if (g < nchunks) v = u32x4{(unsigned)g, 1u, 0u, 0u};
@@ -118,53 +135,65 @@ __device__ __forceinline__ void fetch_block(const int16_t* __restrict__ comp_coe
 #endif
         *reinterpret_cast<u32x4*>(lds_wave + (g >> 3) * kLdsBlockStride + (g & 7) * 16) = v;
     }
-    // Each wave reads back only what it wrote itself.  LDS operations of one wave execute in order, so no workgroup
-    // barrier is needed -- only a compiler-level fence so the reads are not hoisted above the writes.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_fence();
+    const char* mine = lds_wave + (lane >> 1) * kLdsBlockStride + (lane & 1) * 64;
 #pragma unroll
-    for (int c = 0; c < 8; c++) cols[c] = *reinterpret_cast<const u32x4*>(lds_wave + lane * kLdsBlockStride + c * 16);
+    for (int j = 0; j < 4; j++) cols[j] = *reinterpret_cast<const u32x4*>(mine + j * 16);
 }
 
-// Dequantize + column pass.  ws[r][c] afterwards holds the pass-1 workspace.
+// Dequantize + column pass of this lane's four columns, exchange with the partner lane, and assemble the row-pass inputs.
+//   q: this lane's 32 quantizers, q[j*8 + r] for column 4p+j, with odd rows negated when p == 1 (DecodeComponent::qpair).
+//   rows[i][c]: pass-1 workspace of image row (p ? 7-i : i), column c -- ready for idct8<false,18>.
 template <bool EXACT>
-__device__ __forceinline__ void dequant_column_pass(const u32x4 (&cols)[8], const uint16_t* __restrict__ qt, int (&ws)[8][8])
+__device__ __forceinline__ void column_pass_and_exchange(const u32x4 (&cols)[4], const int* __restrict__ q, bool p, int (&rows)[4][8])
 {
+    int keep[4][4], recv[4][4];
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const unsigned w[4] = {cols[c].x, cols[c].y, cols[c].z, cols[c].w};
+    for (int j = 0; j < 4; j++) {
+        const unsigned w[4] = {cols[j].x, cols[j].y, cols[j].z, cols[j].w};
+        const int4 qa = *reinterpret_cast<const int4*>(q + j * 8), qb = *reinterpret_cast<const int4*>(q + j * 8 + 4);
+        const int qq[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
         int d[8];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            int lo = (int)(short)(w[i] & 0xFFFF);
-            int hi = (int)w[i] >> 16;
-            // coefficient (int16) x quantizer (<= 16 bit): always exact in the 24-bit multiplier
-            d[2 * i] = __mul24(lo, (int)qt[c * 8 + 2 * i]);
-            d[2 * i + 1] = __mul24(hi, (int)qt[c * 8 + 2 * i + 1]);
+            const int lo = (int)(short)(w[i] & 0xFFFF), hi = (int)w[i] >> 16;
+            // coefficient (int16) x quantizer (|q| < 2^16): exact in the 24-bit multiplier
+            d[2 * i] = __mul24(lo, qq[2 * i]);
+            d[2 * i + 1] = __mul24(hi, qq[2 * i + 1]);
         }
-        idct8<EXACT, 11>(d);
+        idct8<EXACT, 11>(d);  // lane 0: d[r] = row r; lane 1 (odd inputs negated): d[r] = row 7-r
 #pragma unroll
-        for (int r = 0; r < 8; r++) ws[r][c] = d[r];
+        for (int i = 0; i < 4; i++) {
+            keep[i][j] = d[i];
+            recv[i][j] = pair_swap(d[7 - i]);  // partner's value for MY row i: its register 7-i
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            rows[i][j] = p ? recv[i][j] : keep[i][j];      // columns 0..3 were computed by lane 0
+            rows[i][4 + j] = p ? keep[i][j] : recv[i][j];  // columns 4..7 by lane 1
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: IDCT of 256 consecutive blocks of one component into a u8 plane (internal plane or user output).
+// K1: IDCT of 128 consecutive blocks of one component into a u8 plane (internal plane or user output).
 // ------------------------------------------------------------------------------------------------
 template <bool EXACT>
 __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool p = lane & 1;
     const DecodeComponent& cd = im.comp[u.comp];
     const int bw = cd.blocks_w, nblocks = bw * cd.blocks_h;
-    const int wave_first = u.block_base + wave * 64;
-    u32x4 cols[8];
-    fetch_block(cd.coef, wave_first, nblocks, lds + wave * kLdsWaveBytes, lane, cols);
-    const int b = wave_first + lane;
-    if (b >= nblocks) return;
-    int ws[8][8];
-    dequant_column_pass<EXACT>(cols, cd.qt, ws);
+    const int wave_first = u.block_base + wave * kBlocksPerWave;
+    u32x4 cols[4];
+    fetch_half_block(cd.coef, wave_first, nblocks, lds + wave * kBlocksPerWave * kLdsBlockStride, lane, cols);
+    const int b = wave_first + (lane >> 1);
+    if (b >= nblocks) return;  // whole pairs leave together
+    int rows[4][8];
+    column_pass_and_exchange<EXACT>(cols, EXACT ? cd.qpair_exact[p] : cd.qpair[p], p, rows);
 
     const int by = b / bw, bx = b - by * bw;
     const bool to_out = (u.mode & 0xFF) == kToOutput;
@@ -176,25 +205,23 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
     const int lim_h = to_out ? cd.samp_h : cd.blocks_h * 8;
     const int x0 = bx * 8, y0 = by * 8;
     if (x0 >= lim_w) return;
-    uint8_t* p = dst + (size_t)y0 * pitch + x0;
-    const bool fast = (x0 + 8 <= lim_w) && (((uintptr_t)p | pitch) & 7) == 0;
+    uint8_t* base = dst + (size_t)y0 * pitch + x0;
+    const bool fast = (x0 + 8 <= lim_w) && (((uintptr_t)base | pitch) & 7) == 0;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        int d[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) d[c] = ws[r][c];
-        idct8<false, 18>(d);
+    for (int i = 0; i < 4; i++) {
+        idct8<false, 18>(rows[i]);
+        const int r = p ? 7 - i : i;
         if (y0 + r < lim_h) {
             int px[8];
 #pragma unroll
-            for (int c = 0; c < 8; c++) px[c] = range_limit(d[c]);
-            uint8_t* q = p + (size_t)r * pitch;
+            for (int c = 0; c < 8; c++) px[c] = range_limit(rows[i][c]);
+            uint8_t* qd = base + (size_t)r * pitch;
             if (fast) {
-                *reinterpret_cast<uint2*>(q) = make_uint2(pack4(px[0], px[1], px[2], px[3]), pack4(px[4], px[5], px[6], px[7]));
+                *reinterpret_cast<uint2*>(qd) = make_uint2(pack4(px[0], px[1], px[2], px[3]), pack4(px[4], px[5], px[6], px[7]));
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; c++)
-                    if (x0 + c < lim_w) q[c] = (uint8_t)px[c];
+                    if (x0 + c < lim_w) qd[c] = (uint8_t)px[c];
             }
         }
     }
@@ -203,7 +230,7 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
 template <bool EXACT>
 __global__ __launch_bounds__(kThreads, HJ_MIN_WAVES) void idct_plane_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
-    __shared__ __attribute__((aligned(16))) char lds[4 * kLdsWaveBytes];
+    __shared__ __attribute__((aligned(16))) char lds[4 * kBlocksPerWave * kLdsBlockStride];
     const WorkUnit u = units[blockIdx.x];
     idct_plane_body<EXACT>(images[u.image], u, lds);
 }
@@ -212,48 +239,50 @@ __global__ __launch_bounds__(kThreads, HJ_MIN_WAVES) void idct_plane_kernel(cons
 // K2: luma IDCT fused with chroma upsampling, colour conversion and the output store.
 //   HS, VS = chroma upsampling factors (1 or 2); HS == 0 means "no chroma" (gray source -> RGB).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int byte_of(unsigned long long v, int j) { return (int)((v >> (8 * j)) & 0xFF); }
+__device__ __forceinline__ int byte_of(uint2 v, int j) { return (int)__builtin_amdgcn_ubfe(j < 4 ? v.x : v.y, 8 * (j & 3), 8); }
 
-// Loads the chroma window rows this lane needs.  After the call, byte j of rows[i] is the sample at
-// (clamp(wy + i, 0, dh-1), clamp(wx + j, 0, dw-1)) -- i.e. libjpeg's edge replication is already applied.
-template <int NR, int NW>
-__device__ __forceinline__ void load_chroma_window(const uint8_t* __restrict__ plane, unsigned pitch, int dw, int dh, int wx, int wy,
-                                                   unsigned long long (&rows)[NR])
+// Loads four chroma window rows.  Row k of the result is window row (p ? first_row + 3 - k : first_row + k) -- lane 1 works
+// through its image rows in descending order, so it loads its window upside down and both lanes index it identically.
+// Byte j of a row is the sample at column clamp(wx + j, 0, dw-1): libjpeg's edge replication is already applied.
+template <int NW>
+__device__ __forceinline__ void load_chroma_rows(const uint8_t* __restrict__ plane, unsigned pitch, int dw, int dh, int wx, int first_row, bool p,
+                                                 uint2 (&rows)[4])
 {
     const int base = max(wx, 0);
     const bool edge = (wx < 0) || (wx + NW - 1 > dw - 1);
 #pragma unroll
-    for (int i = 0; i < NR; i++) {
-        int y = min(max(wy + i, 0), dh - 1);
-        const uint8_t* p = plane + (size_t)y * pitch + base;
+    for (int k = 0; k < 4; k++) {
+        const int y = min(max(first_row + (p ? 3 - k : k), 0), dh - 1);
+        const uint8_t* src = plane + (size_t)y * pitch + base;
         // planes are allocated with >= 16 bytes of slack per row, so an 8-byte read starting inside the row is in bounds
-        unsigned long long v;
+        uint2 v;
 #ifdef HJ_ABLATE_CHROMA
-        v = 0x8080808080808080ull + (unsigned long long)(uintptr_t)p;
+        v = make_uint2(0x80808080u + (unsigned)(uintptr_t)src, 0x80808080u);
 #else
-        __builtin_memcpy(&v, p, 8);
+        __builtin_memcpy(&v, src, 8);
 #endif
-        rows[i] = v;
+        rows[k] = v;
     }
     if (__builtin_amdgcn_ballot_w64(edge) != 0) {
         if (edge) {
 #pragma unroll
-            for (int i = 0; i < NR; i++) {
-                unsigned long long v = rows[i], f = 0;
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long v = ((unsigned long long)rows[k].y << 32) | rows[k].x;
+                unsigned long long f = 0;
 #pragma unroll
                 for (int j = 0; j < NW; j++) {
-                    int idx = min(max(wx + j, 0), dw - 1) - base;
+                    const int idx = min(max(wx + j, 0), dw - 1) - base;
                     f |= ((v >> (8 * idx)) & 0xFFull) << (8 * j);
                 }
-                rows[i] = f;
+                rows[k] = make_uint2((unsigned)f, (unsigned)(f >> 32));
             }
         }
     }
 }
 
-// Upsampled chroma for one output row of the lane's 8 pixels.
+// Upsampled chroma for one output row of the lane's 8 pixels.  `odd_row`: the image row is odd (matters for h1v2 only).
 template <int HS, int VS>
-__device__ __forceinline__ void upsample_row(unsigned long long near, unsigned long long far, int r, bool fancy, int (&o)[8])
+__device__ __forceinline__ void upsample_row(uint2 near, uint2 far, bool odd_row, bool fancy, int (&o)[8])
 {
     if constexpr (HS == 2) {
         // window byte j <-> chroma column (4*bx - 1 + j); output pixel 2i+e sits over window column i+1
@@ -282,7 +311,7 @@ __device__ __forceinline__ void upsample_row(unsigned long long near, unsigned l
         }
     } else {
         if (VS == 2 && fancy) {
-            const int bias = (r & 1) ? 2 : 1;
+            const int bias = odd_row ? 2 : 1;
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = (3 * byte_of(near, j) + byte_of(far, j) + bias) >> 2;
         } else {
@@ -292,27 +321,27 @@ __device__ __forceinline__ void upsample_row(unsigned long long near, unsigned l
     }
 }
 
-// Work unit of this kernel: a tile of 64 x 4 luma blocks -- block_base = first block column, comp = first block row;
-// wave w of the workgroup owns the 64 consecutive blocks of block row (comp + w).
-constexpr int kLumaTileW = 64, kLumaTileH = 4;
-constexpr int kOutRowBytes = 64 * 24;               // one pixel row of a wave's 64 blocks, interleaved RGB
-constexpr int kLdsLumaWaveBytes = 8 * kOutRowBytes;  // 12,288 B: first the coefficient staging (9,216 B), then the RGB tile
+// Work unit of this kernel: a tile of 32 x 4 luma blocks -- block_base = first block column, comp = first block row;
+// wave w of the workgroup owns the 32 consecutive blocks of block row (comp + w).
+constexpr int kOutRowBytes = kBlocksPerWave * 24 + 16;  // one pixel row of a wave's 32 blocks (interleaved RGB) + bank-skew pad
+constexpr int kLdsLumaWaveBytes = 8 * kOutRowBytes;     // 6,272 B: first the coefficient staging (4,608 B), then the RGB tile
 
 template <bool EXACT, int HS, int VS>
 __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool p = lane & 1;
+    const int blk = lane >> 1;
     const int bw = im.comp[0].blocks_w, bh = im.comp[0].blocks_h;
     const int bx0 = u.block_base, by = (int)u.comp + wave;
-    const int bx = bx0 + lane;
-    const int wave_first = by * bw + bx0;
+    const int bx = bx0 + blk;
     char* lds_wave = lds + wave * kLdsLumaWaveBytes;
-    u32x4 cols[8];
+    u32x4 cols[4];
     // the wave's blocks are contiguous in memory up to the end of the block row
-    fetch_block(im.comp[0].coef, wave_first, by < bh ? (by + 1) * bw : 0, lds_wave, lane, cols);
+    fetch_half_block(im.comp[0].coef, by * bw + bx0, by < bh ? (by + 1) * bw : 0, lds_wave, lane, cols);
     const int x0 = bx * 8, y0 = by * 8;
     const int W = im.width, H = im.height;
-    const bool valid = bx < bw && by < bh && x0 < W && y0 < H;  // false: lane idles (block is MCU padding or outside the tile)
+    const bool valid = bx < bw && by < bh && x0 < W && y0 < H;  // false: pair idles (block is MCU padding or outside the tile)
 
     const int fmt = im.out_format;
     const bool planar = fmt == kOutPlanarRGB || fmt == kOutPlanarBGR;
@@ -320,58 +349,54 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     const bool ycc = im.color_model == 1;
     const bool full = x0 + 8 <= W;
     // Interleaved output whose rows are 16-byte aligned goes through an LDS tile so that the wave emits 16 B per lane,
-    // fully coalesced: 12 store instructions per wave instead of 24 strided 8-byte ones per lane (store-issue bound).
+    // fully coalesced, instead of 24-byte-strided 8-byte stores.
     const bool staged = !planar && ((((uintptr_t)im.out[0]) | im.out_pitch[0]) & 15) == 0;
 
     if (valid) {
-        // chroma window (issued before the IDCT so the loads fly while we compute)
+        // chroma window rows for this lane's four image rows (issued before the IDCT so the loads fly while we compute)
         constexpr int NW = HS == 2 ? 6 : 8;
-        constexpr int NR = (HS == 0) ? 1 : (VS == 2 ? 6 : 8);
-        unsigned long long cbw[NR], crw[NR];
+        uint2 cbw[4], crw[4];
         bool fancy = false;
         if constexpr (HS != 0) {
             const int dw = im.comp[1].samp_w, dh = im.comp[1].samp_h;
             // libjpeg picks the triangle filters only when do_fancy_upsampling and (for h2v1/h2v2) downsampled_width > 2
             fancy = (im.flags & kFlagFancyUpsampling) && (HS == 1 || dw > 2);
             const int wx = HS == 2 ? 4 * bx - 1 : 8 * bx;
-            const int wy = VS == 2 ? 4 * by - 1 : 8 * by;
-            load_chroma_window<NR, NW>(im.comp[1].plane, im.comp[1].plane_pitch, dw, dh, wx, wy, cbw);
-            load_chroma_window<NR, NW>(im.comp[2].plane, im.comp[2].plane_pitch, dw, dh, wx, wy, crw);
+            // VS == 2: image rows 0..3 need chroma rows 4by-1 .. 4by+2, rows 4..7 need 4by+1 .. 4by+4;  VS == 1: rows map 1:1
+            const int first = VS == 2 ? 4 * by - 1 + (p ? 2 : 0) : 8 * by + (p ? 4 : 0);
+            load_chroma_rows<NW>(im.comp[1].plane, im.comp[1].plane_pitch, dw, dh, wx, first, p, cbw);
+            load_chroma_rows<NW>(im.comp[2].plane, im.comp[2].plane_pitch, dw, dh, wx, first, p, crw);
         }
 
-        int ws[8][8];
-        dequant_column_pass<EXACT>(cols, im.comp[0].qt, ws);
+        int rows[4][8];
+        column_pass_and_exchange<EXACT>(cols, EXACT ? im.comp[0].qpair_exact[p] : im.comp[0].qpair[p], p, rows);
 
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            int d[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) d[c] = ws[r][c];
-            idct8<false, 18>(d);
+        for (int i = 0; i < 4; i++) {
+            idct8<false, 18>(rows[i]);
+            const int r = p ? 7 - i : i;  // image row inside the block
             if (y0 + r >= H) continue;
             int R[8], G[8], B[8];
             if constexpr (HS == 0) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) R[c] = G[c] = B[c] = range_limit(d[c]);
+                for (int c = 0; c < 8; c++) R[c] = G[c] = B[c] = range_limit(rows[i][c]);
             } else {
                 int cb[8], cr[8];
-                int near, far;
-                if constexpr (VS == 2) {
-                    near = 1 + (r >> 1);
-                    far = (r & 1) ? near + 1 : near - 1;
-                } else {
-                    near = far = r;
-                }
-                upsample_row<HS, VS>(cbw[near], cbw[far], r, fancy, cb);
-                upsample_row<HS, VS>(crw[near], crw[far], r, fancy, cr);
+                // local window-row indices are the same for both lanes (lane 1's window is loaded upside down):
+                //   VS == 2:  i = 0: near 1 far 0 | 1: near 1 far 2 | 2: near 2 far 1 | 3: near 2 far 3      VS == 1: row i
+                constexpr int kNear[4] = {1, 1, 2, 2}, kFar[4] = {0, 2, 1, 3};
+                const int near = VS == 2 ? kNear[i] : i, far = VS == 2 ? kFar[i] : i;
+                const bool odd_row = (i & 1) != (int)p;  // r = i or 7 - i
+                upsample_row<HS, VS>(cbw[near], cbw[far], odd_row, fancy, cb);
+                upsample_row<HS, VS>(crw[near], crw[far], odd_row, fancy, cr);
                 if (ycc) {
                     // jdcolor.c ycc_rgb_convert with SCALEBITS = 16; (x - 128) folded into the additive constants
 #pragma unroll
                     for (int c = 0; c < 8; c++) {
-                        int y = range_limit(d[c]);
-                        int rr = (__mul24(cr[c], 91881) + (32768 - 128 * 91881)) >> 16;
-                        int bb = (__mul24(cb[c], 116130) + (32768 - 128 * 116130)) >> 16;
-                        int gg = (__mul24(cb[c], -22554) + __mul24(cr[c], -46802) + (32768 + 128 * 22554 + 128 * 46802)) >> 16;
+                        const int y = range_limit(rows[i][c]);
+                        const int rr = (__mul24(cr[c], 91881) + (32768 - 128 * 91881)) >> 16;
+                        const int bb = (__mul24(cb[c], 116130) + (32768 - 128 * 116130)) >> 16;
+                        const int gg = (__mul24(cb[c], -22554) + __mul24(cr[c], -46802) + (32768 + 128 * 22554 + 128 * 46802)) >> 16;
                         R[c] = clamp255(y + rr);
                         G[c] = clamp255(y + gg);
                         B[c] = clamp255(y + bb);
@@ -380,7 +405,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
                     // Adobe RGB JPEG: the three components already are R, G, B
 #pragma unroll
                     for (int c = 0; c < 8; c++) {
-                        R[c] = range_limit(d[c]);
+                        R[c] = range_limit(rows[i][c]);
                         G[c] = cb[c];
                         B[c] = cr[c];
                     }
@@ -389,7 +414,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
             if (bgr) {
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
-                    int t = R[c];
+                    const int t = R[c];
                     R[c] = B[c];
                     B[c] = t;
                 }
@@ -417,15 +442,14 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
                 const uint2 q1 = make_uint2(pack4(B[2], R[3], G[3], B[3]), pack4(R[4], G[4], B[4], R[5]));
                 const uint2 q2 = make_uint2(pack4(G[5], B[5], R[6], G[6]), pack4(B[6], R[7], G[7], B[7]));
                 if (staged) {
-                    // 24-byte lane stride: the 16 lanes of a ds_write_b64 group land on 32 distinct banks
-                    uint2* t = reinterpret_cast<uint2*>(lds_wave + r * kOutRowBytes + lane * 24);
+                    uint2* t = reinterpret_cast<uint2*>(lds_wave + r * kOutRowBytes + blk * 24);
                     t[0] = q0;
                     t[1] = q1;
                     t[2] = q2;
                 } else {
-                    uint8_t* p = im.out[0] + (size_t)y * im.out_pitch[0] + (size_t)x0 * 3;
-                    if (full && ((uintptr_t)p & 7) == 0) {
-                        uint2* q = reinterpret_cast<uint2*>(p);
+                    uint8_t* o = im.out[0] + (size_t)y * im.out_pitch[0] + (size_t)x0 * 3;
+                    if (full && ((uintptr_t)o & 7) == 0) {
+                        uint2* q = reinterpret_cast<uint2*>(o);
                         q[0] = q0;
                         q[1] = q1;
                         q[2] = q2;
@@ -433,9 +457,9 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 #pragma unroll
                         for (int c = 0; c < 8; c++)
                             if (x0 + c < W) {
-                                p[3 * c] = (uint8_t)R[c];
-                                p[3 * c + 1] = (uint8_t)G[c];
-                                p[3 * c + 2] = (uint8_t)B[c];
+                                o[3 * c] = (uint8_t)R[c];
+                                o[3 * c + 1] = (uint8_t)G[c];
+                                o[3 * c + 2] = (uint8_t)B[c];
                             }
                     }
                 }
@@ -444,17 +468,15 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     }
 
     if (!staged || by >= bh || y0 >= H) return;  // wave-uniform
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_fence();
     // the wave's tile: rows y0..y0+7, bytes [bx0*24, bx0*24 + row_bytes) of each row
-    const int row_bytes = min(W - bx0 * 8, kLumaTileW * 8) * 3;
+    const int row_bytes = min(W - bx0 * 8, kBlocksPerWave * 8) * 3;
     const int nrows = min(8, H - y0);
     uint8_t* out_base = im.out[0] + (size_t)y0 * im.out_pitch[0] + (size_t)bx0 * 24;
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
-        const int g = k * 64 + lane;  // 16-byte chunk of the 8 x 1536 B tile
-        const int r = g / 96, off = (g - r * 96) * 16;
+    for (int k = 0; k < 6; k++) {
+        const int g = k * 64 + lane;  // 16-byte chunk of the 8 x 768 B tile
+        const int r = g / 48, off = (g - r * 48) * 16;
         if (r < nrows && off < row_bytes) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(lds_wave + r * kOutRowBytes + off);
             uint8_t* dst = out_base + (size_t)r * im.out_pitch[0] + off;

@@ -202,7 +202,12 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
             dc.samp_h = (uint16_t)k.samp_h;
             dc.h = (uint16_t)k.h;
             dc.v = (uint16_t)k.v;
-            for (int j = 0; j < 64; j++) dc.qt[(j & 7) * 8 + (j >> 3)] = f.qtab[c][j];  // natural -> column-major
+            for (int pp = 0; pp < 2; pp++)
+                for (int j = 0; j < 4; j++)
+                    for (int r = 0; r < 8; r++) {
+                        const int q = f.qtab[c][r * 8 + 4 * pp + j];
+                        dc.qpair[pp][j * 8 + r] = dc.qpair_exact[pp][j * 8 + r] = (pp && (r & 1)) ? -q : q;
+                    }
             const size_t nblk = (size_t)k.blocks_w * k.blocks_h;
             im.coef_offset[c] = coef_total;
             coef_total += nblk * 128;
@@ -216,7 +221,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
                 plane_total += align_up((size_t)dc.plane_pitch * k.blocks_h * 8 + 16, 256);
             }
             if (needs_plane || to_output) max_units += units;
-            if (c == 0 && im.variant >= 0) max_units += (size_t)((k.blocks_w + 63) / 64) * (size_t)((k.blocks_h + 3) / 4);  // luma tiles 64x4
+            if (c == 0 && im.variant >= 0) max_units += (size_t)((k.blocks_w + kLumaTileW - 1) / kLumaTileW) * (size_t)((k.blocks_h + kLumaTileH - 1) / kLumaTileH);
         }
         if (im.variant == -1) max_units += (size_t)f.height;
         coef_bytes_ += f.total_blocks() * 128;
@@ -306,10 +311,10 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             }
         }
         if (im.variant >= 0) {
-            // luma tiles: 64 blocks wide x 4 block rows (one block row per wave); rows that are pure MCU padding are skipped
+            // luma tiles: 32 blocks wide x 4 block rows (one block row per wave); rows that are pure MCU padding are skipped
             const uint32_t real_rows = (uint32_t)(f.height + 7) / 8;
-            for (uint32_t by = 0; by < real_rows; by += 4)
-                for (uint32_t bx = 0; bx < (uint32_t)f.comp[0].blocks_w; bx += 64)
+            for (uint32_t by = 0; by < real_rows; by += kLumaTileH)
+                for (uint32_t bx = 0; bx < (uint32_t)f.comp[0].blocks_w; bx += kLumaTileW)
                     luma_units_[exact32][im.variant].push_back(WorkUnit{(uint32_t)i, bx, by, 0u});
         } else if (im.variant == -1) {
             for (int y = 0; y < f.height; y++) generic_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});

@@ -39,7 +39,11 @@ struct alignas(16) DecodeComponent {
     uint16_t blocks_w, blocks_h;  // MCU-padded block grid
     uint16_t samp_w, samp_h;      // true component size in samples
     uint16_t h, v;                // sampling factors
-    uint16_t qt[64];              // column-major like the coefficients
+    // Quantizers as the kernels consume them: qpair[p][j*8 + r] = q(row r, column 4p+j), with odd rows NEGATED for p == 1
+    // (lane 1 of a pair runs its column butterflies with negated odd inputs, which reverses their output order exactly).
+    // qpair serves both the 24-bit-multiplier kernels and the exact ones (same values).
+    int32_t qpair[2][32];
+    int32_t qpair_exact[2][32];
 };
 
 struct alignas(16) DecodeImage {
@@ -64,6 +68,7 @@ enum PlaneUnitMode : uint32_t {
     kToOutput = 1,  // write into DecodeImage::out[mode>>8], cropped to samp_w x samp_h
 };
 
-constexpr int kBlocksPerUnit = 256;
+constexpr int kBlocksPerUnit = 128;  // idct_plane_kernel: 256 lanes, two lanes per block
+constexpr int kLumaTileW = 32, kLumaTileH = 4;  // luma_color_kernel tile in blocks (one block row per wave)
 
 }  // namespace hipjpeg
