@@ -96,6 +96,16 @@ __device__ __forceinline__ void idct8(int (&d)[8])
 
 __device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }  // v_med3_i32
 
+// a * k + c on the full-rate 24-bit multiplier.  hipcc rewrites __mul24 of provably small operands into a plain 32-bit
+// multiply and then selects the quarter-rate v_mul_lo_u32 (seen in the ISA: 130 of them per lane in the colour stage), so
+// the colour arithmetic pins the instruction.  |a| < 2^8 and |k| < 2^17 here: exact.
+__device__ __forceinline__ int mad24(int a, int k, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+}
+
 // libjpeg's post-IDCT range-limit table (jdmaster.c prepare_range_limit_table) as arithmetic:
 // index = v & 1023 read as a signed 10-bit number, +128, clamped to [0,255].
 __device__ __forceinline__ int range_limit(int v)
@@ -215,7 +225,7 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
             int px[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) px[c] = range_limit(rows[i][c]);
-            uint8_t* qd = base + (size_t)r * pitch;
+            uint8_t* qd = base + __umul24((unsigned)r, pitch);
             if (fast) {
                 *reinterpret_cast<uint2*>(qd) = make_uint2(pack4(px[0], px[1], px[2], px[3]), pack4(px[4], px[5], px[6], px[7]));
             } else {
@@ -253,7 +263,7 @@ __device__ __forceinline__ void load_chroma_rows(const uint8_t* __restrict__ pla
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int y = min(max(first_row + (p ? 3 - k : k), 0), dh - 1);
-        const uint8_t* src = plane + (size_t)y * pitch + base;
+        const uint8_t* src = plane + (__umul24((unsigned)y, pitch) + (unsigned)base);  // planes are far smaller than 4 GB
         // planes are allocated with >= 16 bytes of slack per row, so an 8-byte read starting inside the row is in bounds
         uint2 v;
 #ifdef HJ_ABLATE_CHROMA
@@ -370,6 +380,8 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 
         int rows[4][8];
         column_pass_and_exchange<EXACT>(cols, EXACT ? im.comp[0].qpair_exact[p] : im.comp[0].qpair[p], p, rows);
+        // additive constants of the colour conversion (kept in VGPRs: a VOP3 instruction reads one scalar operand at most)
+        const int kr = 32768 - 128 * 91881, kb = 32768 - 128 * 116130, kg = 32768 + 128 * 22554 + 128 * 46802;
 
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -394,9 +406,9 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 #pragma unroll
                     for (int c = 0; c < 8; c++) {
                         const int y = range_limit(rows[i][c]);
-                        const int rr = (__mul24(cr[c], 91881) + (32768 - 128 * 91881)) >> 16;
-                        const int bb = (__mul24(cb[c], 116130) + (32768 - 128 * 116130)) >> 16;
-                        const int gg = (__mul24(cb[c], -22554) + __mul24(cr[c], -46802) + (32768 + 128 * 22554 + 128 * 46802)) >> 16;
+                        const int rr = mad24(cr[c], 91881, kr) >> 16;
+                        const int bb = mad24(cb[c], 116130, kb) >> 16;
+                        const int gg = mad24(cr[c], -46802, mad24(cb[c], -22554, kg)) >> 16;
                         R[c] = clamp255(y + rr);
                         G[c] = clamp255(y + gg);
                         B[c] = clamp255(y + bb);
@@ -419,11 +431,11 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
                     B[c] = t;
                 }
             }
-            const int y = y0 + r;
+            // row offsets: (wave-uniform 64-bit part) + (per-lane 32-bit part) keeps 64-bit multiplies off the vector ALU
             if (planar) {
-                uint8_t* p0 = im.out[0] + (size_t)y * im.out_pitch[0] + x0;
-                uint8_t* p1 = im.out[1] + (size_t)y * im.out_pitch[1] + x0;
-                uint8_t* p2 = im.out[2] + (size_t)y * im.out_pitch[2] + x0;
+                uint8_t* p0 = im.out[0] + (size_t)y0 * im.out_pitch[0] + (__umul24((unsigned)r, im.out_pitch[0]) + (unsigned)x0);
+                uint8_t* p1 = im.out[1] + (size_t)y0 * im.out_pitch[1] + (__umul24((unsigned)r, im.out_pitch[1]) + (unsigned)x0);
+                uint8_t* p2 = im.out[2] + (size_t)y0 * im.out_pitch[2] + (__umul24((unsigned)r, im.out_pitch[2]) + (unsigned)x0);
                 if (full && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 7) == 0) {
                     *reinterpret_cast<uint2*>(p0) = make_uint2(pack4(R[0], R[1], R[2], R[3]), pack4(R[4], R[5], R[6], R[7]));
                     *reinterpret_cast<uint2*>(p1) = make_uint2(pack4(G[0], G[1], G[2], G[3]), pack4(G[4], G[5], G[6], G[7]));
@@ -447,7 +459,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
                     t[1] = q1;
                     t[2] = q2;
                 } else {
-                    uint8_t* o = im.out[0] + (size_t)y * im.out_pitch[0] + (size_t)x0 * 3;
+                    uint8_t* o = im.out[0] + (size_t)y0 * im.out_pitch[0] + (__umul24((unsigned)r, im.out_pitch[0]) + (unsigned)x0 * 3u);
                     if (full && ((uintptr_t)o & 7) == 0) {
                         uint2* q = reinterpret_cast<uint2*>(o);
                         q[0] = q0;
@@ -476,10 +488,10 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const int g = k * 64 + lane;  // 16-byte chunk of the 8 x 768 B tile
-        const int r = g / 48, off = (g - r * 48) * 16;
+        const int r = (g * 1366) >> 16, off = (g - r * 48) * 16;  // g / 48 for g < 384
         if (r < nrows && off < row_bytes) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(lds_wave + r * kOutRowBytes + off);
-            uint8_t* dst = out_base + (size_t)r * im.out_pitch[0] + off;
+            uint8_t* dst = out_base + (__umul24((unsigned)r, im.out_pitch[0]) + (unsigned)off);
             if (off + 16 <= row_bytes) {
 #ifdef HJ_ABLATE_STORE
                 if (v.x == 0x12345678u && v.y == 0x9abcdef0u)  // practically never: keeps the value live, drops the traffic
