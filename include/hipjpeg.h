@@ -67,6 +67,8 @@ typedef enum {
 } hipjpegChromaSubsampling_t;
 
 #define HIPJPEG_FLAG_FANCY_UPSAMPLING 1u /* libjpeg do_fancy_upsampling (plugin option fancy_upsampling, default on) */
+#define HIPJPEG_FLAG_GPU_HUFFMAN 2u      /* entropy-decode eligible streams (baseline, one interleaved scan, no restart markers) on the
+                                            GPU; the host then only destuffs the scan.  Other streams keep the host entropy stage. */
 
 typedef struct {
     int32_t width, height, num_components;
@@ -99,6 +101,14 @@ HIPJPEG_API hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t leng
 HIPJPEG_API hipjpegStatus_t hipjpegEntropyDecodeHost(const uint8_t* data, size_t length, int16_t* coef, size_t coef_capacity_bytes,
                                                      uint64_t comp_offsets[4], uint16_t qtables[256]);
 
+/* The GPU entropy decoder's algorithm (self-synchronizing subsequence decoding, csrc/huffman_gpu_core.h) executed on the
+ * host, lane by lane, with the very code the kernels run: lets the algorithm be verified without a GPU.  Same output
+ * layout as hipjpegEntropyDecodeHost; returns HIPJPEG_STATUS_UNSUPPORTED for streams the GPU entropy path does not take
+ * (progressive, multi-scan, restart markers). */
+HIPJPEG_API hipjpegStatus_t hipjpegEntropyDecodeGpuAlgorithmHost(const uint8_t* data, size_t length, int16_t* coef,
+                                                                 size_t coef_capacity_bytes, uint64_t comp_offsets[4],
+                                                                 int32_t* sync_passes);
+
 /* ---- device pipeline ---- */
 /* num_host_threads: CPU threads for the entropy stage (0 = hardware concurrency). */
 HIPJPEG_API hipjpegStatus_t hipjpegCreate(hipjpegHandle_t* handle, int device_id, int num_host_threads);
@@ -117,9 +127,14 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const
                                                    hipjpegStatus_t* statuses);
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchTransfer(hipjpegHandle_t handle, void* stream);
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, void* stream);
-/* One kernel family of the device stage at a time (0 = idct_plane, 1 = luma_color, 2 = generic_color), so a caller can
- * bracket each with events.  hipjpegDecodeBatchDevice == all three in this order. */
+/* One kernel family of the device stage at a time (0 = idct_plane, 1 = luma_color, 2 = generic_color, 3 = GPU entropy stage),
+ * so a caller can bracket each with events.  hipjpegDecodeBatchDevice == entropy (if any image uses it), then 0, 1, 2. */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handle, int which, void* stream);
+/* Final per-image statuses of the current batch (after the device stage they include what the GPU entropy stage found). */
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchGetStatuses(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size);
+/* GPU entropy stage statistics: images that used it, kernel launches the last synchronisation needed, destuffed bytes. */
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchEntropyStats(hipjpegHandle_t handle, int32_t* gpu_images, int32_t* sync_launches,
+                                                           uint64_t* stream_bytes);
 /* Launch statistics of the prepared batch: workgroups per kernel (idct_plane, luma_color, generic). */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchStats(hipjpegHandle_t handle, int32_t num_units[3], uint64_t* coef_bytes,
                                                     uint64_t* output_bytes);

@@ -11,6 +11,7 @@ STATUS_NAMES = {0: "SUCCESS", 1: "INVALID_ARGUMENT", 2: "BAD_JPEG", 3: "UNSUPPOR
 
 OUTPUT_RGBI, OUTPUT_BGRI, OUTPUT_RGB_PLANAR, OUTPUT_BGR_PLANAR, OUTPUT_Y, OUTPUT_YUV_PLANAR = range(6)
 FLAG_FANCY_UPSAMPLING = 1
+FLAG_GPU_HUFFMAN = 2
 
 
 class HipJpegError(RuntimeError):
@@ -58,6 +59,7 @@ def load():
     L.hipjpegVersion.restype = i32
     L.hipjpegGetImageInfo.argtypes = [vp, sz, ctypes.POINTER(ImageInfo)]
     L.hipjpegEntropyDecodeHost.argtypes = [vp, sz, vp, sz, vp, vp]
+    L.hipjpegEntropyDecodeGpuAlgorithmHost.argtypes = [vp, sz, vp, sz, vp, ctypes.POINTER(ctypes.c_int32)]
     L.hipjpegCreate.argtypes = [ctypes.POINTER(vp), i32, i32]
     L.hipjpegDestroy.argtypes = [vp]
     L.hipjpegDecodeBatch.argtypes = [vp, vp, vp, i32, vp, i32, ctypes.c_uint, vp, vp]
@@ -66,6 +68,8 @@ def load():
     L.hipjpegDecodeBatchDevice.argtypes = [vp, vp]
     L.hipjpegDecodeBatchDeviceKernel.argtypes = [vp, i32, vp]
     L.hipjpegDecodeBatchStats.argtypes = [vp, vp, vp, vp]
+    L.hipjpegDecodeBatchGetStatuses.argtypes = [vp, vp, i32]
+    L.hipjpegDecodeBatchEntropyStats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]
     L.hipjpegEncodeBatchDevice.argtypes = [vp, vp, vp, i32, vp, vp]
     L.hipjpegEncodeBatchRelaunch.argtypes = [vp, vp]
     L.hipjpegEncodeBatchHost.argtypes = [vp, vp]

@@ -10,6 +10,7 @@
 
 #include "decode_kernels.h"
 #include "entropy_decode.h"
+#include "gpu_huffman_host.h"
 
 namespace hipjpeg {
 
@@ -91,7 +92,8 @@ void Buffer::release()
 
 // ---------------------------------------------------------------- DecodeBatch
 DecodeBatch::DecodeBatch(int device_id, const MemoryHooks* hooks)
-    : device_id_(device_id), pinned_(Buffer::kPinned, hooks), device_(Buffer::kDevice, hooks), planes_(Buffer::kDevice, hooks)
+    : device_id_(device_id), pinned_(Buffer::kPinned, hooks), device_(Buffer::kDevice, hooks), planes_(Buffer::kDevice, hooks),
+      work_(Buffer::kDevice, hooks)
 {
 }
 
@@ -156,8 +158,14 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     images_.assign(n, PlannedImage());
     desc_.assign(n, DecodeImage());
     const bool fancy = (flags & HIPJPEG_FLAG_FANCY_UPSAMPLING) != 0;
+    const bool want_gpu_entropy = (flags & HIPJPEG_FLAG_GPU_HUFFMAN) != 0;
+    entropy_done_ = false;
+    huff_images_.clear();
+    huff_to_image_.clear();
 
     size_t max_units = 0, coef_total = 0, plane_total = 0;
+    size_t huff_stream_total = 0, huff_subseq_ub = 0;
+    max_huff_units_ = 0;
     std::vector<size_t> plane_off((size_t)n * 4, (size_t)-1);
     coef_bytes_ = output_bytes_ = 0;
     for (int i = 0; i < n; i++) {
@@ -209,8 +217,6 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
                         dc.qpair[pp][j * 8 + r] = dc.qpair_exact[pp][j * 8 + r] = (pp && (r & 1)) ? -q : q;
                     }
             const size_t nblk = (size_t)k.blocks_w * k.blocks_h;
-            im.coef_offset[c] = coef_total;
-            coef_total += nblk * 128;
             const size_t units = (nblk + kBlocksPerUnit - 1) / kBlocksPerUnit;
             // which components go through an intermediate plane
             bool needs_plane = (im.variant == -1) || (im.variant >= kVar11 && c > 0);
@@ -224,6 +230,17 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
             if (c == 0 && im.variant >= 0) max_units += (size_t)((k.blocks_w + kLumaTileW - 1) / kLumaTileW) * (size_t)((k.blocks_h + kLumaTileH - 1) / kLumaTileH);
         }
         if (im.variant == -1) max_units += (size_t)f.height;
+        if (want_gpu_entropy && gpu_entropy_eligible(f)) {
+            im.gpu_entropy = true;
+            im.huff_index = (int)huff_to_image_.size();
+            huff_to_image_.push_back(i);
+            const size_t cap = align_up(destuffed_capacity(f.scans[0]), 64);
+            im.stream_offset = huff_stream_total;  // relative; rebased below
+            huff_stream_total += cap;
+            const size_t nsub = (cap * 8 + kSubseqBits - 1) / kSubseqBits;
+            huff_subseq_ub += nsub;
+            max_huff_units_ += (nsub + 255) / 256;
+        }
         coef_bytes_ += f.total_blocks() * 128;
         if (fmt == kOutPlanarYUV) {
             for (int c = 0; c < f.ncomp; c++) output_bytes_ += (uint64_t)f.comp[c].samp_w * f.comp[c].samp_h;
@@ -232,11 +249,41 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
         }
     }
 
+    // Staging layout (pinned mirror <-> device):  descriptors | work units | entropy descriptors, units, tables, destuffed
+    // streams | coefficients of host-decoded images  ||  (device only from here) coefficients of GPU-decoded images
+    const size_t ng = huff_to_image_.size();
     desc_offset_ = 0;
     units_offset_ = align_up(desc_offset_ + sizeof(DecodeImage) * (size_t)n, 256);
-    coef_offset_ = align_up(units_offset_ + sizeof(WorkUnit) * max_units, 256);
+    huff_desc_offset_ = align_up(units_offset_ + sizeof(WorkUnit) * max_units, 256);
+    huff_units_offset_ = align_up(huff_desc_offset_ + sizeof(HuffImage) * ng, 256);
+    huff_dc_units_offset_ = align_up(huff_units_offset_ + sizeof(HuffUnit) * max_huff_units_, 256);
+    huff_list_offset_ = align_up(huff_dc_units_offset_ + sizeof(HuffUnit) * ng * 4, 256);
+    const size_t tables_base = align_up(huff_list_offset_ + sizeof(uint32_t) * ng, 256);
+    const size_t streams_base = align_up(tables_base + sizeof(HuffDecodeTable) * 8 * ng, 256);
+    coef_offset_ = align_up(streams_base + huff_stream_total, 256);
+    for (int pass = 0; pass < 2; pass++) {  // host-decoded images first, GPU-decoded ones behind the H2D boundary
+        if (pass == 1) {
+            h2d_bytes_ = coef_offset_ + coef_total;
+            gpu_coef_begin_ = align_up(h2d_bytes_, 256);
+            coef_total = gpu_coef_begin_ - coef_offset_;
+        }
+        for (int i = 0; i < n; i++) {
+            PlannedImage& im = images_[i];
+            if (im.status != HIPJPEG_STATUS_SUCCESS || (int)im.gpu_entropy != pass) continue;
+            for (int c = 0; c < im.frame.ncomp; c++) {
+                im.coef_offset[c] = coef_total;
+                coef_total += (size_t)im.frame.comp[c].blocks_w * im.frame.comp[c].blocks_h * 128;
+            }
+            if (im.gpu_entropy) {
+                im.stream_offset += streams_base;
+                im.tables_offset = tables_base + sizeof(HuffDecodeTable) * 8 * (size_t)im.huff_index;
+            }
+        }
+    }
     staging_bytes_ = coef_offset_ + coef_total;
+    gpu_coef_bytes_ = staging_bytes_ - gpu_coef_begin_;
     plane_bytes_ = plane_total;
+    total_subseq_ = huff_subseq_ub;
 
     if (hipSetDevice(device_id_) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
     // the previous use of these buffers (H2D copy + kernels) must have drained before they are rewritten
@@ -245,9 +292,11 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
         in_flight_ = false;
     }
     hipjpegStatus_t st;
-    if ((st = pinned_.reserve(staging_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    if ((st = pinned_.reserve(h2d_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     if ((st = device_.reserve(staging_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     if ((st = planes_.reserve(plane_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    if (ng && (st = work_.reserve(total_subseq_ * 12 + 1024)) != HIPJPEG_STATUS_SUCCESS) return st;
+    huff_images_.assign(ng, HuffImage());
 
     for (int i = 0; i < n; i++) {
         if (images_[i].status != HIPJPEG_STATUS_SUCCESS) continue;
@@ -267,6 +316,25 @@ void DecodeBatch::entropy_stage(int i)
 {
     PlannedImage& im = images_[i];
     if (im.status != HIPJPEG_STATUS_SUCCESS) return;
+    if (im.gpu_entropy) {
+        // host part of the GPU entropy path: drop the byte stuffing, expand the Huffman tables, describe the scan
+        const ScanHeader& sc = im.frame.scans[0];
+        im.stream_bytes = (uint32_t)destuff_scan(im.data, sc, pinned_.data() + im.stream_offset);
+        build_gpu_tables(sc, reinterpret_cast<HuffDecodeTable*>(pinned_.data() + im.tables_offset));
+        HuffImage& h = huff_images_[im.huff_index];
+        fill_huff_image(im.frame, im.stream_bytes, &h);
+        // magnitude bound for the 24-bit multiplier decision without seeing the coefficients: DC values live in int16,
+        // AC magnitudes are below 2^(largest size category any AC table of the scan can code)
+        for (int c = 0; c < im.frame.ncomp; c++) {
+            int maxcat = 0;
+            const HuffSpec& t = sc.ac[sc.ta[c]];
+            int nv = 0;
+            for (int l = 1; l <= 16; l++) nv += t.bits[l];
+            for (int v = 0; v < nv; v++) maxcat = std::max(maxcat, t.vals[v] & 15);
+            im.coef_or[c] = 32767u | ((1u << maxcat) - 1);
+        }
+        return;
+    }
     int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int c = 0; c < im.frame.ncomp; c++) coef[c] = reinterpret_cast<int16_t*>(pinned_.data() + im.coef_offset[c]);
     EntropyStatus es = decode_coefficients(im.data, im.size, im.frame, coef, im.coef_or);
@@ -334,15 +402,113 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[e][k], &unit_off_luma_[e][k]);
     }
     put(generic_units_, &unit_off_generic_);
+
+    // GPU entropy descriptors: batch-wide subsequence numbering, one workgroup per 256 subsequences of an image
+    huff_units_.clear();
+    huff_dc_units_.clear();
+    huff_list_.clear();
+    uint32_t first_subseq = 0;
+    stream_bytes_total_ = 0;
+    for (size_t g = 0; g < huff_images_.size(); g++) {
+        PlannedImage& im = images_[huff_to_image_[g]];
+        HuffImage& h = huff_images_[g];
+        if (im.status != HIPJPEG_STATUS_SUCCESS) {
+            h.num_subseq = 0;
+            continue;
+        }
+        h.stream = device_.data() + im.stream_offset;
+        h.tables = reinterpret_cast<const HuffDecodeTable*>(device_.data() + im.tables_offset);
+        for (int c = 0; c < im.frame.ncomp; c++) h.coef[c] = reinterpret_cast<int16_t*>(device_.data() + im.coef_offset[c]);
+        h.first_subseq = first_subseq;
+        first_subseq += h.num_subseq;
+        for (uint32_t j = 0; j < h.num_subseq; j += 256) huff_units_.push_back(HuffUnit{(uint32_t)g, j});
+        for (int c = 0; c < im.frame.ncomp; c++) huff_dc_units_.push_back(HuffUnit{(uint32_t)g, (uint32_t)c});
+        huff_list_.push_back((uint32_t)g);
+        stream_bytes_total_ += im.stream_bytes;
+    }
+    total_subseq_ = first_subseq;
+    if (!huff_images_.empty()) {
+        memcpy(base + huff_desc_offset_, huff_images_.data(), sizeof(HuffImage) * huff_images_.size());
+        if (!huff_units_.empty()) memcpy(base + huff_units_offset_, huff_units_.data(), sizeof(HuffUnit) * huff_units_.size());
+        if (!huff_dc_units_.empty()) memcpy(base + huff_dc_units_offset_, huff_dc_units_.data(), sizeof(HuffUnit) * huff_dc_units_.size());
+        if (!huff_list_.empty()) memcpy(base + huff_list_offset_, huff_list_.data(), sizeof(uint32_t) * huff_list_.size());
+    }
     finalized_ = true;
 }
 
 hipjpegStatus_t DecodeBatch::transfer(void* stream)
 {
     if (!finalized_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    if (staging_bytes_ == 0) return HIPJPEG_STATUS_SUCCESS;
-    hipError_t e = hipMemcpyAsync(device_.data(), pinned_.data(), staging_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream);
+    entropy_done_ = false;
+    if (h2d_bytes_ == 0) return HIPJPEG_STATUS_SUCCESS;
+    // only descriptors, bitstreams of GPU-decoded images and coefficients of host-decoded images cross PCIe
+    hipError_t e = hipMemcpyAsync(device_.data(), pinned_.data(), h2d_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream);
     return e == hipSuccess ? HIPJPEG_STATUS_SUCCESS : HIPJPEG_STATUS_HIP_ERROR;
+}
+
+// GPU entropy stage: zero the coefficient arena, synchronise the subsequence decoders (relaunching until a launch changes
+// nothing), scan block counts, write coefficients, integrate DC.  Blocks: the host needs the per-image status to fall back
+// to its own entropy decoder for streams the kernels flagged (corrupt or truncated data).
+hipjpegStatus_t DecodeBatch::run_gpu_entropy(void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (huff_units_.empty()) {
+        entropy_done_ = true;
+        return HIPJPEG_STATUS_SUCCESS;
+    }
+    HuffImage* dimg = reinterpret_cast<HuffImage*>(device_.data() + huff_desc_offset_);
+    const HuffUnit* dunits = reinterpret_cast<const HuffUnit*>(device_.data() + huff_units_offset_);
+    const HuffUnit* ddc = reinterpret_cast<const HuffUnit*>(device_.data() + huff_dc_units_offset_);
+    const uint32_t* dlist = reinterpret_cast<const uint32_t*>(device_.data() + huff_list_offset_);
+    unsigned long long* states = reinterpret_cast<unsigned long long*>(work_.data());
+    uint32_t* first_block = reinterpret_cast<uint32_t*>(work_.data() + align_up(total_subseq_ * 8, 256));
+    unsigned int* changed = reinterpret_cast<unsigned int*>(work_.data() + align_up(total_subseq_ * 8, 256) + align_up(total_subseq_ * 4, 256));
+    if (hipMemsetAsync(device_.data() + gpu_coef_begin_, 0, gpu_coef_bytes_, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    unsigned int host_changed = 1;
+    last_sync_launches_ = 0;
+    for (int pass = 0; pass < 64 && host_changed; pass++) {
+        if (hipMemsetAsync(changed, 0, sizeof(unsigned int), s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (launch_huff_sync(dimg, dunits, (int)huff_units_.size(), states, changed, pass == 0, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipMemcpyAsync(&host_changed, changed, sizeof host_changed, hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        last_sync_launches_++;
+    }
+    const bool converged = host_changed == 0;
+    if (converged) {
+        if (launch_huff_scan(dimg, dlist, (int)huff_list_.size(), states, first_block, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+        if (launch_huff_write(dimg, dunits, (int)huff_units_.size(), states, first_block, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+        if (launch_huff_dc(dimg, ddc, (int)huff_dc_units_.size(), stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    }
+    // status read-back (into the pinned mirror of the descriptor array)
+    HuffImage* himg = reinterpret_cast<HuffImage*>(pinned_.data() + huff_desc_offset_);
+    if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    for (size_t g = 0; g < huff_images_.size(); g++) {
+        PlannedImage& im = images_[huff_to_image_[g]];
+        if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
+        if (converged && himg[g].status == 0) continue;
+        // The kernels could not vouch for this stream: let the host entropy decoder produce either the coefficients or the
+        // precise error.  (Rare path: corrupt / truncated data.)
+        const FrameInfo& f = im.frame;
+        std::vector<int16_t> tmp(f.total_blocks() * 64);
+        int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
+        size_t off = 0;
+        for (int c = 0; c < f.ncomp; c++) {
+            coef[c] = tmp.data() + off;
+            off += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 64;
+        }
+        EntropyStatus es = decode_coefficients(im.data, im.size, f, coef, nullptr);
+        if (es != kEntropyOk) {
+            im.status = es == kEntropyTruncated ? HIPJPEG_STATUS_TRUNCATED : HIPJPEG_STATUS_CORRUPT;
+            continue;
+        }
+        for (int c = 0; c < f.ncomp; c++)
+            if (hipMemcpy(device_.data() + im.coef_offset[c], coef[c], (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 128, hipMemcpyHostToDevice) !=
+                hipSuccess)
+                return HIPJPEG_STATUS_HIP_ERROR;
+    }
+    entropy_done_ = true;
+    return HIPJPEG_STATUS_SUCCESS;
 }
 
 hipjpegStatus_t DecodeBatch::launch(void* stream, int which)
@@ -372,6 +538,11 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which)
         check("transfer", 0);
     }
     int rc = 0;
+    if ((which < 0 && !entropy_done_) || which == 3) {
+        hipjpegStatus_t es = run_gpu_entropy(stream);
+        if (es != HIPJPEG_STATUS_SUCCESS) return es;
+        if (which == 3) return HIPJPEG_STATUS_SUCCESS;
+    }
     for (int e = 0; e < 2 && rc == 0 && (which < 0 || which == 0); e++) {
         rc = launch_idct_plane(e == 1, dimg, units_at(unit_off_plane_[e]), (int)plane_units_[e].size(), stream);
         check("idct_plane", (int)plane_units_[e].size());

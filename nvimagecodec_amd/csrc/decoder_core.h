@@ -11,6 +11,7 @@
 
 #include "../../include/hipjpeg.h"
 #include "device_layout.h"
+#include "gpu_huffman.h"
 #include "jpeg_syntax.h"
 
 namespace hipjpeg {
@@ -56,6 +57,12 @@ struct PlannedImage {
     size_t coef_offset[4] = {0, 0, 0, 0};  // byte offset of component c inside the staging area
     int variant = -1;                      // KernelVariant, or -1 = generic colour path, -2 = planes-to-output only
     uint32_t coef_or[4] = {0, 0, 0, 0};    // OR of |coefficient| per component (from the entropy stage)
+    // GPU entropy decoding (flag HIPJPEG_FLAG_GPU_HUFFMAN and an eligible stream): the host only destuffs the scan
+    bool gpu_entropy = false;
+    int huff_index = -1;          // index into the HuffImage array
+    size_t stream_offset = 0;     // staging offsets of the destuffed stream and the 8 expanded tables
+    size_t tables_offset = 0;
+    uint32_t stream_bytes = 0;
 };
 
 class DecodeBatch {
@@ -74,8 +81,12 @@ public:
     void finalize(hipjpegStatus_t* statuses);
     // Phase 2: one async H2D copy of descriptors + coefficients.
     hipjpegStatus_t transfer(void* stream);
-    // Phase 3: kernel launches.  which = -1: all; 0 idct_plane, 1 luma_color (every variant), 2 generic_color.
+    // Phase 3: kernel launches.  which = -1: all; 0 idct_plane, 1 luma_color (every variant), 2 generic_color,
+    // 3 GPU entropy stage (blocks until its result status has been read back).
     hipjpegStatus_t launch(void* stream, int which = -1);
+    int gpu_entropy_images() const { return (int)huff_images_.size(); }
+    int last_sync_launches() const { return last_sync_launches_; }
+    uint64_t stream_bytes() const { return stream_bytes_total_; }
 
     int size() const { return (int)images_.size(); }
     const PlannedImage& image(int i) const { return images_[i]; }
@@ -92,6 +103,18 @@ private:
     size_t unit_off_plane_[2] = {0, 0}, unit_off_luma_[2][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0;
     uint64_t coef_bytes_ = 0, output_bytes_ = 0;
     bool finalized_ = false;
+    // ---- GPU entropy stage
+    hipjpegStatus_t run_gpu_entropy(void* stream);
+    Buffer work_;  // device only: subsequence states, first-block indices, change counter
+    std::vector<HuffImage> huff_images_;
+    std::vector<HuffUnit> huff_units_, huff_dc_units_;
+    std::vector<uint32_t> huff_list_;
+    std::vector<int> huff_to_image_;
+    size_t huff_desc_offset_ = 0, huff_units_offset_ = 0, huff_dc_units_offset_ = 0, huff_list_offset_ = 0, h2d_bytes_ = 0;
+    size_t gpu_coef_begin_ = 0, gpu_coef_bytes_ = 0, total_subseq_ = 0, max_huff_units_ = 0;
+    uint64_t stream_bytes_total_ = 0;
+    int last_sync_launches_ = 0;
+    bool entropy_done_ = false;
     void* done_event_ = nullptr;  // hipEvent_t recorded after the last launch that reads this batch's buffers
     bool in_flight_ = false;
 };

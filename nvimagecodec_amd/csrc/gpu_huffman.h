@@ -1,0 +1,21 @@
+// gpu_huffman.h -- host-callable launchers of the GPU entropy kernels (gpu_huffman.hip); stream = hipStream_t as void*.
+#pragma once
+#include <cstdint>
+
+#include "huffman_gpu_core.h"
+
+namespace hipjpeg {
+
+// sync/write kernels: `first` = first subsequence (inside the image) of the workgroup; dc kernel: `first` = component index
+struct HuffUnit {
+    uint32_t image;  // index into HuffImage[]
+    uint32_t first;
+};
+
+int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned int* changed, int first_pass,
+                     void* stream);
+int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages, const unsigned long long* states, uint32_t* first_block, void* stream);
+int launch_huff_write(HuffImage* images, const HuffUnit* units, int nunits, const unsigned long long* states, const uint32_t* first_block, void* stream);
+int launch_huff_dc(const HuffImage* images, const HuffUnit* units, int nunits, void* stream);
+
+}  // namespace hipjpeg

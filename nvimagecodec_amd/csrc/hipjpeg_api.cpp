@@ -10,6 +10,7 @@
 #include "decoder_core.h"
 #include "encoder_core.h"
 #include "entropy_decode.h"
+#include "gpu_huffman_host.h"
 #include "thread_pool.h"
 
 using namespace hipjpeg;
@@ -99,6 +100,28 @@ hipjpegStatus_t hipjpegEntropyDecodeHost(const uint8_t* data, size_t length, int
     }
 }
 
+hipjpegStatus_t hipjpegEntropyDecodeGpuAlgorithmHost(const uint8_t* data, size_t length, int16_t* coef, size_t coef_capacity_bytes,
+                                                     uint64_t comp_offsets[4], int32_t* sync_passes)
+{
+    if (!data || !coef) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    FrameInfo f;
+    ParseStatus ps = parse_jpeg(data, length, &f);
+    if (ps != kParseOk) return status_from_parse(ps);
+    if (!gpu_entropy_eligible(f)) return HIPJPEG_STATUS_UNSUPPORTED;
+    if (f.total_blocks() * 128 > coef_capacity_bytes) return HIPJPEG_STATUS_BUFFER_TOO_SMALL;
+    int16_t* ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t off = 0;
+    for (int c = 0; c < f.ncomp; c++) {
+        ptr[c] = coef + off;
+        if (comp_offsets) comp_offsets[c] = off;
+        off += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 64;
+    }
+    int passes = 0;
+    int rc = emulate_gpu_entropy(data, length, f, ptr, &passes);
+    if (sync_passes) *sync_passes = passes;
+    return rc == 0 ? HIPJPEG_STATUS_SUCCESS : (rc == 2 ? HIPJPEG_STATUS_TRUNCATED : HIPJPEG_STATUS_CORRUPT);
+}
+
 hipjpegStatus_t hipjpegCreate(hipjpegHandle_t* handle, int device_id, int num_host_threads)
 {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
@@ -171,7 +194,27 @@ hipjpegStatus_t hipjpegDecodeBatch(hipjpegHandle_t handle, const uint8_t* const*
     hipjpegStatus_t st = hipjpegDecodeBatchHost(handle, data, lengths, batch_size, outputs, format, flags, statuses);
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     if ((st = hipjpegDecodeBatchTransfer(handle, stream)) != HIPJPEG_STATUS_SUCCESS) return st;
-    return hipjpegDecodeBatchDevice(handle, stream);
+    st = hipjpegDecodeBatchDevice(handle, stream);
+    // the GPU entropy stage may have found problems the host never looked at (it only destuffed those streams)
+    if (statuses)
+        for (int i = 0; i < batch_size; i++) statuses[i] = handle->cur().image(i).status;
+    return st;
+}
+
+hipjpegStatus_t hipjpegDecodeBatchGetStatuses(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size)
+{
+    if (!handle || !statuses || batch_size != handle->cur().size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    for (int i = 0; i < batch_size; i++) statuses[i] = handle->cur().image(i).status;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegDecodeBatchEntropyStats(hipjpegHandle_t handle, int32_t* gpu_images, int32_t* sync_launches, uint64_t* stream_bytes)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if (gpu_images) *gpu_images = handle->cur().gpu_entropy_images();
+    if (sync_launches) *sync_launches = handle->cur().last_sync_launches();
+    if (stream_bytes) *stream_bytes = handle->cur().stream_bytes();
+    return HIPJPEG_STATUS_SUCCESS;
 }
 
 // ---------------------------------------------------------------- encode

@@ -107,6 +107,7 @@ private:
     const nvimgcodecExecutionParams_t* ep_;
     MemoryHooks hooks_;
     bool fancy_ = true;  // same default as the reference plugins (nvjpeg_utils.cpp:46, libjpeg_turbo_decoder.cpp:253)
+    bool gpu_huffman_ = true;  // entropy-decode eligible streams on the GPU (the reference's GPU_HYBRID backend analogue)
     bool ok_ = false;
     int device_ = 0;
     hipStream_t stream_ = nullptr;
@@ -121,6 +122,7 @@ HipJpegDecoder::HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgc
     for_each_option(options, kDecoderId, [&](const std::string& key, const std::string& value) {
         std::istringstream v(value);
         if (key == "fancy_upsampling") v >> fancy_;
+        if (key == "gpu_huffman") v >> gpu_huffman_;
     });
     if (ep->device_allocator && ep->device_allocator->device_malloc && ep->device_allocator->device_free) {
         hooks_.device_malloc = reinterpret_cast<int (*)(void*, void**, size_t, void*)>(ep->device_allocator->device_malloc);
@@ -283,6 +285,7 @@ void HipJpegDecoder::finish(Job* job)
     if (gpu_ok) gpu_ok = job->batch.transfer(stream_) == HIPJPEG_STATUS_SUCCESS;
     if (gpu_ok) gpu_ok = job->batch.launch(stream_) == HIPJPEG_STATUS_SUCCESS;
     if (gpu_ok) gpu_ok = hipEventRecord(job->event, stream_) == hipSuccess;
+    for (int i = 0; i < n; i++) job->statuses[i] = job->batch.image(i).status;  // incl. what the GPU entropy stage reported
     release_inputs(job);
     for (int i = 0; i < n; i++) {
         Sample& s = job->samples[i];
@@ -383,7 +386,8 @@ nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_stre
     }
 
     bool planned = hipSetDevice(device_) == hipSuccess &&
-                   job->batch.plan(data.data(), sizes.data(), n, outs.data(), HIPJPEG_OUTPUT_RGBI, fancy_ ? HIPJPEG_FLAG_FANCY_UPSAMPLING : 0u,
+                   job->batch.plan(data.data(), sizes.data(), n, outs.data(), HIPJPEG_OUTPUT_RGBI,
+                                   (fancy_ ? HIPJPEG_FLAG_FANCY_UPSAMPLING : 0u) | (gpu_huffman_ ? HIPJPEG_FLAG_GPU_HUFFMAN : 0u),
                                    job->statuses.data(), formats.data()) == HIPJPEG_STATUS_SUCCESS;
     if (!planned) {
         // batch-level failure: every sample is reported failed and an error code is returned (cuda_decoder.cpp:602-608)

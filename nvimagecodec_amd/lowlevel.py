@@ -50,6 +50,24 @@ def entropy_decode_host(data):
     return coefs, qts
 
 
+def entropy_decode_gpu_algorithm_host(data):
+    """The GPU entropy decoder's multi-pass algorithm emulated on the host (no GPU).  Returns (coefs natural order, sync passes)."""
+    a = _as_u8(data)
+    info = get_image_info(a)
+    buf = np.zeros(info["coef_bytes"] // 2, dtype=np.int16)
+    offs = (ctypes.c_uint64 * 4)()
+    passes = ctypes.c_int32()
+    st = N.load().hipjpegEntropyDecodeGpuAlgorithmHost(a.ctypes.data, a.size, buf.ctypes.data, buf.nbytes, ctypes.addressof(offs), ctypes.byref(passes))
+    if st:
+        raise N.HipJpegError(st, "hipjpegEntropyDecodeGpuAlgorithmHost")
+    coefs = []
+    for c in range(info["num_components"]):
+        n = info["blocks_w"][c] * info["blocks_h"][c]
+        blk = buf[offs[c]: offs[c] + n * 64].reshape(info["blocks_h"][c], info["blocks_w"][c], 8, 8)
+        coefs.append(np.ascontiguousarray(blk.transpose(0, 1, 3, 2)).reshape(info["blocks_h"][c], info["blocks_w"][c], 64))
+    return coefs, passes.value
+
+
 class BatchDecoder:
     """hipjpegCreate / hipjpegDecodeBatch* on one device."""
 
@@ -129,12 +147,12 @@ class BatchDecoder:
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         return ctypes.c_void_p(s.cuda_stream)
 
-    def decode(self, jpegs, fmt="rgb", fancy=True, outs=None, stream=None, check=True):
-        """Full pipeline.  Returns (outputs, statuses)."""
+    def decode(self, jpegs, fmt="rgb", fancy=True, outs=None, stream=None, check=True, gpu_huffman=False):
+        """Full pipeline.  Returns (outputs, statuses).  gpu_huffman=True: entropy-decode eligible streams on the GPU."""
         if outs is None:
             outs = self.allocate_outputs(jpegs, fmt)
         ptrs, lens, O, statuses = self._marshal(jpegs, outs, fmt)
-        flags = N.FLAG_FANCY_UPSAMPLING if fancy else 0
+        flags = (N.FLAG_FANCY_UPSAMPLING if fancy else 0) | (N.FLAG_GPU_HUFFMAN if gpu_huffman else 0)
         st = N.load().hipjpegDecodeBatch(self._h, ptrs, lens, len(jpegs), O, _FORMATS[fmt], flags, statuses, self._stream_ptr(stream))
         if st:
             raise N.HipJpegError(st, "hipjpegDecodeBatch")
@@ -146,9 +164,9 @@ class BatchDecoder:
         return outs, statuses
 
     # -- the three phases separately (bench.py times device_stage with coefficients resident in HBM)
-    def host_stage(self, jpegs, outs, fmt="rgb", fancy=True):
+    def host_stage(self, jpegs, outs, fmt="rgb", fancy=True, gpu_huffman=False):
         ptrs, lens, O, statuses = self._marshal(jpegs, outs, fmt)
-        flags = N.FLAG_FANCY_UPSAMPLING if fancy else 0
+        flags = (N.FLAG_FANCY_UPSAMPLING if fancy else 0) | (N.FLAG_GPU_HUFFMAN if gpu_huffman else 0)
         st = N.load().hipjpegDecodeBatchHost(self._h, ptrs, lens, len(jpegs), O, _FORMATS[fmt], flags, statuses)
         if st:
             raise N.HipJpegError(st, "hipjpegDecodeBatchHost")
@@ -172,7 +190,15 @@ class BatchDecoder:
         units = (ctypes.c_int32 * 3)()
         cb, ob = ctypes.c_uint64(), ctypes.c_uint64()
         N.load().hipjpegDecodeBatchStats(self._h, ctypes.addressof(units), ctypes.byref(cb), ctypes.byref(ob))
-        return dict(units=list(units), coef_bytes=cb.value, output_bytes=ob.value)
+        gi, sl, sb = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_uint64()
+        N.load().hipjpegDecodeBatchEntropyStats(self._h, ctypes.byref(gi), ctypes.byref(sl), ctypes.byref(sb))
+        return dict(units=list(units), coef_bytes=cb.value, output_bytes=ob.value, gpu_entropy_images=gi.value, sync_launches=sl.value,
+                    stream_bytes=sb.value)
+
+    def statuses(self, n):
+        st = (ctypes.c_int * n)()
+        N.load().hipjpegDecodeBatchGetStatuses(self._h, st, n)
+        return list(st)
 
 
 # ---------------------------------------------------------------------------------------------- encode

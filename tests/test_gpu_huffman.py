@@ -1,0 +1,102 @@
+"""GPU tests of the GPU entropy stage (flag HIPJPEG_FLAG_GPU_HUFFMAN / plugin option gpu_huffman): full decode with Huffman
+decoding on the device must give the same pixels as the oracle, bit for bit, and broken streams must come back with the same
+statuses as on the host path."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, load_decode_case
+from nvimagecodec_amd.synth import synth_image
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _f:
+    _M = json.load(_f)
+
+
+@pytest.fixture(scope="module")
+def dec():
+    import torch
+    assert torch.cuda.is_available()
+    from nvimagecodec_amd.lowlevel import BatchDecoder
+    d = BatchDecoder(0, num_threads=4)
+    yield d
+    d.close()
+
+
+def _sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def test_all_goldens_mixed_eligibility_one_batch(dec):
+    """Eligible streams (baseline, one interleaved scan) go through the GPU entropy kernels, the others (progressive,
+    restart markers) through the host entropy stage -- in the same batch."""
+    cases = [load_decode_case(e) for e in _M["decode"]]
+    outs, statuses = dec.decode([c[0] for c in cases], gpu_huffman=True)
+    _sync()
+    st = dec.stats()
+    assert st["gpu_entropy_images"] == sum(1 for e in _M["decode"] if not e["progressive"] and e["restart"] == 0)
+    assert all(s == 0 for s in statuses)
+    import hashlib
+    for e, (jpeg, rgb), o in zip(_M["decode"], cases, outs):
+        got = o.cpu().numpy()
+        assert hashlib.sha256(got.tobytes()).hexdigest() == e["rgb_sha256"], e["name"]
+
+
+def test_large_images_and_formats(dec):
+    spec = [(1920, 1080, "420", 90, 1), (1920, 1080, "444", 50, 2), (3840, 2160, "422", 92, 3), (1283, 721, "411", 30, 4), (640, 480, "gray", 75, 5),
+            (2560, 1440, "440", 85, 6)]
+    jpegs = [oracle.encode(synth_image(w, h, seed=s), sub, q) for (w, h, sub, q, s) in spec]
+    for fmt in ("rgb", "bgr_planar", "yuv_planar"):
+        outs, _ = dec.decode(jpegs, fmt=fmt, gpu_huffman=True)
+        _sync()
+        assert dec.stats()["gpu_entropy_images"] == len(jpegs)
+        for j, o in zip(jpegs, outs):
+            if fmt == "yuv_planar":
+                for a, b in zip(o, oracle.decode_planes(j)):
+                    assert np.array_equal(a.cpu().numpy(), b)
+            elif fmt == "rgb":
+                assert np.array_equal(o.cpu().numpy(), oracle.decode(j))
+            else:
+                assert np.array_equal(o.cpu().numpy(), oracle.decode(j, oracle.FMT_BGR).transpose(2, 0, 1))
+
+
+def test_bad_streams_get_the_host_path_statuses(dec):
+    good = oracle.encode(synth_image(320, 240, seed=9), "420", 90)
+    trunc = good[: len(good) * 2 // 3] + b"\xff\xd9"
+    flipped = bytearray(good)
+    for k in range(len(good) // 2, len(good) // 2 + 40):
+        flipped[k] ^= 0x5A
+    flipped = bytes(flipped).replace(b"\xff", b"\xfe")[: len(good)]
+    flipped = good[:700] + flipped[700:-2] + b"\xff\xd9"
+    jpegs = [good, trunc, good, flipped]
+    outs = dec.allocate_outputs(jpegs)
+    _, st_gpu = dec.decode(jpegs, outs=outs, gpu_huffman=True, check=False)
+    _sync()
+    first = outs[0].cpu().numpy().copy()
+    _, st_cpu = dec.decode(jpegs, outs=outs, gpu_huffman=False, check=False)
+    _sync()
+    assert st_gpu[0] == 0 and st_gpu[2] == 0 and st_gpu[1] in (4, 5)
+    assert [s == 0 for s in st_gpu] == [s == 0 for s in st_cpu]
+    assert np.array_equal(first, oracle.decode(good))
+    if st_cpu[3] == 0:  # corrupted bits can still be decodable: then both paths must agree on the pixels as well
+        a = outs[3].cpu().numpy().copy()
+        dec.decode(jpegs, outs=outs, gpu_huffman=True, check=False)
+        _sync()
+        assert np.array_equal(outs[3].cpu().numpy(), a)
+
+
+def test_config1_batch_1080p_gpu_huffman_repeated(dec):
+    jpegs = [oracle.encode(synth_image(1920, 1080, seed=s), "420", 90) for s in range(3)] * 6
+    refs = {}
+    for rep in range(3):
+        outs, _ = dec.decode(jpegs, gpu_huffman=True)
+        _sync()
+        for j, o in zip(jpegs, outs):
+            if j not in refs:
+                refs[j] = oracle.decode(j)
+            assert np.array_equal(o.cpu().numpy(), refs[j])
