@@ -164,8 +164,9 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     huff_to_image_.clear();
 
     size_t max_units = 0, coef_total = 0, plane_total = 0;
-    size_t huff_stream_total = 0, huff_subseq_ub = 0;
+    size_t huff_stream_total = 0, huff_subseq_ub = 0, huff_pool_total = 0, huff_blocks_total = 0;
     max_huff_units_ = 0;
+    max_pool_words_ = 0;
     std::vector<size_t> plane_off((size_t)n * 4, (size_t)-1);
     coef_bytes_ = output_bytes_ = 0;
     for (int i = 0; i < n; i++) {
@@ -240,6 +241,12 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
             const size_t nsub = (cap * 8 + kSubseqBits - 1) / kSubseqBits;
             huff_subseq_ub += nsub;
             max_huff_units_ += (nsub + 255) / 256;
+            const size_t pool_words = gpu_pool_words(f.scans[0]);
+            im.tables_offset = huff_pool_total;  // relative; rebased below
+            huff_pool_total += align_up(pool_words * 2, 64);
+            max_pool_words_ = std::max(max_pool_words_, pool_words);
+            im.dc_diff_offset = huff_blocks_total * 2;
+            huff_blocks_total += (f.total_blocks() + 31) & ~(size_t)31;
         }
         coef_bytes_ += f.total_blocks() * 128;
         if (fmt == kOutPlanarYUV) {
@@ -259,7 +266,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     huff_dc_units_offset_ = align_up(huff_units_offset_ + sizeof(HuffUnit) * max_huff_units_, 256);
     huff_list_offset_ = align_up(huff_dc_units_offset_ + sizeof(HuffUnit) * ng * 4, 256);
     const size_t tables_base = align_up(huff_list_offset_ + sizeof(uint32_t) * ng, 256);
-    const size_t streams_base = align_up(tables_base + sizeof(HuffDecodeTable) * 8 * ng, 256);
+    const size_t streams_base = align_up(tables_base + huff_pool_total, 256);
     coef_offset_ = align_up(streams_base + huff_stream_total, 256);
     for (int pass = 0; pass < 2; pass++) {  // host-decoded images first, GPU-decoded ones behind the H2D boundary
         if (pass == 1) {
@@ -276,7 +283,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
             }
             if (im.gpu_entropy) {
                 im.stream_offset += streams_base;
-                im.tables_offset = tables_base + sizeof(HuffDecodeTable) * 8 * (size_t)im.huff_index;
+                im.tables_offset += tables_base;
             }
         }
     }
@@ -295,7 +302,11 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     if ((st = pinned_.reserve(h2d_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     if ((st = device_.reserve(staging_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     if ((st = planes_.reserve(plane_bytes_ + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
-    if (ng && (st = work_.reserve(total_subseq_ * 12 + 1024)) != HIPJPEG_STATUS_SUCCESS) return st;
+    // device-only scratch of the entropy kernels: subsequence states | first block indices | change counters | DC differences
+    work_first_block_ = align_up(total_subseq_ * 8, 256);
+    work_changed_ = work_first_block_ + align_up(total_subseq_ * 4, 256);
+    work_dc_diff_ = work_changed_ + 256;
+    if (ng && (st = work_.reserve(work_dc_diff_ + huff_blocks_total * 2 + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     huff_images_.assign(ng, HuffImage());
 
     for (int i = 0; i < n; i++) {
@@ -320,9 +331,9 @@ void DecodeBatch::entropy_stage(int i)
         // host part of the GPU entropy path: drop the byte stuffing, expand the Huffman tables, describe the scan
         const ScanHeader& sc = im.frame.scans[0];
         im.stream_bytes = (uint32_t)destuff_scan(im.data, sc, pinned_.data() + im.stream_offset);
-        build_gpu_tables(sc, reinterpret_cast<HuffDecodeTable*>(pinned_.data() + im.tables_offset));
         HuffImage& h = huff_images_[im.huff_index];
         fill_huff_image(im.frame, im.stream_bytes, &h);
+        build_gpu_pool(sc, &h, reinterpret_cast<uint16_t*>(pinned_.data() + im.tables_offset));
         // magnitude bound for the 24-bit multiplier decision without seeing the coefficients: DC values live in int16,
         // AC magnitudes are below 2^(largest size category any AC table of the scan can code)
         for (int c = 0; c < im.frame.ncomp; c++) {
@@ -417,7 +428,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             continue;
         }
         h.stream = device_.data() + im.stream_offset;
-        h.tables = reinterpret_cast<const HuffDecodeTable*>(device_.data() + im.tables_offset);
+        h.pool = reinterpret_cast<const uint16_t*>(device_.data() + im.tables_offset);
+        h.dc_diff = reinterpret_cast<int16_t*>(work_.data() + work_dc_diff_ + im.dc_diff_offset);
         for (int c = 0; c < im.frame.ncomp; c++) h.coef[c] = reinterpret_cast<int16_t*>(device_.data() + im.coef_offset[c]);
         h.first_subseq = first_subseq;
         first_subseq += h.num_subseq;
@@ -446,9 +458,13 @@ hipjpegStatus_t DecodeBatch::transfer(void* stream)
     return e == hipSuccess ? HIPJPEG_STATUS_SUCCESS : HIPJPEG_STATUS_HIP_ERROR;
 }
 
-// GPU entropy stage: zero the coefficient arena, synchronise the subsequence decoders (relaunching until a launch changes
-// nothing), scan block counts, write coefficients, integrate DC.  Blocks: the host needs the per-image status to fall back
-// to its own entropy decoder for streams the kernels flagged (corrupt or truncated data).
+// GPU entropy stage: zero the coefficient arena, synchronise the subsequence decoders, scan block counts, write
+// coefficients, integrate DC.  The common case is enqueued without any host round trip: launch 1 leaves every workgroup in
+// a local fixpoint, launch 2 repairs the workgroup boundaries and counts the workgroups whose outgoing state moved; when
+// that count is zero the states are the global fixpoint (no workgroup consumed a state that changed afterwards).  Only if
+// it is not zero -- a correction crossed a whole workgroup -- more launches follow and the write passes are repeated.
+// Blocks at the end: the host needs the per-image status to fall back to its own entropy decoder for streams the kernels
+// flagged (corrupt or truncated data).
 hipjpegStatus_t DecodeBatch::run_gpu_entropy(void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
@@ -461,28 +477,45 @@ hipjpegStatus_t DecodeBatch::run_gpu_entropy(void* stream)
     const HuffUnit* ddc = reinterpret_cast<const HuffUnit*>(device_.data() + huff_dc_units_offset_);
     const uint32_t* dlist = reinterpret_cast<const uint32_t*>(device_.data() + huff_list_offset_);
     unsigned long long* states = reinterpret_cast<unsigned long long*>(work_.data());
-    uint32_t* first_block = reinterpret_cast<uint32_t*>(work_.data() + align_up(total_subseq_ * 8, 256));
-    unsigned int* changed = reinterpret_cast<unsigned int*>(work_.data() + align_up(total_subseq_ * 8, 256) + align_up(total_subseq_ * 4, 256));
-    if (hipMemsetAsync(device_.data() + gpu_coef_begin_, 0, gpu_coef_bytes_, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-    unsigned int host_changed = 1;
-    last_sync_launches_ = 0;
-    for (int pass = 0; pass < 64 && host_changed; pass++) {
-        if (hipMemsetAsync(changed, 0, sizeof(unsigned int), s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-        if (launch_huff_sync(dimg, dunits, (int)huff_units_.size(), states, changed, pass == 0, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
-        if (hipMemcpyAsync(&host_changed, changed, sizeof host_changed, hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-        if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-        last_sync_launches_++;
-    }
-    const bool converged = host_changed == 0;
-    if (converged) {
-        if (launch_huff_scan(dimg, dlist, (int)huff_list_.size(), states, first_block, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
-        if (launch_huff_write(dimg, dunits, (int)huff_units_.size(), states, first_block, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
-        if (launch_huff_dc(dimg, ddc, (int)huff_dc_units_.size(), stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
-    }
-    // status read-back (into the pinned mirror of the descriptor array)
+    uint32_t* first_block = reinterpret_cast<uint32_t*>(work_.data() + work_first_block_);
+    unsigned int* changed = reinterpret_cast<unsigned int*>(work_.data() + work_changed_);
+    const unsigned pool_bytes = (unsigned)align_up(max_pool_words_ * 2, 256);
+    const int nunits = (int)huff_units_.size();
+    unsigned int* host_changed = reinterpret_cast<unsigned int*>(pinned_.data() + h2d_bytes_);  // 256 spare bytes behind the staged data
+    auto write_passes = [&]() -> bool {
+        return hipMemsetAsync(device_.data() + gpu_coef_begin_, 0, gpu_coef_bytes_, s) == hipSuccess &&
+               launch_huff_scan(dimg, dlist, (int)huff_list_.size(), states, first_block, stream) == 0 &&
+               launch_huff_write(dimg, dunits, nunits, states, first_block, pool_bytes, stream) == 0 &&
+               launch_huff_dc(dimg, ddc, (int)huff_dc_units_.size(), stream) == 0;
+    };
+    if (hipMemsetAsync(changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_huff_sync(dimg, dunits, nunits, states, changed + 1, 1, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_huff_sync(dimg, dunits, nunits, states, changed, 0, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (!write_passes()) return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipMemcpyAsync(host_changed, changed, sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     HuffImage* himg = reinterpret_cast<HuffImage*>(pinned_.data() + huff_desc_offset_);
     if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    last_sync_launches_ = 2;
+    bool converged = *host_changed == 0;
+    if (!converged) {
+        for (int pass = 0; pass < 64 && !converged; pass++) {
+            if (hipMemsetAsync(changed, 0, sizeof(unsigned int), s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+            if (launch_huff_sync(dimg, dunits, nunits, states, changed, 0, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+            if (hipMemcpyAsync(host_changed, changed, sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+            if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+            last_sync_launches_++;
+            converged = *host_changed == 0;
+        }
+        if (converged) {
+            // the first write passes ran on unsettled states: clear their verdicts and repeat them
+            for (size_t g = 0; g < huff_images_.size(); g++) himg[g].status = 0;
+            if (hipMemcpyAsync(dimg, himg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+            if (!write_passes()) return HIPJPEG_STATUS_HIP_ERROR;
+            if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+            if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        }
+    }
     for (size_t g = 0; g < huff_images_.size(); g++) {
         PlannedImage& im = images_[huff_to_image_[g]];
         if (im.status != HIPJPEG_STATUS_SUCCESS) continue;

@@ -62,6 +62,7 @@ struct PlannedImage {
     int huff_index = -1;          // index into the HuffImage array
     size_t stream_offset = 0;     // staging offsets of the destuffed stream and the 8 expanded tables
     size_t tables_offset = 0;
+    size_t dc_diff_offset = 0;  // bytes into the DC-difference scratch
     uint32_t stream_bytes = 0;
 };
 
@@ -111,7 +112,8 @@ private:
     std::vector<uint32_t> huff_list_;
     std::vector<int> huff_to_image_;
     size_t huff_desc_offset_ = 0, huff_units_offset_ = 0, huff_dc_units_offset_ = 0, huff_list_offset_ = 0, h2d_bytes_ = 0;
-    size_t gpu_coef_begin_ = 0, gpu_coef_bytes_ = 0, total_subseq_ = 0, max_huff_units_ = 0;
+    size_t gpu_coef_begin_ = 0, gpu_coef_bytes_ = 0, total_subseq_ = 0, max_huff_units_ = 0, max_pool_words_ = 0;
+    size_t work_first_block_ = 0, work_changed_ = 0, work_dc_diff_ = 0;  // offsets into work_
     uint64_t stream_bytes_total_ = 0;
     int last_sync_launches_ = 0;
     bool entropy_done_ = false;

@@ -12,10 +12,12 @@ struct HuffUnit {
     uint32_t first;
 };
 
+// pool_bytes = dynamic LDS for the lookup tables: 2 * the largest HuffImage::pool_words of the batch
 int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned int* changed, int first_pass,
-                     void* stream);
+                     unsigned pool_bytes, void* stream);
 int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages, const unsigned long long* states, uint32_t* first_block, void* stream);
-int launch_huff_write(HuffImage* images, const HuffUnit* units, int nunits, const unsigned long long* states, const uint32_t* first_block, void* stream);
+int launch_huff_write(HuffImage* images, const HuffUnit* units, int nunits, const unsigned long long* states, const uint32_t* first_block,
+                      unsigned pool_bytes, void* stream);
 int launch_huff_dc(const HuffImage* images, const HuffUnit* units, int nunits, void* stream);
 
 }  // namespace hipjpeg

@@ -4,13 +4,20 @@
 // (extensions/nvjpeg/cuda_decoder.cpp:512-521): the Huffman stage moves to the device, so neither the host cores nor the
 // PCIe copy of 6 MB of coefficients per image sit on the critical path any more -- only the ~0.5 MB bitstream crosses.
 //
-// Mapping: one lane decodes one 1024-bit subsequence; a workgroup owns 256 consecutive subsequences of ONE image and keeps
-// that image's Huffman tables in LDS (8 slots x 2.4 KB).  Decoding is inherently serial per lane (data-dependent code
-// lengths); parallelism comes from the number of subsequences (4096 per 0.5 MB image, ~1M per 256-image batch).
-//   huff_sync_kernel   pass 0 + workgroup-local synchronisation loop in LDS; publishes end states; counts global changes
+// Mapping: one lane decodes one 1024-bit subsequence; a workgroup owns 256 consecutive subsequences of ONE image.
+// Decoding is inherently serial per lane (data-dependent code lengths); parallelism comes from the number of subsequences
+// (4096 per 0.5 MB image, ~1M per 256-image batch).  Everything a lane touches per symbol lives in LDS:
+//   * the workgroup's 32 KB of bitstream, loaded once with coalesced dword loads, byte-swapped to MSB-first words and stored
+//     one row of 33 words per lane (32 own words + a copy of the successor's first word): the odd row stride spreads lanes
+//     that sit at the same column over different banks, and a lane's two-word window never leaves its row;
+//   * the image's two-level Huffman lookup tables (uint16 entries, typically ~10 KB);
+//   * per-MCU-position table offsets and block addressing constants, the zigzag permutation.
+// Kernels:
+//   huff_sync_kernel   pass 0 + workgroup-local synchronisation loop in LDS; publishes end states; counts the workgroups
+//                      whose LAST end state moved (the only state another workgroup consumes)
 //   huff_scan_kernel   per image: exclusive scan of completed-block counts -> first block index of every subsequence
-//   huff_write_kernel  final decode with coefficient stores
-//   huff_dc_kernel     per (image, component): DC differences -> DC values in MCU order
+//   huff_write_kernel  final decode with coefficient stores (DC differences to a compact array)
+//   huff_dc_kernel     per (image, component): DC differences -> DC values, stored into the blocks
 #include <hip/hip_runtime.h>
 
 #include "gpu_huffman.h"
@@ -21,94 +28,163 @@ namespace hipjpeg {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kRowWords = kSubseqWords + 1;
 
-struct LdsTables {
-    HuffDecodeTable t[8];
-    __device__ const HuffDecodeTable& operator[](int i) const { return t[i]; }
+#define HJ_LDS __attribute__((address_space(3)))
+
+struct KSlot {
+    int16_t* base;  // coef[comp] + blk0 * 64
+    uint32_t stride_y, stride_x;
 };
 
-// cooperative copy of the image's tables into LDS (dword granularity; sizeof(HuffDecodeTable) is a multiple of 4)
-__device__ __forceinline__ void load_tables(LdsTables* dst, const HuffDecodeTable* src)
+struct WgShared {
+    uint32_t stream[kThreads * kRowWords];
+    unsigned long long end[kThreads + 1];  // [0] = state entering the workgroup, [t+1] = end state of lane t
+    KSlot kslot[10];
+    uint32_t tsel[10];
+    uint32_t zz[16];  // zigzag permutation, 4 entries per word
+};
+
+// LDS accessors for decode_subsequence; one instance per lane.
+struct DevEnv {
+    const HJ_LDS uint32_t* row;     // this lane's stream row
+    const HJ_LDS uint16_t* pool;
+    const HJ_LDS uint32_t* tsel;
+    const HJ_LDS KSlot* kslot;
+    const HJ_LDS uint8_t* zz;
+    uint32_t row_bit0;              // bit position of the row's first bit
+    __device__ __forceinline__ uint32_t window(uint32_t pos) const
+    {
+        const uint32_t q = pos - row_bit0;
+        const HJ_LDS uint32_t* p = row + (q >> 5);
+        const unsigned long long two = ((unsigned long long)p[0] << 32) | p[1];
+        return (uint32_t)(two >> (32 - (q & 31)));
+    }
+    __device__ __forceinline__ uint32_t entry(uint32_t i) const { return pool[i]; }
+    __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
+    __device__ __forceinline__ int16_t* block_ptr(int k, uint32_t mx, uint32_t my) const
+    {
+        const HJ_LDS KSlot* s = kslot + k;
+        int16_t* base = s->base;
+        const uint32_t sy = s->stride_y, sx = s->stride_x;
+        return base + (size_t)(my * sy + mx * sx) * 64;
+    }
+    __device__ __forceinline__ int zigzag(int z) const { return zz[z]; }
+};
+
+// Cooperative staging of the workgroup's slice of the image: stream rows, lookup tables, per-position constants.
+__device__ __forceinline__ void stage_workgroup(WgShared& sh, HJ_LDS uint16_t* pool, const HuffImage& im, uint32_t first_subseq, bool with_addresses)
 {
-    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-    constexpr int n = (int)(sizeof(LdsTables) / 4);
-    for (int i = threadIdx.x; i < n; i += kThreads) d[i] = s[i];
+    const int t = threadIdx.x;
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(im.stream);
+    const uint32_t nwords = im.stream_words;
+    const uint32_t w0 = first_subseq * kSubseqWords;
+    for (uint32_t d = t; d <= (uint32_t)kThreads * kSubseqWords; d += kThreads) {
+        const uint32_t gd = w0 + d;
+        const uint32_t w = gd < nwords ? __builtin_bswap32(g[gd]) : 0xFFFFFFFFu;
+        const uint32_t row = d >> 5, col = d & 31;
+        if (row < (uint32_t)kThreads) sh.stream[row * kRowWords + col] = w;
+        if (col == 0 && row > 0) sh.stream[(row - 1) * kRowWords + kSubseqWords] = w;
+    }
+    const uint32_t* gp = reinterpret_cast<const uint32_t*>(im.pool);
+    HJ_LDS uint32_t* lp = reinterpret_cast<HJ_LDS uint32_t*>(pool);
+    const uint32_t npool = im.pool_words >> 1;  // pool_words is a multiple of 64
+    for (uint32_t i = t; i < npool; i += kThreads) lp[i] = gp[i];
+    if (t < 10) {
+        const HuffK hk = im.k[t];
+        sh.tsel[t] = (uint32_t)hk.tdc | ((uint32_t)hk.tac << 16);
+        if (with_addresses) {
+            KSlot s;
+            s.base = im.coef[hk.comp & 3] + (size_t)hk.blk0 * 64;
+            s.stride_y = hk.stride_y;
+            s.stride_x = hk.stride_x;
+            sh.kslot[t] = s;
+        }
+    }
+    if (t >= 64 && t < 80) {
+        constexpr uint8_t zz[64] = HJ_ZIGZAG_DEVICE_TABLE;
+        const int i = (t - 64) * 4;
+        sh.zz[t - 64] = (uint32_t)zz[i] | ((uint32_t)zz[i + 1] << 8) | ((uint32_t)zz[i + 2] << 16) | ((uint32_t)zz[i + 3] << 24);
+    }
 }
 
-__device__ __forceinline__ unsigned long long pack_state(const SubseqState& s)
+__device__ __forceinline__ DevEnv make_env(WgShared& sh, HJ_LDS uint16_t* pool, uint32_t j)
 {
-    return ((unsigned long long)s.end_bit) | ((unsigned long long)s.zk << 32) | ((unsigned long long)s.nblocks << 48);
-}
-__device__ __forceinline__ SubseqState unpack_state(unsigned long long v)
-{
-    SubseqState s;
-    s.end_bit = (uint32_t)v;
-    s.zk = (uint16_t)(v >> 32);
-    s.nblocks = (uint16_t)(v >> 48);
-    return s;
+    DevEnv env;
+    env.row = (const HJ_LDS uint32_t*)&sh.stream[threadIdx.x * kRowWords];
+    env.pool = pool;
+    env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
+    env.kslot = (const HJ_LDS KSlot*)sh.kslot;
+    env.zz = (const HJ_LDS uint8_t*)sh.zz;
+    env.row_bit0 = j * kSubseqBits;
+    return env;
 }
 
 // states[]: one 8-byte record per subsequence (batch-wide indexing through HuffImage::first_subseq).
+// changed[0] += 1 for every workgroup whose outgoing state (end state of its last subsequence) differs from the published one.
 __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
                                                              unsigned long long* __restrict__ states, unsigned int* __restrict__ changed,
                                                              int first_pass)
 {
-    __shared__ LdsTables tables;
-    __shared__ unsigned long long s_end[kThreads + 1];  // [0] = state entering the workgroup, [t+1] = end state of lane t
+    __shared__ WgShared sh;
+    extern __shared__ uint16_t dyn_pool[];
+    HJ_LDS uint16_t* pool = (HJ_LDS uint16_t*)dyn_pool;
     const HuffUnit u = units[blockIdx.x];
     const HuffImage& im = images[u.image];
-    load_tables(&tables, im.tables);
+    const HuffGeom geom = make_geom(im);
+    const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
+    if (u.first >= nsub) return;  // uniform: the stream turned out shorter than planned
+    stage_workgroup(sh, pool, im, u.first, false);
     const int t = threadIdx.x;
     const uint32_t j = u.first + t;  // subsequence index inside the image
-    const bool active = j < im.num_subseq;
+    const bool active = j < nsub;
+    const bool last = j == min(nsub, u.first + kThreads) - 1;
     unsigned long long* gstate = states + im.first_subseq;
-    const unsigned long long kInitial = 0;  // end_bit 0, z 0, k 0: the exact state at the start of the scan
+    const DevEnv env = make_env(sh, pool, j);
 
-    unsigned long long old_global = 0, mine = 0;
-    if (t == 0) s_end[0] = u.first == 0 ? kInitial : __hip_atomic_load(&gstate[u.first - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the state a lane assumes in pass 0: a block of the first MCU position starts exactly at the subsequence boundary
+    const unsigned long long assumed = (unsigned long long)j * kSubseqBits;
+    unsigned long long old_global = 0, mine = 0, last_start = assumed;
+    if (t == 0) sh.end[0] = (first_pass || u.first == 0) ? assumed : __hip_atomic_load(&gstate[u.first - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kSyncMask;
     __syncthreads();
     uint32_t err = 0;
-    // the start state this lane decoded from last time (bit position + zk); ~0 = never
-    unsigned long long last_start = ~0ull;
     if (active) {
         if (first_pass) {
-            // pass 0: from the first bit of the own subsequence, as if a block started there
-            SubseqState e = decode_subsequence<false>(im, tables, j * kSubseqBits, (j + 1) * kSubseqBits, 0, 0, 0, &err);
-            mine = pack_state(e);
+            mine = pack_state(decode_subsequence<false>(geom, env, j * kSubseqBits, (j + 1) * kSubseqBits, 0, 0, nullptr, &err));
             old_global = ~0ull;
         } else {
             old_global = gstate[j];
             mine = old_global;
         }
     }
-    s_end[t + 1] = mine;
+    sh.end[t + 1] = mine;
+    if (!first_pass) {
+        // the published states of a workgroup are consistent among themselves (the previous launch ended in a local
+        // fixpoint): only lane 0 has to look at its -- possibly new -- incoming state
+        __syncthreads();
+        last_start = t == 0 ? (u.first == 0 ? assumed : ~0ull) : (sh.end[t] & kSyncMask);
+    }
     // workgroup-local fixpoint: lane t re-decodes whenever the end state of lane t-1 (or the incoming state) is not the
     // one it started from last time.  Corrections travel one lane per round; rounds stop when nothing moved.
     for (int round = 0; round < kThreads + 1; round++) {
         __syncthreads();
-        const unsigned long long prev = s_end[t] & 0x0000FFFFFFFFFFFFull;  // start state = predecessor's end (without its block count)
+        const unsigned long long prev = sh.end[t] & kSyncMask;
         bool moved = false;
-        if (active && prev != last_start && !(j == 0)) {
+        if (active && prev != last_start) {
             const SubseqState p = unpack_state(prev);
-            SubseqState e = decode_subsequence<false>(im, tables, p.end_bit, (j + 1) * kSubseqBits, p.zk & 255, p.zk >> 8, 0, &err);
-            const unsigned long long now = pack_state(e);
-            moved = now != mine;
+            const unsigned long long now =
+                pack_state(decode_subsequence<false>(geom, env, p.end_bit, (j + 1) * kSubseqBits, p.zk & 255, p.zk >> 8, nullptr, &err));
+            moved = ((now ^ mine) & kSyncMask) != 0;
             mine = now;
-            last_start = prev;
-        } else if (active && j == 0 && last_start == ~0ull) {
-            // subsequence 0 of the image starts in the exact state; pass 0 already decoded it from there
             last_start = prev;
         }
         __syncthreads();
-        s_end[t + 1] = mine;
+        sh.end[t + 1] = mine;
         if (!__syncthreads_or(moved ? 1 : 0)) break;
     }
-    if (active) {
-        if (mine != old_global) {
-            __hip_atomic_store(&gstate[j], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicAdd(changed, 1u);
-        }
+    if (active && mine != old_global) {
+        __hip_atomic_store(&gstate[j], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last && ((mine ^ old_global) & kSyncMask) != 0) atomicAdd(changed, 1u);
     }
 }
 
@@ -120,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void huff_scan_kernel(HuffImage* __restri
     HuffImage& im = images[image_list[blockIdx.x]];
     const unsigned long long* st = states + im.first_subseq;
     uint32_t* fb = first_block + im.first_subseq;
-    const uint32_t n = im.num_subseq;
+    const uint32_t n = (im.total_bits + kSubseqBits - 1) / kSubseqBits;
     const uint32_t per = (n + kThreads - 1) / kThreads;
     const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     uint32_t sum = 0;
@@ -145,13 +221,19 @@ __global__ __launch_bounds__(kThreads) void huff_scan_kernel(HuffImage* __restri
 __global__ __launch_bounds__(kThreads) void huff_write_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
                                                               const unsigned long long* __restrict__ states, const uint32_t* __restrict__ first_block)
 {
-    __shared__ LdsTables tables;
+    __shared__ WgShared sh;
+    extern __shared__ uint16_t dyn_pool[];
+    HJ_LDS uint16_t* pool = (HJ_LDS uint16_t*)dyn_pool;
     const HuffUnit u = units[blockIdx.x];
     HuffImage& im = images[u.image];
-    load_tables(&tables, im.tables);
+    const HuffGeom geom = make_geom(im);
+    const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
+    if (u.first >= nsub) return;
+    stage_workgroup(sh, pool, im, u.first, true);
     __syncthreads();
     const uint32_t j = u.first + threadIdx.x;
-    if (j >= im.num_subseq) return;
+    if (j >= nsub) return;
+    const DevEnv env = make_env(sh, pool, j);
     const unsigned long long* st = states + im.first_subseq;
     uint32_t begin = 0;
     int z = 0, k = 0;
@@ -162,11 +244,12 @@ __global__ __launch_bounds__(kThreads) void huff_write_kernel(HuffImage* __restr
         k = p.zk >> 8;
     }
     uint32_t err = 0;
-    decode_subsequence<true>(im, tables, begin, (j + 1) * kSubseqBits, z, k, first_block[im.first_subseq + j], &err);
+    HuffCursor cursor = make_cursor(geom, env, first_block[im.first_subseq + j], k);
+    decode_subsequence<true>(geom, env, begin, (j + 1) * kSubseqBits, z, k, &cursor, &err);
     if (err) im.status = 1;  // benign race: every writer stores the same value
 }
 
-// One workgroup per (image, component): integrate the DC differences in MCU order.
+// One workgroup per (image, component): integrate the DC differences in MCU order and store them into the blocks.
 __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units)
 {
     __shared__ int s_sum[kThreads];
@@ -174,20 +257,25 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
     const HuffImage& im = images[u.image];
     const int c = (int)u.first;
     const uint32_t h = im.comp_h[c], v = im.comp_v[c], bpc = h * v;  // blocks of this component per MCU
-    const uint32_t mcus = im.total_blocks / im.blocks_per_mcu;
+    const uint32_t bpm = im.blocks_per_mcu, k0 = im.comp_k0[c];
+    const uint32_t mcus = im.mcus_x * im.mcus_y;
     const uint32_t n = mcus * bpc;
     int16_t* coef = im.coef[c];
+    const int16_t* diff = im.dc_diff;
     const uint32_t bw = im.blocks_w[c], mcus_x = im.mcus_x;
-    auto dc_ptr = [&](uint32_t s) -> int16_t* {
-        const uint32_t mcu = s / bpc, jj = s - mcu * bpc;
-        const uint32_t my = mcu / mcus_x, mx = mcu - my * mcus_x;
-        const uint32_t dy = jj / h, dx = jj - dy * h;
-        return coef + ((size_t)(my * v + dy) * bw + (mx * h + dx)) * 64;
-    };
     const uint32_t per = (n + kThreads - 1) / kThreads;
     const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     int sum = 0;
-    for (uint32_t s = lo; s < hi; s++) sum += *dc_ptr(s);
+    {
+        uint32_t mcu = lo / bpc, jj = lo - mcu * bpc;
+        for (uint32_t s = lo; s < hi; s++) {
+            sum += diff[mcu * bpm + k0 + jj];
+            if (++jj == bpc) {
+                jj = 0;
+                mcu++;
+            }
+        }
+    }
     s_sum[threadIdx.x] = sum;
     __syncthreads();
     for (int off = 1; off < kThreads; off <<= 1) {
@@ -197,20 +285,30 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
         __syncthreads();
     }
     int run = threadIdx.x ? s_sum[threadIdx.x - 1] : 0;
+    uint32_t mcu = lo / bpc, jj = lo - mcu * bpc;
+    uint32_t my = mcu / mcus_x, mx = mcu - my * mcus_x;
     for (uint32_t s = lo; s < hi; s++) {
-        int16_t* p = dc_ptr(s);
-        run += *p;
-        *p = (int16_t)run;
+        run += diff[mcu * bpm + k0 + jj];
+        const uint32_t dy = jj / h, dx = jj - dy * h;
+        coef[((size_t)(my * v + dy) * bw + (mx * h + dx)) * 64] = (int16_t)run;
+        if (++jj == bpc) {
+            jj = 0;
+            mcu++;
+            if (++mx == mcus_x) {
+                mx = 0;
+                my++;
+            }
+        }
     }
 }
 
 }  // namespace
 
 int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned int* changed, int first_pass,
-                     void* stream)
+                     unsigned pool_bytes, void* stream)
 {
     if (nunits <= 0) return 0;
-    hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units, states, changed, first_pass);
+    hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, units, states, changed, first_pass);
     return (int)hipGetLastError();
 }
 
@@ -221,10 +319,11 @@ int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages,
     return (int)hipGetLastError();
 }
 
-int launch_huff_write(HuffImage* images, const HuffUnit* units, int nunits, const unsigned long long* states, const uint32_t* first_block, void* stream)
+int launch_huff_write(HuffImage* images, const HuffUnit* units, int nunits, const unsigned long long* states, const uint32_t* first_block,
+                      unsigned pool_bytes, void* stream)
 {
     if (nunits <= 0) return 0;
-    hipLaunchKernelGGL(huff_write_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units, states, first_block);
+    hipLaunchKernelGGL(huff_write_kernel, dim3(nunits), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, units, states, first_block);
     return (int)hipGetLastError();
 }
 

@@ -18,7 +18,8 @@ bool gpu_entropy_eligible(const FrameInfo& f)
     }
     if (bpm > 10) return false;
     if ((sc.data_end - sc.data_begin) >= (1ull << 28)) return false;  // bit positions are 32-bit
-    return true;
+    const size_t words = gpu_pool_words(sc);
+    return words != 0 && words <= (size_t)kMaxPoolWords;
 }
 
 size_t destuff_scan(const uint8_t* data, const ScanHeader& sc, uint8_t* out)
@@ -45,80 +46,172 @@ size_t destuff_scan(const uint8_t* data, const ScanHeader& sc, uint8_t* out)
         }
     }
     const size_t n = (size_t)(o - out);
-    memset(o, 0xFF, kStreamSlackBytes);
+    memset(o, 0xFF, kStreamSlackBytes + ((4 - (n & 3)) & 3));  // whole 32-bit words stay readable past the end
     return n;
 }
 
-static void expand_table(const HuffSpec& s, HuffDecodeTable* t)
+namespace {
+
+// Walks the canonical code of `s`; calls fn(length, code, symbol) for every code.  False if the code is over-subscribed.
+template <class Fn>
+bool for_each_code(const HuffSpec& s, Fn fn)
 {
-    memset(t, 0, sizeof *t);
-    if (!s.present) {
-        for (int l = 0; l < 18; l++) t->maxcode[l] = -1;
-        return;
-    }
-    memcpy(t->vals, s.vals, sizeof t->vals);
-    int code = 0, k = 0;
+    uint32_t code = 0;
+    int k = 0;
     for (int l = 1; l <= 16; l++) {
-        t->valoff[l] = k - code;
-        if (s.bits[l]) {
-            if (l <= kHuffFastBits)
-                for (int i = 0; i < s.bits[l]; i++) {
-                    const int lo = (code + i) << (kHuffFastBits - l);
-                    const uint16_t e = (uint16_t)((l << 8) | s.vals[k + i]);
-                    for (int j = 0; j < (1 << (kHuffFastBits - l)); j++) t->fast[lo + j] = e;
-                }
-            k += s.bits[l];
-            code += s.bits[l];
-            t->maxcode[l] = code - 1;
-        } else {
-            t->maxcode[l] = -1;
+        for (int i = 0; i < s.bits[l]; i++, k++, code++) {
+            if (code >= (1u << l) || k >= 256) return false;
+            fn(l, code, s.vals[k]);
         }
         code <<= 1;
     }
-    t->maxcode[0] = -1;
-    t->maxcode[17] = 0x7fffffff;
+    return true;
 }
 
-void build_gpu_tables(const ScanHeader& sc, HuffDecodeTable out[8])
+// entries of one table: first level + second-level tables; 0 = malformed
+size_t table_words(const HuffSpec& s, bool is_dc)
 {
-    for (int i = 0; i < 4; i++) {
-        expand_table(sc.dc[i], &out[i]);
-        expand_table(sc.ac[i], &out[4 + i]);
+    if (!s.present) return 0;
+    std::vector<uint8_t> has_sub(1u << kHuffFastBits, 0);
+    size_t words = 1u << kHuffFastBits;
+    bool bad = false;
+    bool ok = for_each_code(s, [&](int l, uint32_t code, uint8_t sym) {
+        if (is_dc && sym > 15) bad = true;
+        if (l > kHuffFastBits) {
+            const uint32_t prefix = code >> (l - kHuffFastBits);
+            if (!has_sub[prefix]) {
+                has_sub[prefix] = 1;
+                words += 1u << kHuffSubBits;
+            }
+        }
+    });
+    return ok && !bad ? words : 0;
+}
+
+// Expands one table at pool[base...]; returns the number of entries used.
+size_t expand_table(const HuffSpec& s, uint16_t* pool, size_t base)
+{
+    const uint16_t invalid = (uint16_t)(kEntryInvalid | (1u << 8));  // "no such code": consume one bit, symbol 0
+    uint16_t* first = pool + base;
+    for (int i = 0; i < (1 << kHuffFastBits); i++) first[i] = invalid;
+    size_t used = 1u << kHuffFastBits;
+    for_each_code(s, [&](int l, uint32_t code, uint8_t sym) {
+        const uint16_t e = (uint16_t)((l << 8) | sym);
+        if (l <= kHuffFastBits) {
+            const uint32_t lo = code << (kHuffFastBits - l);
+            for (uint32_t j = 0; j < (1u << (kHuffFastBits - l)); j++) first[lo + j] = e;
+        } else {
+            const uint32_t prefix = code >> (l - kHuffFastBits);
+            if (!(first[prefix] & kEntryLong)) {
+                first[prefix] = (uint16_t)(kEntryLong | (base + used));
+                for (int j = 0; j < (1 << kHuffSubBits); j++) pool[base + used + j] = invalid;
+                used += 1u << kHuffSubBits;
+            }
+            uint16_t* sub = pool + (first[prefix] & 0x7FFFu);
+            const uint32_t lo = (code & ((1u << (l - kHuffFastBits)) - 1)) << (16 - l);
+            for (uint32_t j = 0; j < (1u << (16 - l)); j++) sub[lo + j] = e;
+        }
+    });
+    return used;
+}
+
+}  // namespace
+
+size_t gpu_pool_words(const ScanHeader& sc)
+{
+    size_t words = 0;
+    bool dc_seen[4] = {false, false, false, false}, ac_seen[4] = {false, false, false, false};
+    for (int i = 0; i < sc.ncomp; i++) {
+        const int td = sc.td[i], ta = sc.ta[i];
+        if (!dc_seen[td]) {
+            dc_seen[td] = true;
+            const size_t w = table_words(sc.dc[td], true);
+            if (!w) return 0;
+            words += w;
+        }
+        if (!ac_seen[ta]) {
+            ac_seen[ta] = true;
+            const size_t w = table_words(sc.ac[ta], false);
+            if (!w) return 0;
+            words += w;
+        }
+    }
+    return words;
+}
+
+void build_gpu_pool(const ScanHeader& sc, HuffImage* im, uint16_t* pool)
+{
+    size_t dc_off[4] = {0, 0, 0, 0}, ac_off[4] = {0, 0, 0, 0};
+    bool dc_seen[4] = {false, false, false, false}, ac_seen[4] = {false, false, false, false};
+    size_t used = 0;
+    for (int i = 0; i < sc.ncomp; i++) {
+        const int td = sc.td[i], ta = sc.ta[i];
+        if (!dc_seen[td]) {
+            dc_seen[td] = true;
+            dc_off[td] = used;
+            used += expand_table(sc.dc[td], pool, used);
+        }
+        if (!ac_seen[ta]) {
+            ac_seen[ta] = true;
+            ac_off[ta] = used;
+            used += expand_table(sc.ac[ta], pool, used);
+        }
+    }
+    im->pool_words = (uint32_t)used;
+    for (uint32_t k = 0; k < im->blocks_per_mcu; k++) {
+        const int c = im->k[k].comp;
+        im->k[k].tdc = (uint16_t)dc_off[sc.td[c]];
+        im->k[k].tac = (uint16_t)ac_off[sc.ta[c]];
     }
 }
 
 void fill_huff_image(const FrameInfo& f, uint32_t stream_bytes, HuffImage* im)
 {
     memset(im, 0, sizeof *im);
-    const ScanHeader& sc = f.scans[0];
     im->total_bits = stream_bytes * 8u;
     im->num_subseq = (im->total_bits + kSubseqBits - 1) / kSubseqBits;
+    im->stream_words = (uint32_t)((((size_t)stream_bytes + 3) & ~(size_t)3) + kStreamSlackBytes) / 4;
     im->mcus_x = (uint32_t)(f.ncomp == 1 ? (f.comp[0].samp_w + 7) / 8 : f.mcus_x);
-    const uint32_t mcus_y = (uint32_t)(f.ncomp == 1 ? (f.comp[0].samp_h + 7) / 8 : f.mcus_y);
+    im->mcus_y = (uint32_t)(f.ncomp == 1 ? (f.comp[0].samp_h + 7) / 8 : f.mcus_y);
     im->ncomp = (uint32_t)f.ncomp;
     int k = 0;
     for (int c = 0; c < f.ncomp; c++) {
         const int h = f.ncomp == 1 ? 1 : f.comp[c].h, v = f.ncomp == 1 ? 1 : f.comp[c].v;
         im->comp_h[c] = (uint8_t)h;
         im->comp_v[c] = (uint8_t)v;
+        im->comp_k0[c] = (uint8_t)k;
         im->blocks_w[c] = (uint32_t)f.comp[c].blocks_w;
         for (int dy = 0; dy < v; dy++)
             for (int dx = 0; dx < h; dx++, k++) {
-                im->k_comp[k] = (uint8_t)c;
-                im->k_dx[k] = (uint8_t)dx;
-                im->k_dy[k] = (uint8_t)dy;
-                im->k_dc[k] = (uint8_t)sc.td[c];
-                im->k_ac[k] = (uint8_t)(4 + sc.ta[c]);
+                HuffK& hk = im->k[k];
+                hk.comp = (uint8_t)c;
+                hk.blk0 = (uint32_t)(dy * f.comp[c].blocks_w + dx);
+                hk.stride_y = (uint32_t)(v * f.comp[c].blocks_w);
+                hk.stride_x = (uint8_t)h;
             }
     }
     im->blocks_per_mcu = (uint32_t)k;
-    im->total_blocks = im->mcus_x * mcus_y * (uint32_t)k;
+    im->total_blocks = im->mcus_x * im->mcus_y * (uint32_t)k;
 }
 
 namespace {
-struct TablesRef {
-    const HuffDecodeTable* t;
-    const HuffDecodeTable& operator[](int i) const { return t[i]; }
+// plain-memory accessors for decode_subsequence
+struct HostEnv {
+    const HuffImage* im;
+    uint32_t window(uint32_t pos) const
+    {
+        const uint8_t* p = im->stream + (pos >> 3);
+        const uint64_t v = ((uint64_t)p[0] << 32) | ((uint64_t)p[1] << 24) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 8) | (uint64_t)p[4];
+        return (uint32_t)(v >> (8 - (pos & 7)));
+    }
+    uint32_t entry(uint32_t i) const { return im->pool[i]; }
+    uint32_t tables(int k) const { return (uint32_t)im->k[k].tdc | ((uint32_t)im->k[k].tac << 16); }
+    int16_t* block_ptr(int k, uint32_t mx, uint32_t my) const
+    {
+        const HuffK& hk = im->k[k];
+        return im->coef[hk.comp] + ((size_t)hk.blk0 + (size_t)my * hk.stride_y + (size_t)mx * hk.stride_x) * 64;
+    }
+    int zigzag(int z) const { return kZigzagDeviceGpuHost[z]; }
 };
 }  // namespace
 
@@ -128,30 +221,33 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
     const ScanHeader& sc = f.scans[0];
     std::vector<uint8_t> stream(destuffed_capacity(sc));
     const size_t n = destuff_scan(data, sc, stream.data());
-    std::vector<HuffDecodeTable> tables(8);
-    build_gpu_tables(sc, tables.data());
+    std::vector<uint16_t> pool(gpu_pool_words(sc));
     HuffImage im;
     fill_huff_image(f, (uint32_t)n, &im);
+    build_gpu_pool(sc, &im, pool.data());
+    std::vector<int16_t> dc_diff(im.total_blocks);
     im.stream = stream.data();
-    im.tables = tables.data();
+    im.pool = pool.data();
+    im.dc_diff = dc_diff.data();
     for (int c = 0; c < f.ncomp; c++) {
         im.coef[c] = coef[c];
         memset(coef[c], 0, (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 128);
     }
-    TablesRef tr{tables.data()};
+    const HostEnv env{&im};
+    const HuffGeom geom = make_geom(im);
     const uint32_t ns = im.num_subseq;
     std::vector<SubseqState> cur(ns), nxt(ns);
     uint32_t err = 0;
     // pass 0
-    for (uint32_t i = 0; i < ns; i++) cur[i] = decode_subsequence<false>(im, tr, i * kSubseqBits, (i + 1) * kSubseqBits, 0, 0, 0, &err);
+    for (uint32_t i = 0; i < ns; i++) cur[i] = decode_subsequence<false>(geom, env, i * kSubseqBits, (i + 1) * kSubseqBits, 0, 0, nullptr, &err);
     int passes = 0;
     for (;;) {
         bool changed = false;
-        nxt[0] = cur[0];
+        if (ns) nxt[0] = cur[0];
         for (uint32_t i = 1; i < ns; i++) {
             const SubseqState& prev = cur[i - 1];
-            nxt[i] = decode_subsequence<false>(im, tr, prev.end_bit, (i + 1) * kSubseqBits, prev.zk & 255, prev.zk >> 8, 0, &err);
-            if (!same_sync_state(nxt[i], cur[i]) || nxt[i].nblocks != cur[i].nblocks) changed = true;
+            nxt[i] = decode_subsequence<false>(geom, env, prev.end_bit, (i + 1) * kSubseqBits, prev.zk & 255, prev.zk >> 8, nullptr, &err);
+            if (pack_state(nxt[i]) != pack_state(cur[i])) changed = true;
         }
         cur.swap(nxt);
         passes++;
@@ -171,21 +267,20 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
     for (uint32_t i = 0; i < ns; i++) {
         const uint32_t begin = i == 0 ? 0 : cur[i - 1].end_bit;
         const int z = i == 0 ? 0 : (cur[i - 1].zk & 255), k = i == 0 ? 0 : (cur[i - 1].zk >> 8);
-        decode_subsequence<true>(im, tr, begin, (i + 1) * kSubseqBits, z, k, first_block[i], &err);
+        HuffCursor cursor = make_cursor(geom, env, first_block[i], k);
+        decode_subsequence<true>(geom, env, begin, (i + 1) * kSubseqBits, z, k, &cursor, &err);
     }
     if (err) return 1;
     // DC integration, per component in MCU (scan) order
-    const uint32_t mcus = im.total_blocks / im.blocks_per_mcu;
     int pred[4] = {0, 0, 0, 0};
-    for (uint32_t m = 0; m < mcus; m++) {
-        const uint32_t my = m / im.mcus_x, mx = m - my * im.mcus_x;
-        for (uint32_t k = 0; k < im.blocks_per_mcu; k++) {
-            const int c = im.k_comp[k];
-            int16_t* blk = coef[c] + ((size_t)(my * im.comp_v[c] + im.k_dy[k]) * im.blocks_w[c] + (mx * im.comp_h[c] + im.k_dx[k])) * 64;
-            pred[c] += blk[0];
-            blk[0] = (int16_t)pred[c];
-        }
-    }
+    uint32_t block = 0;
+    for (uint32_t my = 0; my < im.mcus_y; my++)
+        for (uint32_t mx = 0; mx < im.mcus_x; mx++)
+            for (uint32_t k = 0; k < im.blocks_per_mcu; k++, block++) {
+                const int c = im.k[k].comp;
+                pred[c] += dc_diff[block];
+                env.block_ptr((int)k, mx, my)[0] = (int16_t)pred[c];
+            }
     return 0;
 }
 

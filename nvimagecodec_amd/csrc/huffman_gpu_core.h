@@ -1,6 +1,7 @@
 // huffman_gpu_core.h -- data structures and the per-subsequence decode routine of the GPU entropy decoder.
 // Compiles for both host and device: the HIP kernels (gpu_huffman.hip) and the host emulation used by the CPU tests
-// (gpu_huffman_host.cpp) run the very same code.
+// (gpu_huffman_host.cpp) run the very same decode routine, parameterised only by how stream words and table entries are
+// fetched (LDS on the device, plain memory on the host).
 //
 // Algorithm (self-synchronizing parallel Huffman decoding; Weissenberger & Schmidt, "Accelerating JPEG Decompression on
 // GPUs", 2021 -- restated, not copied): the destuffed entropy-coded segment of a baseline scan is cut into subsequences of
@@ -14,8 +15,9 @@
 //              is exact).
 //   count      each pass also counts the blocks completed in the subsequence; an exclusive scan gives every lane the
 //              index of its first block.
-//   write      the lanes decode once more and write coefficients (column-major block layout, DC still differential).
-//   dc         a per-component scan in MCU order turns DC differences into DC values.
+//   write      the lanes decode once more and write coefficients (column-major block layout); DC differences go to a
+//              compact per-image array in scan order.
+//   dc         a per-component scan in MCU order turns DC differences into DC values and stores them into the blocks.
 // All decisions are integer/bit exact; the result is compared with the host entropy decoder and the oracle in tests/.
 #pragma once
 #include <cstdint>
@@ -29,34 +31,45 @@
 
 namespace hipjpeg {
 
-constexpr int kSubseqBits = 1024;  // bits per subsequence (128 bytes)
-constexpr int kHuffFastBits = 10;
+constexpr int kSubseqBits = 1024;      // bits per subsequence (128 bytes)
+constexpr int kSubseqWords = kSubseqBits / 32;
+constexpr int kHuffFastBits = 10;      // first-level lookup width
+constexpr int kHuffSubBits = 16 - kHuffFastBits;
 constexpr int kStreamSlackBytes = 32;  // readable bytes after the last real byte of a destuffed stream
+constexpr int kMaxPoolWords = 12288;   // uint16 entries of lookup tables per image the kernels accept (24 KB of LDS)
 
-// One Huffman table as the decoder consumes it.
-struct HuffDecodeTable {
-    uint16_t fast[1 << kHuffFastBits];  // (length << 8) | symbol, 0 = code longer than kHuffFastBits (or invalid)
-    int32_t maxcode[18];                // largest code of each length (right-aligned), -1 = none; [17] = sentinel
-    int32_t valoff[17];
-    uint8_t vals[256];
+// Lookup-table entry (uint16): bits 0-7 symbol, bits 8-12 code length, bit 14 "no such code", bit 15 "longer than
+// kHuffFastBits: bits 0-14 = pool offset of the 64-entry second-level table, indexed by the next kHuffSubBits bits".
+constexpr uint32_t kEntryInvalid = 0x4000u;
+constexpr uint32_t kEntryLong = 0x8000u;
+
+// One block position k inside the MCU (k < blocks_per_mcu <= 10).
+struct HuffK {
+    uint32_t blk0;      // (dy * blocks_w + dx): block offset of this position inside MCU (0,0) of its component
+    uint32_t stride_y;  // blocks between vertically adjacent MCUs: v * blocks_w
+    uint16_t tdc, tac;  // pool offsets (uint16 units) of the first-level DC / AC tables
+    uint8_t comp;       // component index
+    uint8_t stride_x;   // blocks between horizontally adjacent MCUs: h
+    uint8_t pad[2];
 };
 
 // Per-image description for the entropy kernels.
 struct alignas(16) HuffImage {
-    const uint8_t* stream;         // destuffed entropy-coded bytes (+ kStreamSlackBytes of 0xFF padding)
-    const HuffDecodeTable* tables; // 8 slots: [0..3] DC tables by id, [4..7] AC tables by id
-    int16_t* coef[4];              // component coefficient blocks (device layout)
-    uint32_t total_bits;           // 8 * destuffed length
-    uint32_t first_subseq;         // index of this image's first subsequence in the batch-wide arrays
-    uint32_t num_subseq;
-    uint32_t total_blocks;         // mcus * blocks_per_mcu
-    uint32_t mcus_x, blocks_per_mcu, ncomp, pad0;
-    uint32_t blocks_w[4];          // allocation grid width per component
-    // per position k inside an MCU (k < blocks_per_mcu <= 10)
-    uint8_t k_comp[12], k_dx[12], k_dy[12], k_dc[12], k_ac[12];
-    uint8_t comp_h[4], comp_v[4];
-    uint32_t status;               // written by the kernels: 0 ok, 1 = invalid code inside the real data, 2 = block count mismatch
-    uint32_t pad1[3];
+    const uint8_t* stream;   // destuffed entropy-coded bytes, 4-byte aligned, `stream_words` 32-bit words readable
+    const uint16_t* pool;    // lookup tables (pool_words entries)
+    int16_t* coef[4];        // component coefficient blocks (device layout)
+    int16_t* dc_diff;        // total_blocks DC differences in scan order (written by the write pass)
+    uint32_t total_bits;     // 8 * destuffed length
+    uint32_t first_subseq;   // index of this image's first subsequence in the batch-wide arrays
+    uint32_t num_subseq;     // ceil(total_bits / kSubseqBits)
+    uint32_t total_blocks;   // mcus * blocks_per_mcu
+    uint32_t mcus_x, mcus_y, blocks_per_mcu, ncomp;
+    uint32_t pool_words, stream_words;
+    uint32_t status;         // written by the kernels: 0 ok, 1 = invalid code inside the real data, 2 = block count mismatch
+    uint32_t pad0;
+    HuffK k[10];
+    uint32_t blocks_w[4];
+    uint8_t comp_h[4], comp_v[4], comp_k0[4], pad1[4];  // comp_k0 = first position k of the component inside the MCU
 };
 
 // What a lane knows after decoding a subsequence.
@@ -66,140 +79,101 @@ struct SubseqState {
     uint16_t nblocks;   // blocks completed by symbols that started inside the subsequence
 };
 
-HJ_HD bool same_sync_state(const SubseqState& a, const SubseqState& b) { return a.end_bit == b.end_bit && a.zk == b.zk; }
+HJ_HD uint64_t pack_state(const SubseqState& s) { return ((uint64_t)s.end_bit) | ((uint64_t)s.zk << 32) | ((uint64_t)s.nblocks << 48); }
+HJ_HD SubseqState unpack_state(uint64_t v)
+{
+    SubseqState s;
+    s.end_bit = (uint32_t)v;
+    s.zk = (uint16_t)(v >> 32);
+    s.nblocks = (uint16_t)(v >> 48);
+    return s;
+}
+constexpr uint64_t kSyncMask = 0x0000FFFFFFFFFFFFull;  // the part of a packed state the successor depends on
 
 // zigzag index -> position inside a device-layout block (transposed natural order); same table as entropy_decode.cpp.
-// Two copies: a __constant__ one for device code and a plain one for host code (the host shadow of a __constant__ variable
-// holds no data).
 #define HJ_ZIGZAG_DEVICE_TABLE                                                                                                            \
     {0,  8,  1,  2,  9,  16, 24, 17, 10, 3,  4,  11, 18, 25, 32, 40, 33, 26, 19, 12, 5,  6,  13, 20, 27, 34, 41, 48, 56, 49, 42, 35, \
      28, 21, 14, 7,  15, 22, 29, 36, 43, 50, 57, 58, 51, 44, 37, 30, 23, 31, 38, 45, 52, 59, 60, 53, 46, 39, 47, 54, 61, 62, 55, 63}
-#if defined(__HIPCC__)
-__device__ __constant__ static const uint8_t kZigzagDeviceGpuConst[64] = HJ_ZIGZAG_DEVICE_TABLE;
-#endif
 static const uint8_t kZigzagDeviceGpuHost[64] = HJ_ZIGZAG_DEVICE_TABLE;
-HJ_HD int zigzag_to_device(int z)
+
+// The scalars the decode loop needs, copied out of HuffImage so that they live in registers across the coefficient stores.
+struct HuffGeom {
+    uint32_t total_bits, blocks_per_mcu, mcus_x, mcus_y;
+    int16_t* dc_diff;
+};
+HJ_HD HuffGeom make_geom(const HuffImage& im)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return kZigzagDeviceGpuConst[z];
-#else
-    return kZigzagDeviceGpuHost[z];
-#endif
+    HuffGeom g;
+    g.total_bits = im.total_bits;
+    g.blocks_per_mcu = im.blocks_per_mcu;
+    g.mcus_x = im.mcus_x;
+    g.mcus_y = im.mcus_y;
+    g.dc_diff = im.dc_diff;
+    return g;
 }
 
-// Next 64 bits of the stream starting at bit `pos`, MSB first.  The stream has kStreamSlackBytes readable bytes after its end.
-HJ_HD uint64_t stream_window(const uint8_t* s, uint32_t pos)
-{
-    const uint8_t* p = s + (pos >> 3);
-    uint64_t hi = ((uint64_t)p[0] << 56) | ((uint64_t)p[1] << 48) | ((uint64_t)p[2] << 40) | ((uint64_t)p[3] << 32) | ((uint64_t)p[4] << 24) |
-                  ((uint64_t)p[5] << 16) | ((uint64_t)p[6] << 8) | (uint64_t)p[7];
-    uint32_t sh = pos & 7;
-    return sh ? ((hi << sh) | ((uint64_t)p[8] >> (8 - sh))) : hi;
-}
-
-// Decodes one Huffman symbol from the top of `w`.  Returns symbol, *len = code length; invalid code -> returns -1, *len = 1
-// (a deterministic choice: desynchronised lanes may well run into bit patterns that are no code at all).
-template <class TableRef>
-HJ_HD int huff_symbol(const TableRef& t, uint64_t w, int* len)
-{
-    const uint32_t e = t.fast[(uint32_t)(w >> (64 - kHuffFastBits))];
-    if (e) {
-        *len = (int)(e >> 8);
-        return (int)(e & 255);
-    }
-    const uint32_t code16 = (uint32_t)(w >> 48);
-    for (int l = kHuffFastBits + 1; l <= 16; l++) {
-        const int32_t code = (int32_t)(code16 >> (16 - l));
-        if (code <= t.maxcode[l]) {
-            *len = l;
-            return t.vals[(code + t.valoff[l]) & 255];
-        }
-    }
-    *len = 1;
-    return -1;
-}
+// Where the write pass is: block index in scan order, MCU coordinates, and the block being filled.
+struct HuffCursor {
+    uint32_t block, mx, my;
+    int16_t* blk;  // nullptr = past the last block of the scan
+};
 
 // Decodes the symbols that START in [begin, limit) (and before total_bits), beginning in state (z, k).
 //   WRITE == false: only tracks the state and counts completed blocks.
-//   WRITE == true : also stores coefficients; `block` = index (in MCU order over the whole scan) of the block the first symbol
-//                   belongs to.  DC differences go to position 0 of each block (the dc kernel integrates them later).
-// `tables` is indexable by slot (0..7) and yields something with .fast/.maxcode/.valoff/.vals.
-template <bool WRITE, class Tables>
-HJ_HD SubseqState decode_subsequence(const HuffImage& im, const Tables& tables, uint32_t begin, uint32_t limit, int z, int k, uint32_t block,
+//   WRITE == true : also stores coefficients through `cur` (initialised by the caller for the block of the first symbol).
+// Env supplies the memory accessors:
+//   uint32_t window(uint32_t pos)        the 32 stream bits starting at bit `pos`, MSB first
+//   uint32_t entry(uint32_t index)       lookup-table pool entry
+//   uint32_t tables(int k)               tdc | tac << 16 for block position k
+//   int16_t* block_ptr(int k, mx, my)    address of the block at position k of MCU (mx, my)
+//   int      zigzag(int z)               device-layout index of zigzag position z
+template <bool WRITE, class Env>
+HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, HuffCursor* cur,
                                      uint32_t* error)
 {
-    uint32_t pos = begin;
-    uint32_t nblocks = 0;
-    const uint32_t total_bits = im.total_bits;
+    uint32_t pos = begin, nblocks = 0;
+    const uint32_t end = limit < im.total_bits ? limit : im.total_bits;
     const int bpm = (int)im.blocks_per_mcu;
-    int16_t* blk = nullptr;
-    if (WRITE && block < im.total_blocks) {
-        const uint32_t mcu = block / (uint32_t)bpm;  // == (block - k) / bpm
-        const uint32_t my = mcu / im.mcus_x, mx = mcu - my * im.mcus_x;
-        const int c = im.k_comp[k];
-        blk = im.coef[c] + ((uint64_t)(my * im.comp_v[c] + im.k_dy[k]) * im.blocks_w[c] + (mx * im.comp_h[c] + im.k_dx[k])) * 64;
-    }
-    while (pos < limit && pos < total_bits) {
-        const uint64_t w = stream_window(im.stream, pos);
-        int len;
-        if (z == 0) {
-            const int s = huff_symbol(tables[im.k_dc[k]], w, &len);
-            int nb = s;
-            if (s < 0 || s > 15) {
-                nb = 0;
-                if (WRITE && blk) *error = 1;
-            }
-            if (WRITE && blk) {
-                int v = 0;
-                if (nb) {
-                    v = (int)((w << len) >> (64 - nb));
-                    if (v < (1 << (nb - 1))) v = v - (1 << nb) + 1;
-                }
-                blk[0] = (int16_t)v;
-            }
-            pos += (uint32_t)(len + nb);
-            z = 1;
-        } else {
-            const int rs = huff_symbol(tables[im.k_ac[k]], w, &len);
-            int r = 0, nb = 0;
-            if (rs < 0) {
-                if (WRITE && blk) *error = 1;
-                z = 64;  // treat as end of block
-            } else {
-                r = rs >> 4;
-                nb = rs & 15;
-                if (nb == 0) {
-                    z = (r == 15) ? z + 16 : 64;
-                } else {
-                    z += r;
-                    if (z <= 63) {
-                        if (WRITE && blk) {
-                            int v = (int)((w << len) >> (64 - nb));
-                            if (v < (1 << (nb - 1))) v = v - (1 << nb) + 1;
-                            blk[zigzag_to_device(z)] = (int16_t)v;
-                        }
-                        z++;
-                    } else if (WRITE && blk) {
+    uint32_t tsel = env.tables(k);
+    while (pos < end) {
+        const uint32_t w = env.window(pos);
+        const bool is_dc = z == 0;
+        const uint32_t tb = is_dc ? (tsel & 0xFFFFu) : (tsel >> 16);
+        uint32_t e = env.entry(tb + (w >> (32 - kHuffFastBits)));
+        if (e & kEntryLong) e = env.entry((e & 0x7FFFu) + ((w >> 16) & ((1u << kHuffSubBits) - 1)));
+        const uint32_t len = (e >> 8) & 31u, sym = e & 255u;
+        const uint32_t nb = sym & 15u, r = is_dc ? 0u : (sym >> 4);
+        if (WRITE) {
+            // nb value bits follow the code; values below 2^(nb-1) are the negative half (JPEG "EXTEND")
+            const uint32_t v = ((w << len) >> 1) >> (31 - nb);
+            const int val = v < ((1u << nb) >> 1) ? (int)v - (int)(1u << nb) + 1 : (int)v;
+            const uint32_t zpos = (uint32_t)z + r;
+            if (cur->blk) {
+                if (e & kEntryInvalid) *error = 1;
+                if (is_dc) {
+                    im.dc_diff[cur->block] = (int16_t)val;
+                } else if (nb) {
+                    if (zpos <= 63)
+                        cur->blk[env.zigzag((int)zpos)] = (int16_t)val;
+                    else
                         *error = 1;  // run past the end of the block
-                    }
                 }
             }
-            pos += (uint32_t)(len + nb);
         }
+        pos += len + nb;
+        z = (!is_dc && nb == 0 && r != 15) ? 64 : z + (int)r + 1;  // EOB | ZRL (+16) / coefficient (+run+1) / DC (-> 1)
         if (z >= 64) {
             z = 0;
             nblocks++;
-            block++;
             if (++k == bpm) k = 0;
+            tsel = env.tables(k);
             if (WRITE) {
-                if (block < im.total_blocks) {
-                    const uint32_t mcu = block / (uint32_t)bpm;
-                    const uint32_t my = mcu / im.mcus_x, mx = mcu - my * im.mcus_x;
-                    const int c = im.k_comp[k];
-                    blk = im.coef[c] + ((uint64_t)(my * im.comp_v[c] + im.k_dy[k]) * im.blocks_w[c] + (mx * im.comp_h[c] + im.k_dx[k])) * 64;
-                } else {
-                    blk = nullptr;
+                cur->block++;
+                if (k == 0 && ++cur->mx == im.mcus_x) {
+                    cur->mx = 0;
+                    cur->my++;
                 }
+                cur->blk = cur->my < im.mcus_y ? env.block_ptr(k, cur->mx, cur->my) : nullptr;
             }
         }
     }
@@ -208,6 +182,19 @@ HJ_HD SubseqState decode_subsequence(const HuffImage& im, const Tables& tables, 
     st.zk = (uint16_t)((k << 8) | z);
     st.nblocks = (uint16_t)(nblocks > 0xFFFF ? 0xFFFF : nblocks);
     return st;
+}
+
+// Cursor for the block with scan-order index `block` whose position inside the MCU is k.
+template <class Env>
+HJ_HD HuffCursor make_cursor(const HuffGeom& im, const Env& env, uint32_t block, int k)
+{
+    HuffCursor c;
+    c.block = block;
+    const uint32_t mcu = block / im.blocks_per_mcu;  // == (block - k) / blocks_per_mcu
+    c.my = mcu / im.mcus_x;
+    c.mx = mcu - c.my * im.mcus_x;
+    c.blk = c.my < im.mcus_y ? env.block_ptr(k, c.mx, c.my) : nullptr;
+    return c;
 }
 
 }  // namespace hipjpeg
