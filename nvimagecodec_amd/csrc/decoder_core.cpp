@@ -150,7 +150,7 @@ bool choose_variant(const FrameInfo& f, OutFormat fmt, bool fancy, int* variant)
 
 hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
                                   hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
-                                  const hipjpegOutputFormat_t* formats)
+                                  const hipjpegOutputFormat_t* formats, ForkJoinPool* pool)
 {
     if (n < 0 || (n > 0 && (!data || !lengths || !outputs))) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     if ((int)format < 0 || (int)format > (int)HIPJPEG_OUTPUT_YUV_PLANAR) return HIPJPEG_STATUS_INVALID_ARGUMENT;
@@ -164,18 +164,19 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     huff_to_image_.clear();
 
     size_t max_units = 0, coef_total = 0, plane_total = 0;
-    size_t huff_stream_total = 0, huff_subseq_ub = 0, huff_pool_total = 0, huff_blocks_total = 0;
+    size_t huff_stream_total = 0, huff_subseq_ub = 0, huff_pool_total = 0, huff_blocks_total = 0, huff_raw_total = 0, huff_chunks_total = 0;
     max_huff_units_ = 0;
     max_pool_words_ = 0;
     std::vector<size_t> plane_off((size_t)n * 4, (size_t)-1);
     coef_bytes_ = output_bytes_ = 0;
-    for (int i = 0; i < n; i++) {
+    // per-image header work (marker walk through the whole file, eligibility, table sizing) is independent: all cores
+    auto prepare = [&](int i) {
         PlannedImage& im = images_[i];
         im.data = data[i];
         im.size = lengths[i];
         if (formats && ((int)formats[i] < 0 || (int)formats[i] > (int)HIPJPEG_OUTPUT_YUV_PLANAR)) {
             im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
-            continue;
+            return;
         }
         const OutFormat fmt = (OutFormat)(formats ? formats[i] : format);
         im.status = data[i] ? status_from_parse(parse_jpeg(data[i], lengths[i], &im.frame)) : HIPJPEG_STATUS_INVALID_ARGUMENT;
@@ -186,6 +187,20 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
             for (int p = 0; p < (fmt == kOutPlanarYUV ? f.ncomp : nplanes_out); p++)
                 if (!outputs[i].plane[p]) im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
         }
+        if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && gpu_entropy_eligible(f)) {
+            im.gpu_entropy = true;
+            im.pool_words = gpu_pool_words(f.scans[0]);
+        }
+    };
+    if (pool && n > 1)
+        pool->parallel_for(n, [&](int i, int) { prepare(i); });
+    else
+        for (int i = 0; i < n; i++) prepare(i);
+
+    for (int i = 0; i < n; i++) {
+        PlannedImage& im = images_[i];
+        const OutFormat fmt = (OutFormat)(formats && im.status != HIPJPEG_STATUS_INVALID_ARGUMENT ? formats[i] : format);
+        const FrameInfo& f = im.frame;
         if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
 
         DecodeImage& d = desc_[i];
@@ -231,17 +246,21 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
             if (c == 0 && im.variant >= 0) max_units += (size_t)((k.blocks_w + kLumaTileW - 1) / kLumaTileW) * (size_t)((k.blocks_h + kLumaTileH - 1) / kLumaTileH);
         }
         if (im.variant == -1) max_units += (size_t)f.height;
-        if (want_gpu_entropy && gpu_entropy_eligible(f)) {
-            im.gpu_entropy = true;
+        if (im.gpu_entropy) {
             im.huff_index = (int)huff_to_image_.size();
             huff_to_image_.push_back(i);
+            const size_t raw_len = f.scans[0].data_end - f.scans[0].data_begin;
             const size_t cap = align_up(destuffed_capacity(f.scans[0]), 64);
-            im.stream_offset = huff_stream_total;  // relative; rebased below
+            im.raw_offset = huff_raw_total;  // relative; rebased below
+            huff_raw_total += align_up(raw_len, 16) + 16;
+            im.stream_offset = huff_stream_total;  // offset into the device-only scratch
             huff_stream_total += cap;
+            im.first_chunk = (uint32_t)huff_chunks_total;
+            huff_chunks_total += (raw_len + kDestuffChunk - 1) / kDestuffChunk;
             const size_t nsub = (cap * 8 + kSubseqBits - 1) / kSubseqBits;
             huff_subseq_ub += nsub;
             max_huff_units_ += (nsub + 255) / 256;
-            const size_t pool_words = gpu_pool_words(f.scans[0]);
+            const size_t pool_words = im.pool_words;
             im.tables_offset = huff_pool_total;  // relative; rebased below
             huff_pool_total += align_up(pool_words * 2, 64);
             max_pool_words_ = std::max(max_pool_words_, pool_words);
@@ -265,9 +284,10 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     huff_units_offset_ = align_up(huff_desc_offset_ + sizeof(HuffImage) * ng, 256);
     huff_dc_units_offset_ = align_up(huff_units_offset_ + sizeof(HuffUnit) * max_huff_units_, 256);
     huff_list_offset_ = align_up(huff_dc_units_offset_ + sizeof(HuffUnit) * ng * 4, 256);
-    const size_t tables_base = align_up(huff_list_offset_ + sizeof(uint32_t) * ng, 256);
+    huff_chunk_units_offset_ = align_up(huff_list_offset_ + sizeof(uint32_t) * ng, 256);
+    const size_t tables_base = align_up(huff_chunk_units_offset_ + sizeof(HuffUnit) * huff_chunks_total, 256);
     const size_t streams_base = align_up(tables_base + huff_pool_total, 256);
-    coef_offset_ = align_up(streams_base + huff_stream_total, 256);
+    coef_offset_ = align_up(streams_base + huff_raw_total, 256);
     for (int pass = 0; pass < 2; pass++) {  // host-decoded images first, GPU-decoded ones behind the H2D boundary
         if (pass == 1) {
             h2d_bytes_ = coef_offset_ + coef_total;
@@ -282,7 +302,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
                 coef_total += (size_t)im.frame.comp[c].blocks_w * im.frame.comp[c].blocks_h * 128;
             }
             if (im.gpu_entropy) {
-                im.stream_offset += streams_base;
+                im.raw_offset += streams_base;
                 im.tables_offset += tables_base;
             }
         }
@@ -306,7 +326,9 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     work_first_block_ = align_up(total_subseq_ * 8, 256);
     work_changed_ = work_first_block_ + align_up(total_subseq_ * 4, 256);
     work_dc_diff_ = work_changed_ + 256;
-    if (ng && (st = work_.reserve(work_dc_diff_ + huff_blocks_total * 2 + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    work_drops_ = align_up(work_dc_diff_ + huff_blocks_total * 2, 256);
+    work_streams_ = align_up(work_drops_ + huff_chunks_total * 4, 256);
+    if (ng && (st = work_.reserve(work_streams_ + huff_stream_total + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     huff_images_.assign(ng, HuffImage());
 
     for (int i = 0; i < n; i++) {
@@ -328,9 +350,13 @@ void DecodeBatch::entropy_stage(int i)
     PlannedImage& im = images_[i];
     if (im.status != HIPJPEG_STATUS_SUCCESS) return;
     if (im.gpu_entropy) {
-        // host part of the GPU entropy path: drop the byte stuffing, expand the Huffman tables, describe the scan
+        // host part of the GPU entropy path: stage the scan's bytes as they are (the device removes the byte stuffing),
+        // expand the Huffman tables, describe the scan
         const ScanHeader& sc = im.frame.scans[0];
-        im.stream_bytes = (uint32_t)destuff_scan(im.data, sc, pinned_.data() + im.stream_offset);
+        im.stream_bytes = (uint32_t)(sc.data_end - sc.data_begin);
+        uint8_t* raw = pinned_.data() + im.raw_offset;
+        memcpy(raw, im.data + sc.data_begin, im.stream_bytes);
+        memset(raw + im.stream_bytes, 0x01, align_up((size_t)im.stream_bytes, 16) + 16 - im.stream_bytes);  // neither FF nor 00
         HuffImage& h = huff_images_[im.huff_index];
         fill_huff_image(im.frame, im.stream_bytes, &h);
         build_gpu_pool(sc, &h, reinterpret_cast<uint16_t*>(pinned_.data() + im.tables_offset));
@@ -416,6 +442,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
 
     // GPU entropy descriptors: batch-wide subsequence numbering, one workgroup per 256 subsequences of an image
     huff_units_.clear();
+    huff_chunk_units_.clear();
     huff_dc_units_.clear();
     huff_list_.clear();
     uint32_t first_subseq = 0;
@@ -427,7 +454,11 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             h.num_subseq = 0;
             continue;
         }
-        h.stream = device_.data() + im.stream_offset;
+        h.stream = work_.data() + work_streams_ + im.stream_offset;
+        h.raw = device_.data() + im.raw_offset;
+        h.raw_bytes = im.stream_bytes;
+        h.first_chunk = im.first_chunk;
+        for (uint32_t c = 0; c * (uint32_t)kDestuffChunk < im.stream_bytes; c++) huff_chunk_units_.push_back(HuffUnit{(uint32_t)g, c});
         h.pool = reinterpret_cast<const uint16_t*>(device_.data() + im.tables_offset);
         h.dc_diff = reinterpret_cast<int16_t*>(work_.data() + work_dc_diff_ + im.dc_diff_offset);
         for (int c = 0; c < im.frame.ncomp; c++) h.coef[c] = reinterpret_cast<int16_t*>(device_.data() + im.coef_offset[c]);
@@ -444,6 +475,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         if (!huff_units_.empty()) memcpy(base + huff_units_offset_, huff_units_.data(), sizeof(HuffUnit) * huff_units_.size());
         if (!huff_dc_units_.empty()) memcpy(base + huff_dc_units_offset_, huff_dc_units_.data(), sizeof(HuffUnit) * huff_dc_units_.size());
         if (!huff_list_.empty()) memcpy(base + huff_list_offset_, huff_list_.data(), sizeof(uint32_t) * huff_list_.size());
+        if (!huff_chunk_units_.empty())
+            memcpy(base + huff_chunk_units_offset_, huff_chunk_units_.data(), sizeof(HuffUnit) * huff_chunk_units_.size());
     }
     finalized_ = true;
 }
@@ -489,6 +522,9 @@ hipjpegStatus_t DecodeBatch::run_gpu_entropy(void* stream)
                launch_huff_dc(dimg, ddc, (int)huff_dc_units_.size(), stream) == 0;
     };
     if (hipMemsetAsync(changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_destuff(dimg, reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(),
+                       reinterpret_cast<uint32_t*>(work_.data() + work_drops_), stream) != 0)
+        return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_huff_sync(dimg, dunits, nunits, states, changed + 1, 1, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_huff_sync(dimg, dunits, nunits, states, changed, 0, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (!write_passes()) return HIPJPEG_STATUS_HIP_ERROR;

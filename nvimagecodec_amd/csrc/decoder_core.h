@@ -13,6 +13,7 @@
 #include "device_layout.h"
 #include "gpu_huffman.h"
 #include "jpeg_syntax.h"
+#include "thread_pool.h"
 
 namespace hipjpeg {
 
@@ -62,6 +63,9 @@ struct PlannedImage {
     int huff_index = -1;          // index into the HuffImage array
     size_t stream_offset = 0;     // staging offsets of the destuffed stream and the 8 expanded tables
     size_t tables_offset = 0;
+    size_t pool_words = 0;      // lookup-table entries of the scan (GPU entropy path)
+    size_t raw_offset = 0;      // staged copy of the scan's entropy-coded bytes
+    uint32_t first_chunk = 0;   // first destuff chunk (batch-wide numbering)
     size_t dc_diff_offset = 0;  // bytes into the DC-difference scratch
     uint32_t stream_bytes = 0;
 };
@@ -75,7 +79,7 @@ public:
     // `formats` (optional) gives one output format per image; otherwise `format` applies to all.
     hipjpegStatus_t plan(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
                          hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
-                         const hipjpegOutputFormat_t* formats = nullptr);
+                         const hipjpegOutputFormat_t* formats = nullptr, ForkJoinPool* pool = nullptr);
     // Phase 1: entropy-decode image i into the pinned staging area.  Thread-safe for distinct i.
     void entropy_stage(int i);
     // Phase 1b: after every entropy_stage returned: final per-image flags, drop failed images from the unit tables.
@@ -113,7 +117,9 @@ private:
     std::vector<int> huff_to_image_;
     size_t huff_desc_offset_ = 0, huff_units_offset_ = 0, huff_dc_units_offset_ = 0, huff_list_offset_ = 0, h2d_bytes_ = 0;
     size_t gpu_coef_begin_ = 0, gpu_coef_bytes_ = 0, total_subseq_ = 0, max_huff_units_ = 0, max_pool_words_ = 0;
-    size_t work_first_block_ = 0, work_changed_ = 0, work_dc_diff_ = 0;  // offsets into work_
+    size_t work_first_block_ = 0, work_changed_ = 0, work_dc_diff_ = 0, work_drops_ = 0, work_streams_ = 0;
+    size_t huff_chunk_units_offset_ = 0;
+    std::vector<HuffUnit> huff_chunk_units_;  // offsets into work_
     uint64_t stream_bytes_total_ = 0;
     int last_sync_launches_ = 0;
     bool entropy_done_ = false;

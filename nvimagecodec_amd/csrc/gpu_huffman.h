@@ -12,6 +12,10 @@ struct HuffUnit {
     uint32_t first;
 };
 
+// Byte-stuffing removal (count + compact): chunk_units[i] = {image, chunk index inside the image}; drops = one uint32 per chunk.
+// Writes HuffImage::stream contents and total_bits / num_subseq / stream_words.
+int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, void* stream);
+
 // pool_bytes = dynamic LDS for the lookup tables: 2 * the largest HuffImage::pool_words of the batch
 int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned int* changed, int first_pass,
                      unsigned pool_bytes, void* stream);

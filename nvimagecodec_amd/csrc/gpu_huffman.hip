@@ -120,6 +120,168 @@ __device__ __forceinline__ DevEnv make_env(WgShared& sh, HJ_LDS uint16_t* pool, 
     return env;
 }
 
+// ---- byte-stuffing removal ------------------------------------------------------------------------------------------
+// The file's entropy-coded segment escapes every 0xFF data byte as FF 00.  Two kernels turn it into the plain bitstream the
+// decoders read: the first counts the stuffed bytes of every 16 KB chunk, the second compacts each chunk to its final
+// position (chunk offset minus the stuffed bytes before it) through LDS.  Streams with anything else behind an FF (restart
+// markers, fill bytes) never get here (gpu_entropy_eligible()).
+
+// 0x80 in every byte of x (little-endian dword) that is 0x00 and whose predecessor byte is 0xFF; prev = the byte before x.
+__device__ __forceinline__ uint32_t stuffed_mask(uint32_t x, uint32_t prev)
+{
+    const uint32_t np = ~((x << 8) | prev);  // byte i = ~predecessor of x's byte i: zero where the predecessor is 0xFF
+    const uint32_t zero_x = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+    const uint32_t zero_np = ~(((np & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | np | 0x7F7F7F7Fu);
+    return zero_x & zero_np;
+}
+
+// stuffed-byte masks of the 64 bytes at p (16-byte aligned); returns the count
+__device__ __forceinline__ uint32_t lane_masks(const uint8_t* p, bool has_prev, uint32_t m[16], uint32_t x[16])
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint32_t prev = has_prev ? p[-1] : 0u;
+    uint32_t n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint4 v = q[i];
+        x[4 * i + 0] = v.x;
+        x[4 * i + 1] = v.y;
+        x[4 * i + 2] = v.z;
+        x[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        m[i] = stuffed_mask(x[i], prev);
+        prev = x[i] >> 24;
+        n += __popc(m[i]);
+    }
+    return n;
+}
+
+__device__ __forceinline__ uint32_t wg_sum(uint32_t v, uint32_t* scratch /*[4]*/)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+    return total;
+}
+
+// unit.first = chunk index inside the image; drops[im.first_chunk + chunk] = stuffed bytes in the chunk
+__global__ __launch_bounds__(kThreads) void destuff_count_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+                                                                 uint32_t* __restrict__ drops)
+{
+    __shared__ uint32_t scratch[4];
+    const HuffUnit u = units[blockIdx.x];
+    const HuffImage& im = images[u.image];
+    const uint32_t off = u.first * kDestuffChunk + threadIdx.x * 64;
+    uint32_t n = 0;
+    if (off < im.raw_bytes) {  // the raw copy is padded to 16 bytes with a neutral value; whole 16-byte pieces are readable
+        uint32_t m[16], x[16];
+        const uint32_t pieces = min(4u, (im.raw_bytes - off + 15) / 16);
+        if (pieces == 4) {
+            n = lane_masks(im.raw + off, off > 0, m, x);
+        } else {
+            uint32_t prev = off > 0 ? im.raw[off - 1] : 0u;
+            for (uint32_t i = 0; i < pieces * 4; i++) {
+                const uint32_t w = reinterpret_cast<const uint32_t*>(im.raw + off)[i];
+                n += __popc(stuffed_mask(w, prev));
+                prev = w >> 24;
+            }
+        }
+    }
+    const uint32_t total = wg_sum(n, scratch);
+    if (threadIdx.x == 0) drops[im.first_chunk + u.first] = total;
+}
+
+__global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+                                                                   const uint32_t* __restrict__ drops)
+{
+    __shared__ uint32_t scratch[4];
+    __shared__ uint32_t wave_base[4];
+    __shared__ uint32_t out_words[kDestuffChunk / 4 + 2];
+    HJ_LDS uint8_t* out = (HJ_LDS uint8_t*)out_words;
+    const HuffUnit u = units[blockIdx.x];
+    HuffImage& im = images[u.image];
+    const int t = threadIdx.x;
+    const uint32_t raw_bytes = im.raw_bytes;
+    // stuffed bytes in the chunks before this one
+    uint32_t before = 0;
+    for (uint32_t c = t; c < u.first; c += kThreads) before += drops[im.first_chunk + c];
+    before = wg_sum(before, scratch);
+    const uint32_t chunk_begin = u.first * kDestuffChunk;
+    const uint32_t chunk_len = min((uint32_t)kDestuffChunk, raw_bytes - chunk_begin);
+    const uint32_t gout = chunk_begin - before;  // destination offset of the chunk's first kept byte
+    const uint32_t a = gout & 3;                 // the LDS image shares the destination's misalignment
+
+    const uint32_t off = chunk_begin + t * 64;
+    uint32_t m[16], x[16];
+    uint32_t n = 0, len = 0;
+    if (off < raw_bytes) {
+        len = min(64u, raw_bytes - off);
+        const uint32_t pieces = (len + 15) / 16;
+        uint32_t prev = off > 0 ? im.raw[off - 1] : 0u;
+        for (uint32_t i = 0; i < 16; i++) {
+            x[i] = i < pieces * 4 ? reinterpret_cast<const uint32_t*>(im.raw + off)[i] : 0x01010101u;
+            m[i] = stuffed_mask(x[i], prev);
+            prev = x[i] >> 24;
+            n += __popc(m[i]);
+        }
+    }
+    // exclusive scan of the per-lane counts: inside the wave by shuffles, across the four waves through LDS
+    uint32_t incl = n;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d);
+        if ((t & 63) >= d) incl += v;
+    }
+    if ((t & 63) == 63) wave_base[t >> 6] = incl;
+    __syncthreads();
+    uint32_t excl = incl - n;
+    for (int w = 0; w < (t >> 6); w++) excl += wave_base[w];
+    const uint32_t chunk_drops = wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+    // kept bytes of this lane -> LDS
+    if (len) {
+        uint32_t o = a + t * 64 - excl;
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t w = x[i], mask = m[i];
+            if (i * 4 + 4 <= len && mask == 0) {
+                out[o] = (uint8_t)w;
+                out[o + 1] = (uint8_t)(w >> 8);
+                out[o + 2] = (uint8_t)(w >> 16);
+                out[o + 3] = (uint8_t)(w >> 24);
+                o += 4;
+            } else {
+                for (uint32_t b = 0; b < 4; b++)
+                    if (i * 4 + b < len && !((mask >> (8 * b + 7)) & 1)) out[o++] = (uint8_t)(w >> (8 * b));
+            }
+        }
+    }
+    __syncthreads();
+    // LDS -> destination: whole dwords in the middle, single bytes at the ragged ends (neighbouring chunks share those dwords)
+    const uint32_t n_out = chunk_len - chunk_drops;
+    uint8_t* dst = const_cast<uint8_t*>(im.stream) + (gout - a);  // 4-byte aligned
+    const uint32_t first_full = a ? 1 : 0, end_full = (a + n_out) / 4;
+    for (uint32_t d = first_full + t; d < end_full; d += kThreads) reinterpret_cast<uint32_t*>(dst)[d] = out_words[d];
+    if (t < 4) {
+        if (a && (uint32_t)t >= a && (uint32_t)t < a + n_out) dst[t] = out[t];  // head
+        const uint32_t tail = max(end_full, first_full) * 4 + t;
+        if (tail >= a && tail < a + n_out && tail >= 4 * first_full) dst[tail] = out[tail];
+    }
+    // the last chunk knows the destuffed length: publish it and lay down the 0xFF slack behind the data
+    if (chunk_begin + chunk_len == raw_bytes) {
+        const uint32_t total = raw_bytes - before - chunk_drops;
+        const uint32_t padded = ((total + 3) & ~3u) + kStreamSlackBytes;
+        uint8_t* s = const_cast<uint8_t*>(im.stream);
+        if (total + t < padded) s[total + t] = 0xFF;
+        if (t == 0) {
+            im.total_bits = total * 8;
+            im.num_subseq = (total * 8 + kSubseqBits - 1) / kSubseqBits;
+            im.stream_words = padded / 4;
+        }
+    }
+}
+
 // states[]: one 8-byte record per subsequence (batch-wide indexing through HuffImage::first_subseq).
 // changed[0] += 1 for every workgroup whose outgoing state (end state of its last subsequence) differs from the published one.
 __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
@@ -303,6 +465,14 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
 }
 
 }  // namespace
+
+int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, void* stream)
+{
+    if (nchunks <= 0) return 0;
+    hipLaunchKernelGGL(destuff_count_kernel, dim3(nchunks), dim3(kThreads), 0, (hipStream_t)stream, images, chunk_units, drops);
+    hipLaunchKernelGGL(destuff_compact_kernel, dim3(nchunks), dim3(kThreads), 0, (hipStream_t)stream, images, chunk_units, drops);
+    return (int)hipGetLastError();
+}
 
 int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned int* changed, int first_pass,
                      unsigned pool_bytes, void* stream)

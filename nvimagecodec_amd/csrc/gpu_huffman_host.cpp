@@ -9,7 +9,7 @@ bool gpu_entropy_eligible(const FrameInfo& f)
 {
     if (f.progressive() || f.scans.size() != 1) return false;
     const ScanHeader& sc = f.scans[0];
-    if (sc.ncomp != f.ncomp || sc.restart_interval != 0) return false;
+    if (sc.ncomp != f.ncomp || sc.restart_interval != 0 || !sc.plain_stuffing) return false;
     int bpm = 0;
     for (int i = 0; i < sc.ncomp; i++) {
         if (sc.comp_index[i] != i) return false;  // keep the MCU layout simple: components in frame order

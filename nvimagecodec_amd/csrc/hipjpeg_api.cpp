@@ -13,6 +13,10 @@
 #include "gpu_huffman_host.h"
 #include "thread_pool.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 using namespace hipjpeg;
 
 struct hipjpegHandle {
@@ -155,10 +159,20 @@ hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const uint8_t* co
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     handle->current ^= 1;
     DecodeBatch& b = handle->cur();
-    hipjpegStatus_t st = b.plan(data, lengths, batch_size, outputs, format, flags, statuses);
+    static const bool timing = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;  // debug aid: host-stage phase times on stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    hipjpegStatus_t st = b.plan(data, lengths, batch_size, outputs, format, flags, statuses, nullptr, handle->pool.get());
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
+    const auto t1 = std::chrono::steady_clock::now();
     handle->pool->parallel_for(batch_size, [&](int i, int) { b.entropy_stage(i); });
+    const auto t2 = std::chrono::steady_clock::now();
     b.finalize(statuses);
+    if (timing) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[hipjpeg] host stage: plan %.2f ms, entropy/staging %.2f ms, finalize %.2f ms (%d threads)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3),
+                handle->pool->num_threads());
+    }
     return HIPJPEG_STATUS_SUCCESS;
 }
 

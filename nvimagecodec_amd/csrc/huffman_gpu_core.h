@@ -36,6 +36,7 @@ constexpr int kSubseqWords = kSubseqBits / 32;
 constexpr int kHuffFastBits = 10;      // first-level lookup width
 constexpr int kHuffSubBits = 16 - kHuffFastBits;
 constexpr int kStreamSlackBytes = 32;  // readable bytes after the last real byte of a destuffed stream
+constexpr int kDestuffChunk = 16384;   // raw bytes one workgroup of the destuff kernels handles
 constexpr int kMaxPoolWords = 12288;   // uint16 entries of lookup tables per image the kernels accept (24 KB of LDS)
 
 // Lookup-table entry (uint16): bits 0-7 symbol, bits 8-12 code length, bit 14 "no such code", bit 15 "longer than
@@ -56,6 +57,7 @@ struct HuffK {
 // Per-image description for the entropy kernels.
 struct alignas(16) HuffImage {
     const uint8_t* stream;   // destuffed entropy-coded bytes, 4-byte aligned, `stream_words` 32-bit words readable
+                             // (written by the destuff kernels together with total_bits, num_subseq, stream_words)
     const uint16_t* pool;    // lookup tables (pool_words entries)
     int16_t* coef[4];        // component coefficient blocks (device layout)
     int16_t* dc_diff;        // total_blocks DC differences in scan order (written by the write pass)
@@ -66,7 +68,9 @@ struct alignas(16) HuffImage {
     uint32_t mcus_x, mcus_y, blocks_per_mcu, ncomp;
     uint32_t pool_words, stream_words;
     uint32_t status;         // written by the kernels: 0 ok, 1 = invalid code inside the real data, 2 = block count mismatch
-    uint32_t pad0;
+    uint32_t first_chunk;    // index of this image's first kDestuffChunk-byte chunk in the batch-wide drop-count array
+    const uint8_t* raw;      // the scan's entropy-coded bytes as they are in the file (byte-stuffed), padded to 16 bytes
+    uint32_t raw_bytes, pad0;
     HuffK k[10];
     uint32_t blocks_w[4];
     uint8_t comp_h[4], comp_v[4], comp_k0[4], pad1[4];  // comp_k0 = first position k of the component inside the MCU

@@ -14,17 +14,27 @@ namespace {
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
 // Finds the end of an entropy-coded segment: first 0xFF followed by something other than 0x00, 0xFF or RSTn.
-size_t find_scan_end(const uint8_t* data, size_t pos, size_t size)
+// *plain = false when the segment holds anything but data bytes and FF 00 pairs (RSTn markers, fill bytes, a lone FF at the
+// end of the input).
+size_t find_scan_end(const uint8_t* data, size_t pos, size_t size, bool* plain)
 {
+    *plain = true;
     while (pos < size) {
         const uint8_t* ff = static_cast<const uint8_t*>(memchr(data + pos, 0xFF, size - pos));
         if (!ff) return size;
         size_t i = ff - data;
-        if (i + 1 >= size) return size;
+        if (i + 1 >= size) {
+            *plain = false;
+            return size;
+        }
         uint8_t m = data[i + 1];
-        if (m == 0x00 || (m >= 0xD0 && m <= 0xD7)) {
+        if (m == 0x00) {
+            pos = i + 2;
+        } else if (m >= 0xD0 && m <= 0xD7) {
+            *plain = false;
             pos = i + 2;
         } else if (m == 0xFF) {
+            *plain = false;
             pos = i + 1;  // fill byte; re-examine the next FF
         } else {
             return i;
@@ -236,7 +246,7 @@ ParseStatus parse_jpeg(const uint8_t* data, size_t size, FrameInfo* f, bool head
             }
             sc.restart_interval = restart_interval;
             sc.data_begin = pos + L;
-            sc.data_end = find_scan_end(data, sc.data_begin, size);
+            sc.data_end = find_scan_end(data, sc.data_begin, size, &sc.plain_stuffing);
             f->scans.push_back(sc);
             pos = sc.data_end;
             continue;

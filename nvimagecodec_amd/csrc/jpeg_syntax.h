@@ -41,6 +41,7 @@ struct ScanHeader {
     // Tables in force when this scan starts (DHT/DQT/DRI may be redefined between scans)
     HuffSpec dc[4], ac[4];
     int restart_interval = 0;
+    bool plain_stuffing = true;  // the segment consists of data bytes and FF 00 pairs only (no RSTn, no fill bytes)
 };
 
 struct FrameInfo {

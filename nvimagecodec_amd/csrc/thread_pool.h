@@ -6,17 +6,41 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <sched.h>
+
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
 namespace hipjpeg {
 
+// CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (containers often see every core
+// of the host in hardware_concurrency() while being allowed a fraction of them).
+inline int usable_cpus()
+{
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0) {
+            quota = atoll(q);
+            const int cap = (int)((quota + period - 1) / period);
+            if (cap > 0 && cap < n) n = cap;
+        }
+        fclose(f);
+    }
+    return n > 0 ? n : 1;
+}
+
 class ForkJoinPool {
 public:
     explicit ForkJoinPool(int num_threads)
     {
-        if (num_threads <= 0) num_threads = (int)std::thread::hardware_concurrency();
-        if (num_threads <= 0) num_threads = 1;
+        if (num_threads <= 0) num_threads = usable_cpus();
         nthreads_ = num_threads;
         // the calling thread participates, so spawn nthreads-1 helpers
         for (int t = 1; t < nthreads_; t++) workers_.emplace_back([this, t] { worker_loop(t); });
