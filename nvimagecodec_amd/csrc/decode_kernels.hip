@@ -129,11 +129,16 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // Coalesced HBM -> LDS staging of the 32 blocks a wave owns (4 KB contiguous), then each lane reads back the four
 // 16-byte column chunks of its half block: columns 4p .. 4p+3 of block lane>>1.
-__device__ __forceinline__ void fetch_half_block(const int16_t* __restrict__ comp_coef, int wave_first_block, int block_limit, char* lds_wave,
-                                                 int lane, u32x4 (&cols)[4])
+// The DC coefficient comes from cd.dc (see DecodeComponent): lane 0 of each pair patches it into column 0, row 0.
+__device__ __forceinline__ void fetch_half_block(const DecodeComponent& cd, int wave_first_block, int block_limit, char* lds_wave, int lane,
+                                                 u32x4 (&cols)[4])
 {
+    const int16_t* __restrict__ comp_coef = cd.coef;
     const u32x4* src = reinterpret_cast<const u32x4*>(comp_coef) + (size_t)wave_first_block * 8;
     const int nchunks = min(kBlocksPerWave, block_limit - wave_first_block) * 8;  // valid 16-byte chunks (may be <= 0)
+    const int my_block = wave_first_block + (lane >> 1);
+    unsigned dc = 0;
+    if (my_block < block_limit) dc = (unsigned short)cd.dc[__umul24((unsigned)my_block, cd.dc_stride)];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int g = k * 64 + lane;
@@ -149,6 +154,7 @@ __device__ __forceinline__ void fetch_half_block(const int16_t* __restrict__ com
     const char* mine = lds_wave + (lane >> 1) * kLdsBlockStride + (lane & 1) * 64;
 #pragma unroll
     for (int j = 0; j < 4; j++) cols[j] = *reinterpret_cast<const u32x4*>(mine + j * 16);
+    if (!(lane & 1)) cols[0].x = (cols[0].x & 0xFFFF0000u) | dc;
 }
 
 // Dequantize + column pass of this lane's four columns, exchange with the partner lane, and assemble the row-pass inputs.
@@ -199,7 +205,7 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
     const int bw = cd.blocks_w, nblocks = bw * cd.blocks_h;
     const int wave_first = u.block_base + wave * kBlocksPerWave;
     u32x4 cols[4];
-    fetch_half_block(cd.coef, wave_first, nblocks, lds + wave * kBlocksPerWave * kLdsBlockStride, lane, cols);
+    fetch_half_block(cd, wave_first, nblocks, lds + wave * kBlocksPerWave * kLdsBlockStride, lane, cols);
     const int b = wave_first + (lane >> 1);
     if (b >= nblocks) return;  // whole pairs leave together
     int rows[4][8];
@@ -348,7 +354,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     char* lds_wave = lds + wave * kLdsLumaWaveBytes;
     u32x4 cols[4];
     // the wave's blocks are contiguous in memory up to the end of the block row
-    fetch_half_block(im.comp[0].coef, by * bw + bx0, by < bh ? (by + 1) * bw : 0, lds_wave, lane, cols);
+    fetch_half_block(im.comp[0], by * bw + bx0, by < bh ? (by + 1) * bw : 0, lds_wave, lane, cols);
     const int x0 = bx * 8, y0 = by * 8;
     const int W = im.width, H = im.height;
     const bool valid = bx < bw && by < bh && x0 < W && y0 < H;  // false: pair idles (block is MCU padding or outside the tile)

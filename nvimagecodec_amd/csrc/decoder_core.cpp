@@ -165,7 +165,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
 
     size_t max_units = 0, coef_total = 0, plane_total = 0;
     size_t huff_stream_total = 0, huff_subseq_ub = 0, huff_pool_total = 0, huff_blocks_total = 0, huff_raw_total = 0, huff_chunks_total = 0;
-    max_huff_units_ = 0;
+    max_huff_units_ = max_huff_wunits_ = 0;
     max_pool_words_ = 0;
     std::vector<size_t> plane_off((size_t)n * 4, (size_t)-1);
     coef_bytes_ = output_bytes_ = 0;
@@ -259,13 +259,18 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
             huff_chunks_total += (raw_len + kDestuffChunk - 1) / kDestuffChunk;
             const size_t nsub = (cap * 8 + kSubseqBits - 1) / kSubseqBits;
             huff_subseq_ub += nsub;
-            max_huff_units_ += (nsub + 255) / 256;
+            max_huff_units_ += (nsub + kHuffOwn - 1) / kHuffOwn;
             const size_t pool_words = im.pool_words;
             im.tables_offset = huff_pool_total;  // relative; rebased below
             huff_pool_total += align_up(pool_words * 2, 64);
             max_pool_words_ = std::max(max_pool_words_, pool_words);
             im.dc_diff_offset = huff_blocks_total * 2;
             huff_blocks_total += (f.total_blocks() + 31) & ~(size_t)31;
+            for (int c = 0; c < f.ncomp; c++) {  // DC planes live in the same scratch, behind the differences
+                im.dc_plane_offset[c] = huff_blocks_total * 2;
+                huff_blocks_total += ((size_t)f.comp[c].blocks_w * f.comp[c].blocks_h + 31) & ~(size_t)31;
+            }
+            max_huff_wunits_ += (nsub + kHuffWriteOwn - 1) / kHuffWriteOwn;
         }
         coef_bytes_ += f.total_blocks() * 128;
         if (fmt == kOutPlanarYUV) {
@@ -282,7 +287,8 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     units_offset_ = align_up(desc_offset_ + sizeof(DecodeImage) * (size_t)n, 256);
     huff_desc_offset_ = align_up(units_offset_ + sizeof(WorkUnit) * max_units, 256);
     huff_units_offset_ = align_up(huff_desc_offset_ + sizeof(HuffImage) * ng, 256);
-    huff_dc_units_offset_ = align_up(huff_units_offset_ + sizeof(HuffUnit) * max_huff_units_, 256);
+    huff_wunits_offset_ = align_up(huff_units_offset_ + sizeof(HuffUnit) * max_huff_units_, 256);
+    huff_dc_units_offset_ = align_up(huff_wunits_offset_ + sizeof(HuffUnit) * max_huff_wunits_, 256);
     huff_list_offset_ = align_up(huff_dc_units_offset_ + sizeof(HuffUnit) * ng * 4, 256);
     huff_chunk_units_offset_ = align_up(huff_list_offset_ + sizeof(uint32_t) * ng, 256);
     const size_t tables_base = align_up(huff_chunk_units_offset_ + sizeof(HuffUnit) * huff_chunks_total, 256);
@@ -325,7 +331,8 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     // device-only scratch of the entropy kernels: subsequence states | first block indices | change counters | DC differences
     work_first_block_ = align_up(total_subseq_ * 8, 256);
     work_changed_ = work_first_block_ + align_up(total_subseq_ * 4, 256);
-    work_dc_diff_ = work_changed_ + 256;
+    work_incoming_ = work_changed_ + 256;
+    work_dc_diff_ = align_up(work_incoming_ + max_huff_units_ * 8, 256);
     work_drops_ = align_up(work_dc_diff_ + huff_blocks_total * 2, 256);
     work_streams_ = align_up(work_drops_ + huff_chunks_total * 4, 256);
     if (ng && (st = work_.reserve(work_streams_ + huff_stream_total + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
@@ -337,6 +344,13 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
         for (int c = 0; c < images_[i].frame.ncomp; c++) {
             images_[i].coef_offset[c] += coef_offset_;
             d.comp[c].coef = reinterpret_cast<const int16_t*>(device_.data() + images_[i].coef_offset[c]);
+            if (images_[i].gpu_entropy) {
+                d.comp[c].dc = reinterpret_cast<const int16_t*>(work_.data() + work_dc_diff_ + images_[i].dc_plane_offset[c]);
+                d.comp[c].dc_stride = 1;
+            } else {
+                d.comp[c].dc = d.comp[c].coef;
+                d.comp[c].dc_stride = 64;
+            }
             if (plane_off[(size_t)i * 4 + c] != (size_t)-1) d.comp[c].plane = planes_.data() + plane_off[(size_t)i * 4 + c];
         }
     }
@@ -442,6 +456,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
 
     // GPU entropy descriptors: batch-wide subsequence numbering, one workgroup per 256 subsequences of an image
     huff_units_.clear();
+    huff_wunits_.clear();
     huff_chunk_units_.clear();
     huff_dc_units_.clear();
     huff_list_.clear();
@@ -461,10 +476,12 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         for (uint32_t c = 0; c * (uint32_t)kDestuffChunk < im.stream_bytes; c++) huff_chunk_units_.push_back(HuffUnit{(uint32_t)g, c});
         h.pool = reinterpret_cast<const uint16_t*>(device_.data() + im.tables_offset);
         h.dc_diff = reinterpret_cast<int16_t*>(work_.data() + work_dc_diff_ + im.dc_diff_offset);
+        for (int c = 0; c < im.frame.ncomp; c++) h.dc_plane[c] = reinterpret_cast<int16_t*>(work_.data() + work_dc_diff_ + im.dc_plane_offset[c]);
+        for (uint32_t j = 0; j < h.num_subseq; j += kHuffWriteOwn) huff_wunits_.push_back(HuffUnit{(uint32_t)g, j});
         for (int c = 0; c < im.frame.ncomp; c++) h.coef[c] = reinterpret_cast<int16_t*>(device_.data() + im.coef_offset[c]);
         h.first_subseq = first_subseq;
         first_subseq += h.num_subseq;
-        for (uint32_t j = 0; j < h.num_subseq; j += 256) huff_units_.push_back(HuffUnit{(uint32_t)g, j});
+        for (uint32_t j = 0; j < h.num_subseq; j += kHuffOwn) huff_units_.push_back(HuffUnit{(uint32_t)g, j});
         for (int c = 0; c < im.frame.ncomp; c++) huff_dc_units_.push_back(HuffUnit{(uint32_t)g, (uint32_t)c});
         huff_list_.push_back((uint32_t)g);
         stream_bytes_total_ += im.stream_bytes;
@@ -473,6 +490,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
     if (!huff_images_.empty()) {
         memcpy(base + huff_desc_offset_, huff_images_.data(), sizeof(HuffImage) * huff_images_.size());
         if (!huff_units_.empty()) memcpy(base + huff_units_offset_, huff_units_.data(), sizeof(HuffUnit) * huff_units_.size());
+        if (!huff_wunits_.empty()) memcpy(base + huff_wunits_offset_, huff_wunits_.data(), sizeof(HuffUnit) * huff_wunits_.size());
         if (!huff_dc_units_.empty()) memcpy(base + huff_dc_units_offset_, huff_dc_units_.data(), sizeof(HuffUnit) * huff_dc_units_.size());
         if (!huff_list_.empty()) memcpy(base + huff_list_offset_, huff_list_.data(), sizeof(uint32_t) * huff_list_.size());
         if (!huff_chunk_units_.empty())
@@ -491,8 +509,8 @@ hipjpegStatus_t DecodeBatch::transfer(void* stream)
     return e == hipSuccess ? HIPJPEG_STATUS_SUCCESS : HIPJPEG_STATUS_HIP_ERROR;
 }
 
-// GPU entropy stage: zero the coefficient arena, synchronise the subsequence decoders, scan block counts, write
-// coefficients, integrate DC.  The common case is enqueued without any host round trip: launch 1 leaves every workgroup in
+// GPU entropy stage: remove the byte stuffing, synchronise the subsequence decoders, scan block counts, write the
+// coefficient blocks, integrate DC.  The common case is enqueued without any host round trip: launch 1 leaves every workgroup in
 // a local fixpoint, launch 2 repairs the workgroup boundaries and counts the workgroups whose outgoing state moved; when
 // that count is zero the states are the global fixpoint (no workgroup consumed a state that changed afterwards).  Only if
 // it is not zero -- a correction crossed a whole workgroup -- more launches follow and the write passes are repeated.
@@ -512,32 +530,39 @@ hipjpegStatus_t DecodeBatch::run_gpu_entropy(void* stream)
     unsigned long long* states = reinterpret_cast<unsigned long long*>(work_.data());
     uint32_t* first_block = reinterpret_cast<uint32_t*>(work_.data() + work_first_block_);
     unsigned int* changed = reinterpret_cast<unsigned int*>(work_.data() + work_changed_);
+    unsigned long long* incoming = reinterpret_cast<unsigned long long*>(work_.data() + work_incoming_);
     const unsigned pool_bytes = (unsigned)align_up(max_pool_words_ * 2, 256);
     const int nunits = (int)huff_units_.size();
     unsigned int* host_changed = reinterpret_cast<unsigned int*>(pinned_.data() + h2d_bytes_);  // 256 spare bytes behind the staged data
+    const HuffUnit* dwunits = reinterpret_cast<const HuffUnit*>(device_.data() + huff_wunits_offset_);
     auto write_passes = [&]() -> bool {
-        return hipMemsetAsync(device_.data() + gpu_coef_begin_, 0, gpu_coef_bytes_, s) == hipSuccess &&
-               launch_huff_scan(dimg, dlist, (int)huff_list_.size(), states, first_block, stream) == 0 &&
-               launch_huff_write(dimg, dunits, nunits, states, first_block, pool_bytes, stream) == 0 &&
+        return launch_huff_scan(dimg, dlist, (int)huff_list_.size(), states, first_block, stream) == 0 &&
+               launch_huff_write(dimg, dwunits, (int)huff_wunits_.size(), states, first_block, pool_bytes, stream) == 0 &&
                launch_huff_dc(dimg, ddc, (int)huff_dc_units_.size(), stream) == 0;
     };
     if (hipMemsetAsync(changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_destuff(dimg, reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(),
                        reinterpret_cast<uint32_t*>(work_.data() + work_drops_), stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
-    if (launch_huff_sync(dimg, dunits, nunits, states, changed + 1, 1, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
-    if (launch_huff_sync(dimg, dunits, nunits, states, changed, 0, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_huff_sync(dimg, dunits, nunits, states, incoming, changed, 1, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_huff_sync(dimg, dunits, nunits, states, incoming, changed, 0, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (!write_passes()) return HIPJPEG_STATUS_HIP_ERROR;
-    if (hipMemcpyAsync(host_changed, changed, sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipMemcpyAsync(host_changed, changed, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     HuffImage* himg = reinterpret_cast<HuffImage*>(pinned_.data() + huff_desc_offset_);
     if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     last_sync_launches_ = 2;
+    sync_rounds_total_ = host_changed[2];
+    sync_rounds_max_ = host_changed[3];
+    static const bool debug_stats = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;
+    if (debug_stats)
+        fprintf(stderr, "[hipjpeg] entropy: %d workgroups, launch 1 rounds avg %.2f max %u; launch 2: %u rounds in total, max %u, %u boundary changes\n", nunits,
+                (double)sync_rounds_total_ / nunits, sync_rounds_max_, host_changed[4], host_changed[5], host_changed[0]);
     bool converged = *host_changed == 0;
     if (!converged) {
         for (int pass = 0; pass < 64 && !converged; pass++) {
             if (hipMemsetAsync(changed, 0, sizeof(unsigned int), s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-            if (launch_huff_sync(dimg, dunits, nunits, states, changed, 0, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+            if (launch_huff_sync(dimg, dunits, nunits, states, incoming, changed, 0, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
             if (hipMemcpyAsync(host_changed, changed, sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
             if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
             last_sync_launches_++;
@@ -571,10 +596,14 @@ hipjpegStatus_t DecodeBatch::run_gpu_entropy(void* stream)
             im.status = es == kEntropyTruncated ? HIPJPEG_STATUS_TRUNCATED : HIPJPEG_STATUS_CORRUPT;
             continue;
         }
-        for (int c = 0; c < f.ncomp; c++)
-            if (hipMemcpy(device_.data() + im.coef_offset[c], coef[c], (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 128, hipMemcpyHostToDevice) !=
-                hipSuccess)
+        for (int c = 0; c < f.ncomp; c++) {
+            const size_t nblk = (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+            std::vector<int16_t> dc(nblk);  // the kernels take this image's DC values from its compact DC plane
+            for (size_t b = 0; b < nblk; b++) dc[b] = coef[c][b * 64];
+            if (hipMemcpy(device_.data() + im.coef_offset[c], coef[c], nblk * 128, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(work_.data() + work_dc_diff_ + im.dc_plane_offset[c], dc.data(), nblk * 2, hipMemcpyHostToDevice) != hipSuccess)
                 return HIPJPEG_STATUS_HIP_ERROR;
+        }
     }
     entropy_done_ = true;
     return HIPJPEG_STATUS_SUCCESS;

@@ -39,6 +39,10 @@ struct alignas(16) DecodeComponent {
     uint16_t blocks_w, blocks_h;  // MCU-padded block grid
     uint16_t samp_w, samp_h;      // true component size in samples
     uint16_t h, v;                // sampling factors
+    // Where the DC coefficient of block b is: dc[b * dc_stride].  Host entropy stage: inside the block (dc == coef,
+    // stride 64); GPU entropy stage: a compact plane of DC values (stride 1), position 0 of the blocks holds zero.
+    const int16_t* dc;
+    uint32_t dc_stride, pad0;
     // Quantizers as the kernels consume them: qpair[p][j*8 + r] = q(row r, column 4p+j), with odd rows NEGATED for p == 1
     // (lane 1 of a pair runs its column butterflies with negated odd inputs, which reverses their output order exactly).
     // qpair serves both the 24-bit-multiplier kernels and the exact ones (same values).

@@ -6,7 +6,7 @@
 
 namespace hipjpeg {
 
-// sync/write kernels: `first` = first subsequence (inside the image) of the workgroup; dc kernel: `first` = component index
+// sync/write kernels: `first` = first subsequence (inside the image) the workgroup owns (it owns kHuffOwn of them); dc kernel: `first` = component index
 struct HuffUnit {
     uint32_t image;  // index into HuffImage[]
     uint32_t first;
@@ -17,8 +17,9 @@ struct HuffUnit {
 int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, void* stream);
 
 // pool_bytes = dynamic LDS for the lookup tables: 2 * the largest HuffImage::pool_words of the batch
-int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned int* changed, int first_pass,
-                     unsigned pool_bytes, void* stream);
+// units[i].first = first owned subsequence of workgroup i, a multiple of kHuffOwn; incoming = one uint64 per unit
+int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
+                     unsigned int* changed, int first_pass, unsigned pool_bytes, void* stream);
 int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages, const unsigned long long* states, uint32_t* first_block, void* stream);
 int launch_huff_write(HuffImage* images, const HuffUnit* units, int nunits, const unsigned long long* states, const uint32_t* first_block,
                       unsigned pool_bytes, void* stream);

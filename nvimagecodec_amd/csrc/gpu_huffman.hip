@@ -28,9 +28,12 @@ namespace hipjpeg {
 namespace {
 
 constexpr int kThreads = 256;
+
 constexpr int kRowWords = kSubseqWords + 1;
 
 #define HJ_LDS __attribute__((address_space(3)))
+#define HJ_GLOBAL __attribute__((address_space(1)))
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // plain vector type: usable behind address-space pointers
 
 struct KSlot {
     int16_t* base;  // coef[comp] + blk0 * 64
@@ -39,85 +42,144 @@ struct KSlot {
 
 struct WgShared {
     uint32_t stream[kThreads * kRowWords];
-    unsigned long long end[kThreads + 1];  // [0] = state entering the workgroup, [t+1] = end state of lane t
-    KSlot kslot[10];
+    unsigned long long end[kThreads];  // end state of lane t's subsequence ([0] = halo = state entering the workgroup)
     uint32_t tsel[10];
-    uint32_t zz[16];  // zigzag permutation, 4 entries per word
+    uint32_t queue[kThreads];
+    uint32_t wave_count[4];
 };
 
-// LDS accessors for decode_subsequence; one instance per lane.
+// LDS accessors for decode_subsequence; one instance per (lane, row).
 struct DevEnv {
-    const HJ_LDS uint32_t* row;     // this lane's stream row
-    const HJ_LDS uint16_t* pool;
-    const HJ_LDS uint32_t* tsel;
-    const HJ_LDS KSlot* kslot;
-    const HJ_LDS uint8_t* zz;
-    uint32_t row_bit0;              // bit position of the row's first bit
+    uint32_t row_bias;   // LDS byte address of the row's first word minus 4 * (index of that word in the image)
+    uint32_t pool;       // LDS byte address of the lookup tables
+    const HJ_LDS uint32_t* tsel;  // per MCU position: BYTE offsets of the DC / AC first-level tables, packed lo/hi
     __device__ __forceinline__ uint32_t window(uint32_t pos) const
     {
-        const uint32_t q = pos - row_bit0;
-        const HJ_LDS uint32_t* p = row + (q >> 5);
-        const unsigned long long two = ((unsigned long long)p[0] << 32) | p[1];
-        return (uint32_t)(two >> (32 - (q & 31)));
+        const HJ_LDS uint32_t* p = (const HJ_LDS uint32_t*)(uintptr_t)(row_bias + ((pos >> 5) << 2));
+        const uint32_t w0 = p[0], w1 = p[1], sh = pos & 31;
+        return (w0 << sh) | ((w1 >> 1) >> (sh ^ 31));  // no special case for sh == 0, no 64-bit shift
     }
-    __device__ __forceinline__ uint32_t entry(uint32_t i) const { return pool[i]; }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
-    __device__ __forceinline__ int16_t* block_ptr(int k, uint32_t mx, uint32_t my) const
+    __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
     {
-        const HJ_LDS KSlot* s = kslot + k;
-        int16_t* base = s->base;
-        const uint32_t sy = s->stride_y, sx = s->stride_x;
-        return base + (size_t)(my * sy + mx * sx) * 64;
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + t + ((w >> (31 - kHuffFastBits)) & ((2u << kHuffFastBits) - 2)));
     }
-    __device__ __forceinline__ int zigzag(int z) const { return zz[z]; }
+    __device__ __forceinline__ uint32_t lookup2(uint32_t e, uint32_t w) const
+    {
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0xFFE0u) << 2) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
+    }
 };
 
-// Cooperative staging of the workgroup's slice of the image: stream rows, lookup tables, per-position constants.
-__device__ __forceinline__ void stage_workgroup(WgShared& sh, HJ_LDS uint16_t* pool, const HuffImage& im, uint32_t first_subseq, bool with_addresses)
+// Cooperative staging of stream rows: row r = subsequence first_row + r of the image (first_row may be -1: that row is
+// filled with ones).  Every row holds its 32 words plus a copy of the successor's first word.  16-byte global loads, all of
+// a lane's loads in flight together.
+template <int THREADS, int ROWS>
+__device__ __forceinline__ void stage_rows(uint32_t* lds_stream, const HuffImage& im, int first_row)
 {
     const int t = threadIdx.x;
-    const uint32_t* g = reinterpret_cast<const uint32_t*>(im.stream);
-    const uint32_t nwords = im.stream_words;
-    const uint32_t w0 = first_subseq * kSubseqWords;
-    for (uint32_t d = t; d <= (uint32_t)kThreads * kSubseqWords; d += kThreads) {
-        const uint32_t gd = w0 + d;
-        const uint32_t w = gd < nwords ? __builtin_bswap32(g[gd]) : 0xFFFFFFFFu;
-        const uint32_t row = d >> 5, col = d & 31;
-        if (row < (uint32_t)kThreads) sh.stream[row * kRowWords + col] = w;
-        if (col == 0 && row > 0) sh.stream[(row - 1) * kRowWords + kSubseqWords] = w;
+    const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
+    const int nwords = (int)im.stream_words;
+    const int w0 = first_row * kSubseqWords;
+    constexpr int kGroups = ROWS * kSubseqWords / 4;  // 16-byte groups
+    constexpr int kIters = (kGroups + THREADS - 1) / THREADS;
+    u32x4 v[kIters];
+#pragma unroll
+    for (int i = 0; i < kIters; i++) {
+        const int gd = w0 + (i * THREADS + t) * 4;
+        // streams are allocated in whole 64-byte units: a 16-byte group that starts inside the stream is readable.  The
+        // load itself is unconditional (clamped address) so that all of them are in flight together.
+        const int gc = min(max(gd, 0), (nwords - 1) & ~3);
+        const u32x4 x = *(const HJ_GLOBAL u32x4*)(g + gc);
+        v[i] = (gd >= 0 && gd < nwords) ? x : u32x4{~0u, ~0u, ~0u, ~0u};
     }
-    const uint32_t* gp = reinterpret_cast<const uint32_t*>(im.pool);
-    HJ_LDS uint32_t* lp = reinterpret_cast<HJ_LDS uint32_t*>(pool);
-    const uint32_t npool = im.pool_words >> 1;  // pool_words is a multiple of 64
-    for (uint32_t i = t; i < npool; i += kThreads) lp[i] = gp[i];
+#pragma unroll
+    for (int i = 0; i < kIters; i++) {
+        if (i * THREADS + t < kGroups) {
+            const uint32_t d = (uint32_t)(i * THREADS + t) * 4;
+            const uint32_t row = d >> 5, col = d & 31;
+            HJ_LDS uint32_t* dst = (HJ_LDS uint32_t*)&lds_stream[row * kRowWords + col];
+            const uint32_t a = __builtin_bswap32(v[i].x);
+            dst[0] = a;
+            dst[1] = __builtin_bswap32(v[i].y);
+            dst[2] = __builtin_bswap32(v[i].z);
+            dst[3] = __builtin_bswap32(v[i].w);
+            if (col == 0 && row > 0) lds_stream[(row - 1) * kRowWords + kSubseqWords] = a;  // the predecessor row's 33rd word
+        }
+    }
+    if (t == 0) {
+        const int gd = w0 + ROWS * kSubseqWords;
+        lds_stream[(ROWS - 1) * kRowWords + kSubseqWords] = (gd >= 0 && gd < nwords) ? __builtin_bswap32(g[gd]) : ~0u;
+    }
+}
+
+// lookup tables -> LDS
+template <int THREADS>
+__device__ __forceinline__ void stage_pool(HJ_LDS uint16_t* pool, const HuffImage& im)
+{
+    const HJ_GLOBAL u32x4* gp = (const HJ_GLOBAL u32x4*)im.pool;
+    const uint32_t npool = im.pool_words >> 3;  // pool_words is a multiple of 64
+    for (uint32_t i = threadIdx.x; i < npool; i += THREADS) {
+        const u32x4 x = gp[i];
+        HJ_LDS uint32_t* lp = reinterpret_cast<HJ_LDS uint32_t*>(pool) + i * 4;
+        lp[0] = x.x;
+        lp[1] = x.y;
+        lp[2] = x.z;
+        lp[3] = x.w;
+    }
+}
+
+// per-MCU-position constants and the zigzag permutation -> LDS (needs >= 80 lanes)
+__device__ __forceinline__ void stage_constants(uint32_t* tsel, KSlot* kslot, uint32_t* zzw, const HuffImage& im, bool with_addresses)
+{
+    const int t = threadIdx.x;
     if (t < 10) {
         const HuffK hk = im.k[t];
-        sh.tsel[t] = (uint32_t)hk.tdc | ((uint32_t)hk.tac << 16);
+        tsel[t] = ((uint32_t)hk.tdc * 2) | ((uint32_t)hk.tac * 2 << 16);  // byte offsets (<= 2 * kMaxPoolWords < 65536)
         if (with_addresses) {
             KSlot s;
             s.base = im.coef[hk.comp & 3] + (size_t)hk.blk0 * 64;
             s.stride_y = hk.stride_y;
             s.stride_x = hk.stride_x;
-            sh.kslot[t] = s;
+            kslot[t] = s;
         }
     }
     if (t >= 64 && t < 80) {
         constexpr uint8_t zz[64] = HJ_ZIGZAG_DEVICE_TABLE;
         const int i = (t - 64) * 4;
-        sh.zz[t - 64] = (uint32_t)zz[i] | ((uint32_t)zz[i + 1] << 8) | ((uint32_t)zz[i + 2] << 16) | ((uint32_t)zz[i + 3] << 24);
+        zzw[t - 64] = (uint32_t)zz[i] | ((uint32_t)zz[i + 1] << 8) | ((uint32_t)zz[i + 2] << 16) | ((uint32_t)zz[i + 3] << 24);
     }
 }
 
-__device__ __forceinline__ DevEnv make_env(WgShared& sh, HJ_LDS uint16_t* pool, uint32_t j)
+// environment for decoding the subsequence in LDS row `r` (image subsequence index first - 1 + r)
+__device__ __forceinline__ DevEnv make_env(WgShared& sh, HJ_LDS uint16_t* pool, uint32_t first, uint32_t r)
 {
     DevEnv env;
-    env.row = (const HJ_LDS uint32_t*)&sh.stream[threadIdx.x * kRowWords];
-    env.pool = pool;
+    env.row_bias = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&sh.stream[r * kRowWords] - (first - 1 + r) * (kSubseqWords * 4);
+    env.pool = (uint32_t)(uintptr_t)pool;
     env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
-    env.kslot = (const HJ_LDS KSlot*)sh.kslot;
-    env.zz = (const HJ_LDS uint8_t*)sh.zz;
-    env.row_bit0 = j * kSubseqBits;
     return env;
+}
+
+// Packs the lanes with has == true to the front: returns how many there are; *task = value of the t-th of them for the
+// lanes t below that count, -1 for the others.  Contains barriers: call from uniform control flow.
+__device__ __forceinline__ int compact_tasks(WgShared& sh, bool has, int value, int* task)
+{
+    const int t = threadIdx.x;
+    const unsigned long long mask = __ballot(has);
+    const int below = __popcll(mask & ((1ull << (t & 63)) - 1));
+    if ((t & 63) == 0) sh.wave_count[t >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    int base = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int c = (int)sh.wave_count[w];
+        if (w < (t >> 6)) base += c;
+        n += c;
+    }
+    if (has) sh.queue[base + below] = (uint32_t)value;
+    __syncthreads();
+    *task = t < n ? (int)sh.queue[t] : -1;
+    return n;
 }
 
 // ---- byte-stuffing removal ------------------------------------------------------------------------------------------
@@ -283,10 +345,20 @@ __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __
 }
 
 // states[]: one 8-byte record per subsequence (batch-wide indexing through HuffImage::first_subseq).
-// changed[0] += 1 for every workgroup whose outgoing state (end state of its last subsequence) differs from the published one.
+// incoming[]: per workgroup, the state it assumed to enter with the last time it ran.
+// counters[0] += 1 for every workgroup whose outgoing state (end state of its last subsequence) differs from the published
+// one (counters[1] in the first pass, where every state is new); counters[2..5] = statistics.
+//
+// first_pass: every lane decodes its subsequence from the assumed state "a block of MCU position 0 starts at the boundary";
+// lane 0 does so for the LAST subsequence of the predecessor workgroup (the halo), whose end state is the workgroup's guess
+// of the state it is entered with.  Then corrections ripple: a subsequence whose predecessor's end state differs from the
+// one it was decoded from is decoded again.  Every round packs the subsequences to redo into the lowest lanes, so that the
+// long tail of rounds with a handful of corrections occupies one wave instead of four.
+// later passes: a workgroup whose incoming state still equals its guess has nothing to do and leaves before staging
+// anything; otherwise the ripple starts from its first subsequence.
 __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
-                                                             unsigned long long* __restrict__ states, unsigned int* __restrict__ changed,
-                                                             int first_pass)
+                                                             unsigned long long* __restrict__ states, unsigned long long* __restrict__ incoming,
+                                                             unsigned int* __restrict__ counters, int first_pass)
 {
     __shared__ WgShared sh;
     extern __shared__ uint16_t dyn_pool[];
@@ -296,57 +368,67 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
     const HuffGeom geom = make_geom(im);
     const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
     if (u.first >= nsub) return;  // uniform: the stream turned out shorter than planned
-    stage_workgroup(sh, pool, im, u.first, false);
-    const int t = threadIdx.x;
-    const uint32_t j = u.first + t;  // subsequence index inside the image
-    const bool active = j < nsub;
-    const bool last = j == min(nsub, u.first + kThreads) - 1;
     unsigned long long* gstate = states + im.first_subseq;
-    const DevEnv env = make_env(sh, pool, j);
-
-    // the state a lane assumes in pass 0: a block of the first MCU position starts exactly at the subsequence boundary
-    const unsigned long long assumed = (unsigned long long)j * kSubseqBits;
-    unsigned long long old_global = 0, mine = 0, last_start = assumed;
-    if (t == 0) sh.end[0] = (first_pass || u.first == 0) ? assumed : __hip_atomic_load(&gstate[u.first - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kSyncMask;
-    __syncthreads();
-    uint32_t err = 0;
-    if (active) {
-        if (first_pass) {
-            mine = pack_state(decode_subsequence<false>(geom, env, j * kSubseqBits, (j + 1) * kSubseqBits, 0, 0, nullptr, &err));
-            old_global = ~0ull;
-        } else {
-            old_global = gstate[j];
-            mine = old_global;
-        }
-    }
-    sh.end[t + 1] = mine;
+    const int t = threadIdx.x;
+    const uint32_t j = u.first - 1 + t;  // subsequence of lane t (lane 0: the halo; none for the first workgroup of an image)
+    const bool owner = t >= 1 && j < nsub;
+    const int n_rows = (int)min((uint32_t)kThreads, nsub - u.first + 1);  // rows 1 .. n_rows-1 are owned
+    unsigned long long in_state = 0;
     if (!first_pass) {
-        // the published states of a workgroup are consistent among themselves (the previous launch ended in a local
-        // fixpoint): only lane 0 has to look at its -- possibly new -- incoming state
-        __syncthreads();
-        last_start = t == 0 ? (u.first == 0 ? assumed : ~0ull) : (sh.end[t] & kSyncMask);
+        in_state = u.first ? __hip_atomic_load(&gstate[u.first - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kSyncMask : 0ull;
+        if (in_state == incoming[blockIdx.x]) return;  // uniform
     }
-    // workgroup-local fixpoint: lane t re-decodes whenever the end state of lane t-1 (or the incoming state) is not the
-    // one it started from last time.  Corrections travel one lane per round; rounds stop when nothing moved.
-    for (int round = 0; round < kThreads + 1; round++) {
-        __syncthreads();
-        const unsigned long long prev = sh.end[t] & kSyncMask;
-        bool moved = false;
-        if (active && prev != last_start) {
-            const SubseqState p = unpack_state(prev);
-            const unsigned long long now =
-                pack_state(decode_subsequence<false>(geom, env, p.end_bit, (j + 1) * kSubseqBits, p.zk & 255, p.zk >> 8, nullptr, &err));
-            moved = ((now ^ mine) & kSyncMask) != 0;
-            mine = now;
-            last_start = prev;
+    stage_rows<kThreads, kThreads>(sh.stream, im, (int)u.first - 1);
+    stage_pool<kThreads>(pool, im);
+    stage_constants(sh.tsel, nullptr, nullptr, im, false);
+    __syncthreads();
+
+    unsigned long long old_global = ~0ull;
+    int task = -1;
+    if (first_pass) {
+        const unsigned long long assumed = (unsigned long long)j * kSubseqBits;
+        unsigned long long mine = 0;  // first workgroup of an image, lane 0: the exact initial state (bit 0, z 0, k 0)
+        if (owner || (t == 0 && u.first > 0)) {
+            const DevEnv env = make_env(sh, pool, u.first, t);
+            mine = pack_state(decode_subsequence(geom, env, j * kSubseqBits, (j + 1) * kSubseqBits, 0, 0));
         }
+        sh.end[t] = mine;
         __syncthreads();
-        sh.end[t + 1] = mine;
-        if (!__syncthreads_or(moved ? 1 : 0)) break;
+        if (owner && (sh.end[t - 1] & kSyncMask) != assumed) task = t;
+    } else {
+        if (owner) old_global = gstate[j];
+        sh.end[t] = t == 0 ? in_state : old_global;
+        if (t == 1) task = 1;
     }
-    if (active && mine != old_global) {
-        __hip_atomic_store(&gstate[j], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (last && ((mine ^ old_global) & kSyncMask) != 0) atomicAdd(changed, 1u);
+    int rounds = 0;
+    for (int round = 0; round < kThreads + 2; round++) {
+        __syncthreads();
+        rounds++;
+        unsigned long long now = 0;
+        bool moved = false;
+        if (task >= 0) {
+            const SubseqState p = unpack_state(sh.end[task - 1]);
+            const DevEnv env = make_env(sh, pool, u.first, (uint32_t)task);
+            now = pack_state(decode_subsequence(geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8));
+            moved = ((now ^ sh.end[task]) & kSyncMask) != 0;
+        }
+        __syncthreads();  // every start state has been read before any end state is replaced
+        if (task >= 0) sh.end[task] = now;
+        if (compact_tasks(sh, moved && task + 1 < n_rows, task + 1, &task) == 0) break;
+    }
+    __syncthreads();
+    if (owner) {
+        const unsigned long long mine = sh.end[t];
+        if (mine != old_global) {
+            __hip_atomic_store(&gstate[j], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == n_rows - 1 && ((mine ^ old_global) & kSyncMask) != 0) atomicAdd(counters + (first_pass ? 1 : 0), 1u);
+        }
+    }
+    if (t == 0) {
+        incoming[blockIdx.x] = first_pass ? (sh.end[0] & kSyncMask) : in_state;
+        // statistics: correction rounds (sum, maximum) of the first launch / of the later launches
+        atomicAdd(counters + (first_pass ? 2 : 4), (unsigned)rounds);
+        atomicMax(counters + (first_pass ? 3 : 5), (unsigned)rounds);
     }
 }
 
@@ -380,10 +462,86 @@ __global__ __launch_bounds__(kThreads) void huff_scan_kernel(HuffImage* __restri
     if (threadIdx.x == kThreads - 1 && s_sum[kThreads - 1] < im.total_blocks) im.status = 2;  // the stream ends before the last block
 }
 
-__global__ __launch_bounds__(kThreads) void huff_write_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
-                                                              const unsigned long long* __restrict__ states, const uint32_t* __restrict__ first_block)
+// ---- write pass -----------------------------------------------------------------------------------------------------------
+// 128 lanes, one subsequence each (no halo).  Besides the stream rows (one extra row for the last lane's overshoot into the
+// successor workgroup's range) every lane has a 128-byte block buffer in LDS: coefficients land there, and a finished block
+// leaves as eight 16-byte stores -- one full 128-byte line, written once.  (Scattered 2-byte stores into a zeroed arena cost
+// 2.5x the arena size in partial-line HBM writes, plus the memset.)
+constexpr int kWThreads = kHuffWriteOwn;
+constexpr int kWRows = kWThreads + 1;
+constexpr int kBlockBufBytes = 144;  // 128 + 16: 16-byte aligned rows whose starts are spread over the banks
+
+struct WriteShared {
+    uint32_t stream[kWRows * kRowWords];
+    __attribute__((aligned(16))) uint8_t blocks[kWThreads * kBlockBufBytes];
+    KSlot kslot[10];
+    uint32_t tsel[10];
+    uint32_t zz[16];  // zigzag permutation, 4 entries per word
+};
+
+struct WriteEnv {
+    uint32_t stream_base;  // LDS byte address of the staged rows
+    uint32_t word0;        // image word index of the first staged word
+    const uint32_t* gstream;
+    uint32_t gwords;
+    uint32_t pool;
+    uint32_t buf;          // LDS byte address of this lane's block buffer
+    int16_t* dc_diff;
+    const HJ_LDS uint32_t* tsel;
+    const HJ_LDS KSlot* kslot;
+    const HJ_LDS uint8_t* zz;
+    __device__ __forceinline__ uint32_t window(uint32_t pos) const
+    {
+        const uint32_t sh = pos & 31, d = pos >> 5, local = d - word0;
+        uint32_t w0, w1;
+        if (local < (uint32_t)(kWRows * kSubseqWords)) {
+            const HJ_LDS uint32_t* p = (const HJ_LDS uint32_t*)(uintptr_t)(stream_base + ((local + (local >> 5)) << 2));  // 33 words per row
+            w0 = p[0];
+            w1 = p[1];
+        } else {  // a block that runs more than a whole subsequence past the workgroup's range: rare, straight from memory
+            const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)gstream;
+            w0 = d < gwords ? __builtin_bswap32(g[d]) : ~0u;
+            w1 = d + 1 < gwords ? __builtin_bswap32(g[d + 1]) : ~0u;
+        }
+        return (w0 << sh) | ((w1 >> 1) >> (sh ^ 31));
+    }
+    __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
+    __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
+    {
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + t + ((w >> (31 - kHuffFastBits)) & ((2u << kHuffFastBits) - 2)));
+    }
+    __device__ __forceinline__ uint32_t lookup2(uint32_t e, uint32_t w) const
+    {
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0xFFE0u) << 2) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
+    }
+    __device__ __forceinline__ int16_t* block_ptr(int k, uint32_t mx, uint32_t my) const
+    {
+        const HJ_LDS KSlot* s = kslot + k;
+        int16_t* base = s->base;
+        const uint32_t sy = s->stride_y, sx = s->stride_x;
+        return base + (size_t)(my * sy + mx * sx) * 64;
+    }
+    __device__ __forceinline__ int zigzag(int z) const { return zz[z]; }
+    __device__ __forceinline__ void put(int index, int value) const { *(HJ_LDS int16_t*)(uintptr_t)(buf + index * 2) = (int16_t)value; }
+    __device__ __forceinline__ void put_dc(uint32_t block, int value) const { ((HJ_GLOBAL int16_t*)dc_diff)[block] = (int16_t)value; }
+    __device__ __forceinline__ void flush(int16_t* dst) const
+    {
+        HJ_LDS u32x4* b = (HJ_LDS u32x4*)(uintptr_t)buf;
+        u32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = b[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            __builtin_nontemporal_store(v[i], (HJ_GLOBAL u32x4*)dst + i);  // explicitly global: a flat store would tie up the LDS counter
+            b[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+};
+
+__global__ __launch_bounds__(kWThreads) void huff_write_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+                                                               const unsigned long long* __restrict__ states, const uint32_t* __restrict__ first_block)
 {
-    __shared__ WgShared sh;
+    __shared__ WriteShared sh;
     extern __shared__ uint16_t dyn_pool[];
     HJ_LDS uint16_t* pool = (HJ_LDS uint16_t*)dyn_pool;
     const HuffUnit u = units[blockIdx.x];
@@ -391,11 +549,29 @@ __global__ __launch_bounds__(kThreads) void huff_write_kernel(HuffImage* __restr
     const HuffGeom geom = make_geom(im);
     const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
     if (u.first >= nsub) return;
-    stage_workgroup(sh, pool, im, u.first, true);
+    const int t = threadIdx.x;
+    stage_rows<kWThreads, kWRows>(sh.stream, im, (int)u.first);
+    stage_pool<kWThreads>(pool, im);
+    stage_constants(sh.tsel, sh.kslot, sh.zz, im, true);
+    {
+        HJ_LDS u32x4* b = (HJ_LDS u32x4*)&sh.blocks[t * kBlockBufBytes];
+#pragma unroll
+        for (int i = 0; i < kBlockBufBytes / 16; i++) b[i] = u32x4{0u, 0u, 0u, 0u};
+    }
     __syncthreads();
-    const uint32_t j = u.first + threadIdx.x;
+    const uint32_t j = u.first + t;
     if (j >= nsub) return;
-    const DevEnv env = make_env(sh, pool, j);
+    WriteEnv env;
+    env.stream_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)sh.stream;
+    env.word0 = u.first * kSubseqWords;
+    env.gstream = reinterpret_cast<const uint32_t*>(im.stream);
+    env.gwords = im.stream_words;
+    env.pool = (uint32_t)(uintptr_t)pool;
+    env.buf = (uint32_t)(uintptr_t)(HJ_LDS uint8_t*)&sh.blocks[t * kBlockBufBytes];
+    env.dc_diff = geom.dc_diff;
+    env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
+    env.kslot = (const HJ_LDS KSlot*)sh.kslot;
+    env.zz = (const HJ_LDS uint8_t*)sh.zz;
     const unsigned long long* st = states + im.first_subseq;
     uint32_t begin = 0;
     int z = 0, k = 0;
@@ -406,12 +582,12 @@ __global__ __launch_bounds__(kThreads) void huff_write_kernel(HuffImage* __restr
         k = p.zk >> 8;
     }
     uint32_t err = 0;
-    HuffCursor cursor = make_cursor(geom, env, first_block[im.first_subseq + j], k);
-    decode_subsequence<true>(geom, env, begin, (j + 1) * kSubseqBits, z, k, &cursor, &err);
+    write_subsequence(geom, env, begin, (j + 1) * kSubseqBits, z, k, make_cursor(geom, env, first_block[im.first_subseq + j], k), &err);
     if (err) im.status = 1;  // benign race: every writer stores the same value
 }
 
-// One workgroup per (image, component): integrate the DC differences in MCU order and store them into the blocks.
+// One workgroup per (image, component): integrate the DC differences in MCU order; DC values go to the component's compact
+// DC plane (raster block order), which the IDCT kernels read beside the coefficient blocks.
 __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units)
 {
     __shared__ int s_sum[kThreads];
@@ -422,7 +598,7 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
     const uint32_t bpm = im.blocks_per_mcu, k0 = im.comp_k0[c];
     const uint32_t mcus = im.mcus_x * im.mcus_y;
     const uint32_t n = mcus * bpc;
-    int16_t* coef = im.coef[c];
+    int16_t* plane = im.dc_plane[c];
     const int16_t* diff = im.dc_diff;
     const uint32_t bw = im.blocks_w[c], mcus_x = im.mcus_x;
     const uint32_t per = (n + kThreads - 1) / kThreads;
@@ -452,7 +628,7 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
     for (uint32_t s = lo; s < hi; s++) {
         run += diff[mcu * bpm + k0 + jj];
         const uint32_t dy = jj / h, dx = jj - dy * h;
-        coef[((size_t)(my * v + dy) * bw + (mx * h + dx)) * 64] = (int16_t)run;
+        plane[(my * v + dy) * bw + (mx * h + dx)] = (int16_t)run;
         if (++jj == bpc) {
             jj = 0;
             mcu++;
@@ -474,11 +650,12 @@ int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, 
     return (int)hipGetLastError();
 }
 
-int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned int* changed, int first_pass,
-                     unsigned pool_bytes, void* stream)
+int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
+                     unsigned int* changed, int first_pass, unsigned pool_bytes, void* stream)
 {
     if (nunits <= 0) return 0;
-    hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, units, states, changed, first_pass);
+    hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
+                       first_pass);
     return (int)hipGetLastError();
 }
 
@@ -493,7 +670,7 @@ int launch_huff_write(HuffImage* images, const HuffUnit* units, int nunits, cons
                       unsigned pool_bytes, void* stream)
 {
     if (nunits <= 0) return 0;
-    hipLaunchKernelGGL(huff_write_kernel, dim3(nunits), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, units, states, first_block);
+    hipLaunchKernelGGL(huff_write_kernel, dim3(nunits), dim3(kWThreads), pool_bytes, (hipStream_t)stream, images, units, states, first_block);
     return (int)hipGetLastError();
 }
 

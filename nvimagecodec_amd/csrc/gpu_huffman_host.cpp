@@ -88,26 +88,29 @@ size_t table_words(const HuffSpec& s, bool is_dc)
     return ok && !bad ? words : 0;
 }
 
-// Expands one table at pool[base...]; returns the number of entries used.
-size_t expand_table(const HuffSpec& s, uint16_t* pool, size_t base)
+// Expands one table at pool[base...] (base is a multiple of 64); returns the number of entries used.
+size_t expand_table(const HuffSpec& s, bool is_dc, uint16_t* pool, size_t base)
 {
-    const uint16_t invalid = (uint16_t)(kEntryInvalid | (1u << 8));  // "no such code": consume one bit, symbol 0
     uint16_t* first = pool + base;
-    for (int i = 0; i < (1 << kHuffFastBits); i++) first[i] = invalid;
+    for (int i = 0; i < (1 << kHuffFastBits); i++) first[i] = (uint16_t)kEntryInvalid;
     size_t used = 1u << kHuffFastBits;
     for_each_code(s, [&](int l, uint32_t code, uint8_t sym) {
-        const uint16_t e = (uint16_t)((l << 8) | sym);
+        const uint32_t nb = sym & 15u, run = sym >> 4;
+        // DC: the symbol is the size category.  AC: (run, size); size 0 is EOB except for run 15 (ZRL, 16 zeros) -- libjpeg
+        // treats every other run with size 0 as EOB too (jdhuff.c decode_mcu: "if (r != 15) break").
+        const uint32_t zadv = is_dc ? 1u : (nb ? run + 1 : (run == 15 ? 16u : 64u));
+        const uint16_t e = (uint16_t)make_entry((uint32_t)l + nb, nb, zadv);
         if (l <= kHuffFastBits) {
             const uint32_t lo = code << (kHuffFastBits - l);
             for (uint32_t j = 0; j < (1u << (kHuffFastBits - l)); j++) first[lo + j] = e;
         } else {
             const uint32_t prefix = code >> (l - kHuffFastBits);
-            if (!(first[prefix] & kEntryLong)) {
-                first[prefix] = (uint16_t)(kEntryLong | (base + used));
-                for (int j = 0; j < (1 << kHuffSubBits); j++) pool[base + used + j] = invalid;
+            if ((first[prefix] & 31u) != 0) {  // still "no such code": open a second-level table
+                first[prefix] = (uint16_t)(((base + used) / 64) << 5);
+                for (int j = 0; j < (1 << kHuffSubBits); j++) pool[base + used + j] = (uint16_t)kEntryInvalid;
                 used += 1u << kHuffSubBits;
             }
-            uint16_t* sub = pool + (first[prefix] & 0x7FFFu);
+            uint16_t* sub = pool + (size_t)(first[prefix] >> 5) * 64;
             const uint32_t lo = (code & ((1u << (l - kHuffFastBits)) - 1)) << (16 - l);
             for (uint32_t j = 0; j < (1u << (16 - l)); j++) sub[lo + j] = e;
         }
@@ -149,12 +152,12 @@ void build_gpu_pool(const ScanHeader& sc, HuffImage* im, uint16_t* pool)
         if (!dc_seen[td]) {
             dc_seen[td] = true;
             dc_off[td] = used;
-            used += expand_table(sc.dc[td], pool, used);
+            used += expand_table(sc.dc[td], true, pool, used);
         }
         if (!ac_seen[ta]) {
             ac_seen[ta] = true;
             ac_off[ta] = used;
-            used += expand_table(sc.ac[ta], pool, used);
+            used += expand_table(sc.ac[ta], false, pool, used);
         }
     }
     im->pool_words = (uint32_t)used;
@@ -204,7 +207,8 @@ struct HostEnv {
         const uint64_t v = ((uint64_t)p[0] << 32) | ((uint64_t)p[1] << 24) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 8) | (uint64_t)p[4];
         return (uint32_t)(v >> (8 - (pos & 7)));
     }
-    uint32_t entry(uint32_t i) const { return im->pool[i]; }
+    uint32_t lookup1(uint32_t t, uint32_t w) const { return im->pool[t + (w >> (32 - kHuffFastBits))]; }
+    uint32_t lookup2(uint32_t e, uint32_t w) const { return im->pool[(e >> 5) * 64u + ((w >> 16) & ((1u << kHuffSubBits) - 1))]; }
     uint32_t tables(int k) const { return (uint32_t)im->k[k].tdc | ((uint32_t)im->k[k].tac << 16); }
     int16_t* block_ptr(int k, uint32_t mx, uint32_t my) const
     {
@@ -212,6 +216,14 @@ struct HostEnv {
         return im->coef[hk.comp] + ((size_t)hk.blk0 + (size_t)my * hk.stride_y + (size_t)mx * hk.stride_x) * 64;
     }
     int zigzag(int z) const { return kZigzagDeviceGpuHost[z]; }
+    int16_t* buf;  // 64-entry block buffer
+    void put(int index, int value) const { buf[index] = (int16_t)value; }
+    void put_dc(uint32_t block, int value) const { im->dc_diff[block] = (int16_t)value; }
+    void flush(int16_t* dst) const
+    {
+        memcpy(dst, buf, 128);
+        memset(buf, 0, 128);
+    }
 };
 }  // namespace
 
@@ -231,22 +243,23 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
     im.dc_diff = dc_diff.data();
     for (int c = 0; c < f.ncomp; c++) {
         im.coef[c] = coef[c];
-        memset(coef[c], 0, (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 128);
+        memset(coef[c], 0x5A, (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 128);  // every block must be written by the write pass
     }
-    const HostEnv env{&im};
+    int16_t block_buffer[64] = {0};
+    const HostEnv env{&im, block_buffer};
     const HuffGeom geom = make_geom(im);
     const uint32_t ns = im.num_subseq;
     std::vector<SubseqState> cur(ns), nxt(ns);
     uint32_t err = 0;
     // pass 0
-    for (uint32_t i = 0; i < ns; i++) cur[i] = decode_subsequence<false>(geom, env, i * kSubseqBits, (i + 1) * kSubseqBits, 0, 0, nullptr, &err);
+    for (uint32_t i = 0; i < ns; i++) cur[i] = decode_subsequence(geom, env, i * kSubseqBits, (i + 1) * kSubseqBits, 0, 0);
     int passes = 0;
     for (;;) {
         bool changed = false;
         if (ns) nxt[0] = cur[0];
         for (uint32_t i = 1; i < ns; i++) {
             const SubseqState& prev = cur[i - 1];
-            nxt[i] = decode_subsequence<false>(geom, env, prev.end_bit, (i + 1) * kSubseqBits, prev.zk & 255, prev.zk >> 8, nullptr, &err);
+            nxt[i] = decode_subsequence(geom, env, prev.end_bit, (i + 1) * kSubseqBits, prev.zk & 255, prev.zk >> 8);
             if (pack_state(nxt[i]) != pack_state(cur[i])) changed = true;
         }
         cur.swap(nxt);
@@ -267,8 +280,7 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
     for (uint32_t i = 0; i < ns; i++) {
         const uint32_t begin = i == 0 ? 0 : cur[i - 1].end_bit;
         const int z = i == 0 ? 0 : (cur[i - 1].zk & 255), k = i == 0 ? 0 : (cur[i - 1].zk >> 8);
-        HuffCursor cursor = make_cursor(geom, env, first_block[i], k);
-        decode_subsequence<true>(geom, env, begin, (i + 1) * kSubseqBits, z, k, &cursor, &err);
+        write_subsequence(geom, env, begin, (i + 1) * kSubseqBits, z, k, make_cursor(geom, env, first_block[i], k), &err);
     }
     if (err) return 1;
     // DC integration, per component in MCU (scan) order

@@ -15,9 +15,11 @@
 //              is exact).
 //   count      each pass also counts the blocks completed in the subsequence; an exclusive scan gives every lane the
 //              index of its first block.
-//   write      the lanes decode once more and write coefficients (column-major block layout); DC differences go to a
-//              compact per-image array in scan order.
-//   dc         a per-component scan in MCU order turns DC differences into DC values and stores them into the blocks.
+//   write      the lanes decode once more; each assembles the blocks that start in its subsequence and stores them whole
+//              (column-major block layout, DC position left zero); DC differences go to a compact per-image array in scan
+//              order.
+//   dc         a per-component scan in MCU order turns DC differences into DC values, stored as one compact plane per
+//              component (raster block order) that the IDCT kernels read next to the coefficient blocks.
 // All decisions are integer/bit exact; the result is compared with the host entropy decoder and the oracle in tests/.
 #pragma once
 #include <cstdint>
@@ -36,13 +38,20 @@ constexpr int kSubseqWords = kSubseqBits / 32;
 constexpr int kHuffFastBits = 10;      // first-level lookup width
 constexpr int kHuffSubBits = 16 - kHuffFastBits;
 constexpr int kStreamSlackBytes = 32;  // readable bytes after the last real byte of a destuffed stream
+constexpr int kHuffOwn = 255;          // subsequences per workgroup of the sync/write kernels (256 lanes, one is the halo)
+constexpr int kHuffWriteOwn = 128;     // subsequences (= lanes) per workgroup of the write kernel
 constexpr int kDestuffChunk = 16384;   // raw bytes one workgroup of the destuff kernels handles
 constexpr int kMaxPoolWords = 12288;   // uint16 entries of lookup tables per image the kernels accept (24 KB of LDS)
 
-// Lookup-table entry (uint16): bits 0-7 symbol, bits 8-12 code length, bit 14 "no such code", bit 15 "longer than
-// kHuffFastBits: bits 0-14 = pool offset of the 64-entry second-level table, indexed by the next kHuffSubBits bits".
-constexpr uint32_t kEntryInvalid = 0x4000u;
-constexpr uint32_t kEntryLong = 0x8000u;
+// Lookup-table entry (uint16), laid out for the state update the decoders do per symbol:
+//   bits 0-4   total = code length + number of value bits (1..31); 0 = "code longer than kHuffFastBits": bits 5-15 hold the
+//              pool offset / 64 of the second-level table, indexed by the next kHuffSubBits bits
+//   bits 5-8   nb = number of value bits (size category)
+//   bits 9-15  zadv = how far the zigzag position advances: 1 for a DC symbol, run + 1 for a coefficient, 16 for ZRL,
+//              64 for EOB (any value that takes the position past 63 ends the block)
+// "No such code" is total = 1, nb = 15 (impossible for a real symbol), zadv = 1.
+HJ_HD constexpr uint32_t make_entry(uint32_t total, uint32_t nb, uint32_t zadv) { return total | (nb << 5) | (zadv << 9); }
+constexpr uint32_t kEntryInvalid = 1u | (15u << 5) | (1u << 9);
 
 // One block position k inside the MCU (k < blocks_per_mcu <= 10).
 struct HuffK {
@@ -61,6 +70,7 @@ struct alignas(16) HuffImage {
     const uint16_t* pool;    // lookup tables (pool_words entries)
     int16_t* coef[4];        // component coefficient blocks (device layout)
     int16_t* dc_diff;        // total_blocks DC differences in scan order (written by the write pass)
+    int16_t* dc_plane[4];    // per component: DC values, one per block, raster order over the allocation grid (dc kernel)
     uint32_t total_bits;     // 8 * destuffed length
     uint32_t first_subseq;   // index of this image's first subsequence in the batch-wide arrays
     uint32_t num_subseq;     // ceil(total_bits / kSubseqBits)
@@ -122,63 +132,35 @@ struct HuffCursor {
     int16_t* blk;  // nullptr = past the last block of the scan
 };
 
-// Decodes the symbols that START in [begin, limit) (and before total_bits), beginning in state (z, k).
-//   WRITE == false: only tracks the state and counts completed blocks.
-//   WRITE == true : also stores coefficients through `cur` (initialised by the caller for the block of the first symbol).
+// Synchronisation decode: the symbols that START in [begin, limit) (and before total_bits), beginning in state (z, k).
+// Tracks the decoder state and counts the blocks completed; nothing is stored.
 // Env supplies the memory accessors:
 //   uint32_t window(uint32_t pos)        the 32 stream bits starting at bit `pos`, MSB first
-//   uint32_t entry(uint32_t index)       lookup-table pool entry
-//   uint32_t tables(int k)               tdc | tac << 16 for block position k
-//   int16_t* block_ptr(int k, mx, my)    address of the block at position k of MCU (mx, my)
-//   int      zigzag(int z)               device-layout index of zigzag position z
-template <bool WRITE, class Env>
-HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, HuffCursor* cur,
-                                     uint32_t* error)
+//   uint32_t tables(int k)               tdc | tac << 16 for block position k: where the first-level tables are, in whatever
+//                                        unit lookup1 wants
+//   uint32_t lookup1(uint32_t t, w)      first-level entry of table t for window w (index = top kHuffFastBits bits)
+//   uint32_t lookup2(uint32_t e, w)      second-level entry behind first-level entry e (index = next kHuffSubBits bits)
+template <class Env>
+HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k)
 {
     uint32_t pos = begin, nblocks = 0;
     const uint32_t end = limit < im.total_bits ? limit : im.total_bits;
     const int bpm = (int)im.blocks_per_mcu;
     uint32_t tsel = env.tables(k);
+    uint32_t tcur = z == 0 ? (tsel & 0xFFFFu) : (tsel >> 16);  // table of the next symbol: DC at the start of a block, AC after it
     while (pos < end) {
         const uint32_t w = env.window(pos);
-        const bool is_dc = z == 0;
-        const uint32_t tb = is_dc ? (tsel & 0xFFFFu) : (tsel >> 16);
-        uint32_t e = env.entry(tb + (w >> (32 - kHuffFastBits)));
-        if (e & kEntryLong) e = env.entry((e & 0x7FFFu) + ((w >> 16) & ((1u << kHuffSubBits) - 1)));
-        const uint32_t len = (e >> 8) & 31u, sym = e & 255u;
-        const uint32_t nb = sym & 15u, r = is_dc ? 0u : (sym >> 4);
-        if (WRITE) {
-            // nb value bits follow the code; values below 2^(nb-1) are the negative half (JPEG "EXTEND")
-            const uint32_t v = ((w << len) >> 1) >> (31 - nb);
-            const int val = v < ((1u << nb) >> 1) ? (int)v - (int)(1u << nb) + 1 : (int)v;
-            const uint32_t zpos = (uint32_t)z + r;
-            if (cur->blk) {
-                if (e & kEntryInvalid) *error = 1;
-                if (is_dc) {
-                    im.dc_diff[cur->block] = (int16_t)val;
-                } else if (nb) {
-                    if (zpos <= 63)
-                        cur->blk[env.zigzag((int)zpos)] = (int16_t)val;
-                    else
-                        *error = 1;  // run past the end of the block
-                }
-            }
-        }
-        pos += len + nb;
-        z = (!is_dc && nb == 0 && r != 15) ? 64 : z + (int)r + 1;  // EOB | ZRL (+16) / coefficient (+run+1) / DC (-> 1)
+        uint32_t e = env.lookup1(tcur, w);
+        if ((e & 31u) == 0) e = env.lookup2(e, w);
+        pos += e & 31u;
+        z += (int)(e >> 9);
+        tcur = tsel >> 16;
         if (z >= 64) {
             z = 0;
             nblocks++;
             if (++k == bpm) k = 0;
             tsel = env.tables(k);
-            if (WRITE) {
-                cur->block++;
-                if (k == 0 && ++cur->mx == im.mcus_x) {
-                    cur->mx = 0;
-                    cur->my++;
-                }
-                cur->blk = cur->my < im.mcus_y ? env.block_ptr(k, cur->mx, cur->my) : nullptr;
-            }
+            tcur = tsel & 0xFFFFu;
         }
     }
     SubseqState st;
@@ -186,6 +168,68 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
     st.zk = (uint16_t)((k << 8) | z);
     st.nblocks = (uint16_t)(nblocks > 0xFFFF ? 0xFFFF : nblocks);
     return st;
+}
+
+// Write pass.  The subsequence's lane OWNS the blocks whose first (DC) symbol starts in [begin, limit): it decodes each of
+// them to its end -- past `limit` for the last one -- collects the coefficients in a block buffer and flushes whole blocks,
+// so that every block is stored exactly once, by one lane, as one 128-byte line.  A block already in progress at `begin`
+// (z != 0) belongs to the predecessor: its symbols are decoded to find the next block boundary but not stored.
+// DC differences go to dc_diff[scan-order block index].
+// Env additionally supplies:
+//   int16_t* block_ptr(int k, mx, my)    address of the block at position k of MCU (mx, my)
+//   int      zigzag(int z)               device-layout index of zigzag position z
+//   void     put(int index, int value)   store into the (zero-initialised) block buffer
+//   void     put_dc(block, int value)    store the DC difference of scan-order block `block`
+//   void     flush(int16_t* dst)         copy the block buffer to dst and zero it again
+// `cur` is the cursor of the block that contains the first symbol.
+template <class Env>
+HJ_HD void write_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, HuffCursor cur, uint32_t* error)
+{
+    uint32_t pos = begin;
+    const uint32_t end = limit < im.total_bits ? limit : im.total_bits;
+    const int bpm = (int)im.blocks_per_mcu;
+    uint32_t tsel = env.tables(k);
+    uint32_t tcur = z == 0 ? (tsel & 0xFFFFu) : (tsel >> 16);
+    bool own = z == 0;
+    while (pos < im.total_bits && (pos < end || (own && z != 0))) {
+        const uint32_t w = env.window(pos);
+        const bool is_dc = z == 0;
+        uint32_t e = env.lookup1(tcur, w);
+        if ((e & 31u) == 0) e = env.lookup2(e, w);
+        const uint32_t total = e & 31u, zadv = e >> 9;
+        {
+            // straight-line arithmetic, predicated stores: lanes of a wave sit at unrelated points of their blocks
+            const bool live = own && cur.blk != nullptr;
+            const uint32_t nb_raw = (e >> 5) & 15u;
+            const bool bad_code = nb_raw >= total;  // "no such code"
+            const uint32_t nb = bad_code ? 0u : nb_raw;
+            // nb value bits follow the code; values below 2^(nb-1) are the negative half (JPEG "EXTEND")
+            const uint32_t v = ((w << (total - nb)) >> 1) >> (31 - nb);
+            const int val = v < ((1u << nb) >> 1) ? (int)v - (int)(1u << nb) + 1 : (int)v;
+            const uint32_t zpos = (uint32_t)z + zadv - 1;
+            const bool ac = !is_dc && nb != 0;
+            if (live && (bad_code || (ac && zpos > 63))) *error = 1;  // invalid code / run past the end of the block
+            if (live && is_dc) env.put_dc(cur.block, val);
+            if (live && ac && zpos <= 63) env.put(env.zigzag((int)zpos), val);
+        }
+        pos += total;
+        z += (int)zadv;
+        tcur = tsel >> 16;
+        if (z >= 64) {
+            if (own && cur.blk) env.flush(cur.blk);
+            own = true;  // whatever starts now starts inside the lane's range, or the loop ends
+            z = 0;
+            if (++k == bpm) k = 0;
+            tsel = env.tables(k);
+            tcur = tsel & 0xFFFFu;
+            cur.block++;
+            if (k == 0 && ++cur.mx == im.mcus_x) {
+                cur.mx = 0;
+                cur.my++;
+            }
+            cur.blk = cur.my < im.mcus_y ? env.block_ptr(k, cur.mx, cur.my) : nullptr;
+        }
+    }
 }
 
 // Cursor for the block with scan-order index `block` whose position inside the MCU is k.
