@@ -40,24 +40,30 @@ struct KSlot {
     uint32_t stride_y, stride_x;
 };
 
+// Stream words in LDS: word d of the staged range sits at index d + (d >> 5) -- 33 words per 32-word subsequence, so that
+// lanes at the same column of their rows hit different banks.  kStagedExtra words behind the last row cover the bit
+// reader's look-ahead.
+constexpr int kStagedExtra = 4;
+__host__ __device__ constexpr int staged_lds_words(int rows) { return rows * kRowWords + kStagedExtra; }
+
 struct WgShared {
-    uint32_t stream[kThreads * kRowWords];
+    uint32_t stream[staged_lds_words(kThreads)];
     unsigned long long end[kThreads];  // end state of lane t's subsequence ([0] = halo = state entering the workgroup)
     uint32_t tsel[10];
     uint32_t queue[kThreads];
     uint32_t wave_count[4];
 };
 
-// LDS accessors for decode_subsequence; one instance per (lane, row).
+// LDS accessors for decode_subsequence.
 struct DevEnv {
-    uint32_t row_bias;   // LDS byte address of the row's first word minus 4 * (index of that word in the image)
-    uint32_t pool;       // LDS byte address of the lookup tables
+    uint32_t stream_base;  // LDS byte address of the staged words
+    uint32_t word0;        // image word index of the first staged word
+    uint32_t pool;         // LDS byte address of the lookup tables
     const HJ_LDS uint32_t* tsel;  // per MCU position: BYTE offsets of the DC / AC first-level tables, packed lo/hi
-    __device__ __forceinline__ uint32_t window(uint32_t pos) const
+    __device__ __forceinline__ uint32_t word(uint32_t i) const
     {
-        const HJ_LDS uint32_t* p = (const HJ_LDS uint32_t*)(uintptr_t)(row_bias + ((pos >> 5) << 2));
-        const uint32_t w0 = p[0], w1 = p[1], sh = pos & 31;
-        return (w0 << sh) | ((w1 >> 1) >> (sh ^ 31));  // no special case for sh == 0, no 64-bit shift
+        const uint32_t local = i - word0;
+        return *(const HJ_LDS uint32_t*)(uintptr_t)(stream_base + ((local + (local >> 5)) << 2));
     }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
     __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
@@ -66,13 +72,13 @@ struct DevEnv {
     }
     __device__ __forceinline__ uint32_t lookup2(uint32_t e, uint32_t w) const
     {
-        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0xFFE0u) << 2) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0x1FFu) << 7) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
     }
 };
 
-// Cooperative staging of stream rows: row r = subsequence first_row + r of the image (first_row may be -1: that row is
-// filled with ones).  Every row holds its 32 words plus a copy of the successor's first word.  16-byte global loads, all of
-// a lane's loads in flight together.
+// Cooperative staging of stream words: ROWS subsequences starting with subsequence first_row of the image (first_row may
+// be -1: that row is filled with ones) plus kStagedExtra words.  16-byte global loads, all of a lane's loads in flight
+// together.
 template <int THREADS, int ROWS>
 __device__ __forceinline__ void stage_rows(uint32_t* lds_stream, const HuffImage& im, int first_row)
 {
@@ -80,7 +86,7 @@ __device__ __forceinline__ void stage_rows(uint32_t* lds_stream, const HuffImage
     const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
     const int nwords = (int)im.stream_words;
     const int w0 = first_row * kSubseqWords;
-    constexpr int kGroups = ROWS * kSubseqWords / 4;  // 16-byte groups
+    constexpr int kGroups = (ROWS * kSubseqWords + kStagedExtra) / 4;  // 16-byte groups
     constexpr int kIters = (kGroups + THREADS - 1) / THREADS;
     u32x4 v[kIters];
 #pragma unroll
@@ -95,20 +101,13 @@ __device__ __forceinline__ void stage_rows(uint32_t* lds_stream, const HuffImage
 #pragma unroll
     for (int i = 0; i < kIters; i++) {
         if (i * THREADS + t < kGroups) {
-            const uint32_t d = (uint32_t)(i * THREADS + t) * 4;
-            const uint32_t row = d >> 5, col = d & 31;
-            HJ_LDS uint32_t* dst = (HJ_LDS uint32_t*)&lds_stream[row * kRowWords + col];
-            const uint32_t a = __builtin_bswap32(v[i].x);
-            dst[0] = a;
+            const uint32_t d = (uint32_t)(i * THREADS + t) * 4;  // the four words share a row: 32 % 4 == 0
+            HJ_LDS uint32_t* dst = (HJ_LDS uint32_t*)&lds_stream[d + (d >> 5)];
+            dst[0] = __builtin_bswap32(v[i].x);
             dst[1] = __builtin_bswap32(v[i].y);
             dst[2] = __builtin_bswap32(v[i].z);
             dst[3] = __builtin_bswap32(v[i].w);
-            if (col == 0 && row > 0) lds_stream[(row - 1) * kRowWords + kSubseqWords] = a;  // the predecessor row's 33rd word
         }
-    }
-    if (t == 0) {
-        const int gd = w0 + ROWS * kSubseqWords;
-        lds_stream[(ROWS - 1) * kRowWords + kSubseqWords] = (gd >= 0 && gd < nwords) ? __builtin_bswap32(g[gd]) : ~0u;
     }
 }
 
@@ -150,11 +149,11 @@ __device__ __forceinline__ void stage_constants(uint32_t* tsel, KSlot* kslot, ui
     }
 }
 
-// environment for decoding the subsequence in LDS row `r` (image subsequence index first - 1 + r)
-__device__ __forceinline__ DevEnv make_env(WgShared& sh, HJ_LDS uint16_t* pool, uint32_t first, uint32_t r)
+__device__ __forceinline__ DevEnv make_env(WgShared& sh, HJ_LDS uint16_t* pool, uint32_t first)
 {
     DevEnv env;
-    env.row_bias = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&sh.stream[r * kRowWords] - (first - 1 + r) * (kSubseqWords * 4);
+    env.stream_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)sh.stream;
+    env.word0 = (first - 1) * kSubseqWords;  // row 0 = the halo (wraps for the first workgroup of an image; so do the indices)
     env.pool = (uint32_t)(uintptr_t)pool;
     env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
     return env;
@@ -383,13 +382,13 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
     stage_constants(sh.tsel, nullptr, nullptr, im, false);
     __syncthreads();
 
+    const DevEnv env = make_env(sh, pool, u.first);
     unsigned long long old_global = ~0ull;
     int task = -1;
     if (first_pass) {
         const unsigned long long assumed = (unsigned long long)j * kSubseqBits;
         unsigned long long mine = 0;  // first workgroup of an image, lane 0: the exact initial state (bit 0, z 0, k 0)
         if (owner || (t == 0 && u.first > 0)) {
-            const DevEnv env = make_env(sh, pool, u.first, t);
             mine = pack_state(decode_subsequence(geom, env, j * kSubseqBits, (j + 1) * kSubseqBits, 0, 0));
         }
         sh.end[t] = mine;
@@ -408,7 +407,6 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
         bool moved = false;
         if (task >= 0) {
             const SubseqState p = unpack_state(sh.end[task - 1]);
-            const DevEnv env = make_env(sh, pool, u.first, (uint32_t)task);
             now = pack_state(decode_subsequence(geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8));
             moved = ((now ^ sh.end[task]) & kSyncMask) != 0;
         }
@@ -463,16 +461,16 @@ __global__ __launch_bounds__(kThreads) void huff_scan_kernel(HuffImage* __restri
 }
 
 // ---- write pass -----------------------------------------------------------------------------------------------------------
-// 128 lanes, one subsequence each (no halo).  Besides the stream rows (one extra row for the last lane's overshoot into the
+// 128 lanes, one subsequence each (no halo).  Besides the stream rows (two extra rows for the last lane's overshoot into the
 // successor workgroup's range) every lane has a 128-byte block buffer in LDS: coefficients land there, and a finished block
 // leaves as eight 16-byte stores -- one full 128-byte line, written once.  (Scattered 2-byte stores into a zeroed arena cost
 // 2.5x the arena size in partial-line HBM writes, plus the memset.)
 constexpr int kWThreads = kHuffWriteOwn;
-constexpr int kWRows = kWThreads + 1;
+constexpr int kWRows = kWThreads + 2;  // a block is at most 31 + 63 * 31 bits: it ends less than two subsequences past its start
 constexpr int kBlockBufBytes = 144;  // 128 + 16: 16-byte aligned rows whose starts are spread over the banks
 
 struct WriteShared {
-    uint32_t stream[kWRows * kRowWords];
+    uint32_t stream[staged_lds_words(kWRows)];
     __attribute__((aligned(16))) uint8_t blocks[kWThreads * kBlockBufBytes];
     KSlot kslot[10];
     uint32_t tsel[10];
@@ -482,28 +480,16 @@ struct WriteShared {
 struct WriteEnv {
     uint32_t stream_base;  // LDS byte address of the staged rows
     uint32_t word0;        // image word index of the first staged word
-    const uint32_t* gstream;
-    uint32_t gwords;
     uint32_t pool;
     uint32_t buf;          // LDS byte address of this lane's block buffer
     int16_t* dc_diff;
     const HJ_LDS uint32_t* tsel;
     const HJ_LDS KSlot* kslot;
     const HJ_LDS uint8_t* zz;
-    __device__ __forceinline__ uint32_t window(uint32_t pos) const
+    __device__ __forceinline__ uint32_t word(uint32_t i) const
     {
-        const uint32_t sh = pos & 31, d = pos >> 5, local = d - word0;
-        uint32_t w0, w1;
-        if (local < (uint32_t)(kWRows * kSubseqWords)) {
-            const HJ_LDS uint32_t* p = (const HJ_LDS uint32_t*)(uintptr_t)(stream_base + ((local + (local >> 5)) << 2));  // 33 words per row
-            w0 = p[0];
-            w1 = p[1];
-        } else {  // a block that runs more than a whole subsequence past the workgroup's range: rare, straight from memory
-            const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)gstream;
-            w0 = d < gwords ? __builtin_bswap32(g[d]) : ~0u;
-            w1 = d + 1 < gwords ? __builtin_bswap32(g[d + 1]) : ~0u;
-        }
-        return (w0 << sh) | ((w1 >> 1) >> (sh ^ 31));
+        const uint32_t local = i - word0;  // always inside the staged range: see kWRows
+        return *(const HJ_LDS uint32_t*)(uintptr_t)(stream_base + ((local + (local >> 5)) << 2));
     }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
     __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
@@ -512,7 +498,7 @@ struct WriteEnv {
     }
     __device__ __forceinline__ uint32_t lookup2(uint32_t e, uint32_t w) const
     {
-        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0xFFE0u) << 2) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0x1FFu) << 7) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
     }
     __device__ __forceinline__ int16_t* block_ptr(int k, uint32_t mx, uint32_t my) const
     {
@@ -523,9 +509,10 @@ struct WriteEnv {
     }
     __device__ __forceinline__ int zigzag(int z) const { return zz[z]; }
     __device__ __forceinline__ void put(int index, int value) const { *(HJ_LDS int16_t*)(uintptr_t)(buf + index * 2) = (int16_t)value; }
-    __device__ __forceinline__ void put_dc(uint32_t block, int value) const { ((HJ_GLOBAL int16_t*)dc_diff)[block] = (int16_t)value; }
-    __device__ __forceinline__ void flush(int16_t* dst) const
+    __device__ __forceinline__ void flush(int16_t* dst, uint32_t block) const
     {
+        ((HJ_GLOBAL int16_t*)dc_diff)[block] = *(const HJ_LDS int16_t*)(uintptr_t)(buf + 128);
+        *(HJ_LDS int16_t*)(uintptr_t)(buf + 128) = 0;
         HJ_LDS u32x4* b = (HJ_LDS u32x4*)(uintptr_t)buf;
         u32x4 v[8];
 #pragma unroll
@@ -564,8 +551,6 @@ __global__ __launch_bounds__(kWThreads) void huff_write_kernel(HuffImage* __rest
     WriteEnv env;
     env.stream_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)sh.stream;
     env.word0 = u.first * kSubseqWords;
-    env.gstream = reinterpret_cast<const uint32_t*>(im.stream);
-    env.gwords = im.stream_words;
     env.pool = (uint32_t)(uintptr_t)pool;
     env.buf = (uint32_t)(uintptr_t)(HJ_LDS uint8_t*)&sh.blocks[t * kBlockBufBytes];
     env.dc_diff = geom.dc_diff;

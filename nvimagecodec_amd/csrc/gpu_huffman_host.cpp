@@ -105,12 +105,12 @@ size_t expand_table(const HuffSpec& s, bool is_dc, uint16_t* pool, size_t base)
             for (uint32_t j = 0; j < (1u << (kHuffFastBits - l)); j++) first[lo + j] = e;
         } else {
             const uint32_t prefix = code >> (l - kHuffFastBits);
-            if ((first[prefix] & 31u) != 0) {  // still "no such code": open a second-level table
-                first[prefix] = (uint16_t)(((base + used) / 64) << 5);
+            if ((first[prefix] >> 9) != kZadvLong) {  // still "no such code": open a second-level table
+                first[prefix] = (uint16_t)(((base + used) / 64) | (kZadvLong << 9));
                 for (int j = 0; j < (1 << kHuffSubBits); j++) pool[base + used + j] = (uint16_t)kEntryInvalid;
                 used += 1u << kHuffSubBits;
             }
-            uint16_t* sub = pool + (size_t)(first[prefix] >> 5) * 64;
+            uint16_t* sub = pool + (size_t)(first[prefix] & 0x1FFu) * 64;
             const uint32_t lo = (code & ((1u << (l - kHuffFastBits)) - 1)) << (16 - l);
             for (uint32_t j = 0; j < (1u << (16 - l)); j++) sub[lo + j] = e;
         }
@@ -201,14 +201,13 @@ namespace {
 // plain-memory accessors for decode_subsequence
 struct HostEnv {
     const HuffImage* im;
-    uint32_t window(uint32_t pos) const
+    uint32_t word(uint32_t i) const
     {
-        const uint8_t* p = im->stream + (pos >> 3);
-        const uint64_t v = ((uint64_t)p[0] << 32) | ((uint64_t)p[1] << 24) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 8) | (uint64_t)p[4];
-        return (uint32_t)(v >> (8 - (pos & 7)));
+        const uint8_t* p = im->stream + (size_t)i * 4;  // the slack behind the stream covers the reader's look-ahead
+        return i < im->stream_words ? ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3] : ~0u;
     }
     uint32_t lookup1(uint32_t t, uint32_t w) const { return im->pool[t + (w >> (32 - kHuffFastBits))]; }
-    uint32_t lookup2(uint32_t e, uint32_t w) const { return im->pool[(e >> 5) * 64u + ((w >> 16) & ((1u << kHuffSubBits) - 1))]; }
+    uint32_t lookup2(uint32_t e, uint32_t w) const { return im->pool[(e & 0x1FFu) * 64u + ((w >> 16) & ((1u << kHuffSubBits) - 1))]; }
     uint32_t tables(int k) const { return (uint32_t)im->k[k].tdc | ((uint32_t)im->k[k].tac << 16); }
     int16_t* block_ptr(int k, uint32_t mx, uint32_t my) const
     {
@@ -216,13 +215,13 @@ struct HostEnv {
         return im->coef[hk.comp] + ((size_t)hk.blk0 + (size_t)my * hk.stride_y + (size_t)mx * hk.stride_x) * 64;
     }
     int zigzag(int z) const { return kZigzagDeviceGpuHost[z]; }
-    int16_t* buf;  // 64-entry block buffer
+    int16_t* buf;  // block buffer: 64 coefficients + the DC difference
     void put(int index, int value) const { buf[index] = (int16_t)value; }
-    void put_dc(uint32_t block, int value) const { im->dc_diff[block] = (int16_t)value; }
-    void flush(int16_t* dst) const
+    void flush(int16_t* dst, uint32_t block) const
     {
         memcpy(dst, buf, 128);
-        memset(buf, 0, 128);
+        im->dc_diff[block] = buf[64];
+        memset(buf, 0, 130);
     }
 };
 }  // namespace
@@ -245,7 +244,7 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
         im.coef[c] = coef[c];
         memset(coef[c], 0x5A, (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 128);  // every block must be written by the write pass
     }
-    int16_t block_buffer[64] = {0};
+    int16_t block_buffer[65] = {0};
     const HostEnv env{&im, block_buffer};
     const HuffGeom geom = make_geom(im);
     const uint32_t ns = im.num_subseq;

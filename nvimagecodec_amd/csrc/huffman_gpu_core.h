@@ -44,14 +44,16 @@ constexpr int kDestuffChunk = 16384;   // raw bytes one workgroup of the destuff
 constexpr int kMaxPoolWords = 12288;   // uint16 entries of lookup tables per image the kernels accept (24 KB of LDS)
 
 // Lookup-table entry (uint16), laid out for the state update the decoders do per symbol:
-//   bits 0-4   total = code length + number of value bits (1..31); 0 = "code longer than kHuffFastBits": bits 5-15 hold the
-//              pool offset / 64 of the second-level table, indexed by the next kHuffSubBits bits
+//   bits 0-4   total = code length + number of value bits (1..31)
 //   bits 5-8   nb = number of value bits (size category)
 //   bits 9-15  zadv = how far the zigzag position advances: 1 for a DC symbol, run + 1 for a coefficient, 16 for ZRL,
 //              64 for EOB (any value that takes the position past 63 ends the block)
-// "No such code" is total = 1, nb = 15 (impossible for a real symbol), zadv = 1.
+// "Code longer than kHuffFastBits" is zadv = 127 with bits 0-8 = pool offset / 64 of the second-level table, indexed by
+// the next kHuffSubBits bits: it trips the same "position past 63" test as the end of a block, so the common path has one
+// test for both.  "No such code" is total = 1, nb = 15 (impossible for a real symbol), zadv = 1.
 HJ_HD constexpr uint32_t make_entry(uint32_t total, uint32_t nb, uint32_t zadv) { return total | (nb << 5) | (zadv << 9); }
 constexpr uint32_t kEntryInvalid = 1u | (15u << 5) | (1u << 9);
+constexpr uint32_t kZadvLong = 127;
 
 // One block position k inside the MCU (k < blocks_per_mcu <= 10).
 struct HuffK {
@@ -132,10 +134,41 @@ struct HuffCursor {
     int16_t* blk;  // nullptr = past the last block of the scan
 };
 
+// MSB-first bit reader over 32-bit words fetched through Env::word(index): `hi` always holds the next 32 bits of the stream
+// (a symbol is at most 16 code + 15 value bits), `lo` the bits behind them.  The word that may be needed next is requested
+// at the top of every step, before the table lookup, so that its latency overlaps the lookup instead of preceding it.
+struct BitReader {
+    uint32_t hi, lo;
+    uint32_t nbits;  // valid bits in hi:lo, 32 <= nbits <= 64 between steps
+    uint32_t next;   // index of the next word to fetch
+    template <class Env>
+    HJ_HD void start(const Env& env, uint32_t pos)
+    {
+        const uint32_t i = pos >> 5, sh = pos & 31;
+        const uint32_t w0 = env.word(i), w1 = env.word(i + 1);
+        hi = (w0 << sh) | ((w1 >> 1) >> (sh ^ 31));
+        lo = w1 << sh;
+        nbits = 64 - sh;
+        next = i + 2;
+    }
+    // drops c (1..31) bits and, when fewer than 32 remain, appends `fetched` (= word `next`)
+    HJ_HD void consume(uint32_t c, uint32_t fetched)
+    {
+        hi = (hi << c) | (lo >> (32 - c));
+        lo <<= c;
+        nbits -= c;
+        const bool need = nbits < 32;  // then 1 <= nbits <= 31 and lo is empty
+        hi |= need ? fetched >> (nbits & 31) : 0u;
+        lo = need ? fetched << ((32 - nbits) & 31) : lo;
+        nbits += need ? 32u : 0u;
+        next += need ? 1u : 0u;
+    }
+};
+
 // Synchronisation decode: the symbols that START in [begin, limit) (and before total_bits), beginning in state (z, k).
 // Tracks the decoder state and counts the blocks completed; nothing is stored.
 // Env supplies the memory accessors:
-//   uint32_t window(uint32_t pos)        the 32 stream bits starting at bit `pos`, MSB first
+//   uint32_t word(uint32_t i)            32-bit word i of the stream, first byte in the most significant position
 //   uint32_t tables(int k)               tdc | tac << 16 for block position k: where the first-level tables are, in whatever
 //                                        unit lookup1 wants
 //   uint32_t lookup1(uint32_t t, w)      first-level entry of table t for window w (index = top kHuffFastBits bits)
@@ -148,20 +181,28 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
     const int bpm = (int)im.blocks_per_mcu;
     uint32_t tsel = env.tables(k);
     uint32_t tcur = z == 0 ? (tsel & 0xFFFFu) : (tsel >> 16);  // table of the next symbol: DC at the start of a block, AC after it
+    BitReader br;
+    br.start(env, pos);
     while (pos < end) {
-        const uint32_t w = env.window(pos);
-        uint32_t e = env.lookup1(tcur, w);
-        if ((e & 31u) == 0) e = env.lookup2(e, w);
-        pos += e & 31u;
-        z += (int)(e >> 9);
+        const uint32_t fetched = env.word(br.next);
+        uint32_t e = env.lookup1(tcur, br.hi);
         tcur = tsel >> 16;
-        if (z >= 64) {
-            z = 0;
-            nblocks++;
-            if (++k == bpm) k = 0;
-            tsel = env.tables(k);
-            tcur = tsel & 0xFFFFu;
+        z += (int)(e >> 9);
+        if (z >= 64) {  // end of a block, or a code that continues in a second-level table
+            if ((e >> 9) == kZadvLong) {
+                e = env.lookup2(e, br.hi);
+                z += (int)(e >> 9) - (int)kZadvLong;
+            }
+            if (z >= 64) {
+                z = 0;
+                nblocks++;
+                if (++k == bpm) k = 0;
+                tsel = env.tables(k);
+                tcur = tsel & 0xFFFFu;
+            }
         }
+        pos += e & 31u;
+        br.consume(e & 31u, fetched);
     }
     SubseqState st;
     st.end_bit = pos;
@@ -178,9 +219,9 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
 // Env additionally supplies:
 //   int16_t* block_ptr(int k, mx, my)    address of the block at position k of MCU (mx, my)
 //   int      zigzag(int z)               device-layout index of zigzag position z
-//   void     put(int index, int value)   store into the (zero-initialised) block buffer
-//   void     put_dc(block, int value)    store the DC difference of scan-order block `block`
-//   void     flush(int16_t* dst)         copy the block buffer to dst and zero it again
+//   void     put(int index, int value)   store into the (zero-initialised) block buffer; index 64 = the DC difference
+//   void     flush(int16_t* dst, block)  copy the 64 coefficients to dst and the DC difference to dc_diff[block] (scan-order
+//                                        block index), zero the buffer again
 // `cur` is the cursor of the block that contains the first symbol.
 template <class Env>
 HJ_HD void write_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, HuffCursor cur, uint32_t* error)
@@ -191,14 +232,19 @@ HJ_HD void write_subsequence(const HuffGeom& im, const Env& env, uint32_t begin,
     uint32_t tsel = env.tables(k);
     uint32_t tcur = z == 0 ? (tsel & 0xFFFFu) : (tsel >> 16);
     bool own = z == 0;
+    uint32_t err = 0;
+    BitReader br;
+    br.start(env, pos);
     while (pos < im.total_bits && (pos < end || (own && z != 0))) {
-        const uint32_t w = env.window(pos);
+        const uint32_t fetched = env.word(br.next);
+        const uint32_t w = br.hi;
         const bool is_dc = z == 0;
         uint32_t e = env.lookup1(tcur, w);
-        if ((e & 31u) == 0) e = env.lookup2(e, w);
+        if ((e >> 9) == kZadvLong) e = env.lookup2(e, w);
         const uint32_t total = e & 31u, zadv = e >> 9;
         {
-            // straight-line arithmetic, predicated stores: lanes of a wave sit at unrelated points of their blocks
+            // straight-line arithmetic and ONE predicated store: lanes of a wave sit at unrelated points of their blocks.
+            // The DC difference travels in slot 64 of the block buffer and leaves with the flush.
             const bool live = own && cur.blk != nullptr;
             const uint32_t nb_raw = (e >> 5) & 15u;
             const bool bad_code = nb_raw >= total;  // "no such code"
@@ -208,15 +254,15 @@ HJ_HD void write_subsequence(const HuffGeom& im, const Env& env, uint32_t begin,
             const int val = v < ((1u << nb) >> 1) ? (int)v - (int)(1u << nb) + 1 : (int)v;
             const uint32_t zpos = (uint32_t)z + zadv - 1;
             const bool ac = !is_dc && nb != 0;
-            if (live && (bad_code || (ac && zpos > 63))) *error = 1;  // invalid code / run past the end of the block
-            if (live && is_dc) env.put_dc(cur.block, val);
-            if (live && ac && zpos <= 63) env.put(env.zigzag((int)zpos), val);
+            err |= (uint32_t)(live & (bad_code | (ac & (zpos > 63))));  // invalid code / run past the end of the block
+            if (live & (is_dc | (ac & (zpos <= 63)))) env.put(is_dc ? 64 : env.zigzag((int)(zpos & 63)), val);
         }
         pos += total;
+        br.consume(total, fetched);
         z += (int)zadv;
         tcur = tsel >> 16;
         if (z >= 64) {
-            if (own && cur.blk) env.flush(cur.blk);
+            if (own && cur.blk) env.flush(cur.blk, cur.block);
             own = true;  // whatever starts now starts inside the lane's range, or the loop ends
             z = 0;
             if (++k == bpm) k = 0;
@@ -230,6 +276,7 @@ HJ_HD void write_subsequence(const HuffGeom& im, const Env& env, uint32_t begin,
             cur.blk = cur.my < im.mcus_y ? env.block_ptr(k, cur.mx, cur.my) : nullptr;
         }
     }
+    if (err) *error = 1;
 }
 
 // Cursor for the block with scan-order index `block` whose position inside the MCU is k.
