@@ -130,7 +130,15 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, voi
 /* One kernel family of the device stage at a time (0 = idct_plane, 1 = luma_color, 2 = generic_color, 3 = GPU entropy stage),
  * so a caller can bracket each with events.  hipjpegDecodeBatchDevice == entropy (if any image uses it), then 0, 1, 2. */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handle, int which, void* stream);
-/* Final per-image statuses of the current batch (after the device stage they include what the GPU entropy stage found). */
+/* Pipelined submission.  Submit = host stage + H2D copy (on an internal copy stream) + every kernel on `stream`, without
+ * waiting for anything on the device; at most two batches may be in flight (the handle's two staging pages).  Wait = block
+ * until the OLDEST submitted batch has finished and return its final per-image statuses.  The host stage of batch n+1 and
+ * its H2D copy overlap the kernels of batch n.  Outputs and `data` of a submitted batch must stay valid until its Wait. */
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
+                                                     const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags, void* stream);
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size);
+/* Final per-image statuses of the current batch (after the device stage they include what the GPU entropy stage found;
+ * blocks until that stage has reported). */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchGetStatuses(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size);
 /* GPU entropy stage statistics: images that used it, kernel launches the last synchronisation needed, destuffed bytes. */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchEntropyStats(hipjpegHandle_t handle, int32_t* gpu_images, int32_t* sync_launches,

@@ -99,6 +99,7 @@ DecodeBatch::DecodeBatch(int device_id, const MemoryHooks* hooks)
 
 DecodeBatch::~DecodeBatch()
 {
+    if (copied_event_) (void)hipEventDestroy((hipEvent_t)copied_event_);
     if (done_event_) {
         if (in_flight_) (void)hipEventSynchronize((hipEvent_t)done_event_);
         (void)hipEventDestroy((hipEvent_t)done_event_);
@@ -160,6 +161,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     const bool fancy = (flags & HIPJPEG_FLAG_FANCY_UPSAMPLING) != 0;
     const bool want_gpu_entropy = (flags & HIPJPEG_FLAG_GPU_HUFFMAN) != 0;
     entropy_done_ = false;
+    entropy_pending_ = false;  // a caller that re-plans without resolve() gives up the statuses of the previous batch
     huff_images_.clear();
     huff_to_image_.clear();
 
@@ -499,13 +501,23 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
     finalized_ = true;
 }
 
-hipjpegStatus_t DecodeBatch::transfer(void* stream)
+hipjpegStatus_t DecodeBatch::transfer(void* stream, bool kernels_on_other_stream)
 {
     if (!finalized_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     entropy_done_ = false;
+    pixels_launched_ = false;
     if (h2d_bytes_ == 0) return HIPJPEG_STATUS_SUCCESS;
     // only descriptors, bitstreams of GPU-decoded images and coefficients of host-decoded images cross PCIe
     hipError_t e = hipMemcpyAsync(device_.data(), pinned_.data(), h2d_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess && kernels_on_other_stream) {
+        if (!copied_event_) {
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+            copied_event_ = ev;
+        }
+        e = hipEventRecord((hipEvent_t)copied_event_, (hipStream_t)stream);
+        copy_pending_ = true;
+    }
     return e == hipSuccess ? HIPJPEG_STATUS_SUCCESS : HIPJPEG_STATUS_HIP_ERROR;
 }
 
@@ -516,41 +528,80 @@ hipjpegStatus_t DecodeBatch::transfer(void* stream)
 // it is not zero -- a correction crossed a whole workgroup -- more launches follow and the write passes are repeated.
 // Blocks at the end: the host needs the per-image status to fall back to its own entropy decoder for streams the kernels
 // flagged (corrupt or truncated data).
-hipjpegStatus_t DecodeBatch::run_gpu_entropy(void* stream)
+// Everything of the entropy stage that needs no answer from the device: enqueued, not waited for.
+hipjpegStatus_t DecodeBatch::enqueue_gpu_entropy(void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    if (huff_units_.empty()) {
-        entropy_done_ = true;
-        return HIPJPEG_STATUS_SUCCESS;
-    }
-    HuffImage* dimg = reinterpret_cast<HuffImage*>(device_.data() + huff_desc_offset_);
-    const HuffUnit* dunits = reinterpret_cast<const HuffUnit*>(device_.data() + huff_units_offset_);
-    const HuffUnit* ddc = reinterpret_cast<const HuffUnit*>(device_.data() + huff_dc_units_offset_);
-    const uint32_t* dlist = reinterpret_cast<const uint32_t*>(device_.data() + huff_list_offset_);
-    unsigned long long* states = reinterpret_cast<unsigned long long*>(work_.data());
-    uint32_t* first_block = reinterpret_cast<uint32_t*>(work_.data() + work_first_block_);
-    unsigned int* changed = reinterpret_cast<unsigned int*>(work_.data() + work_changed_);
-    unsigned long long* incoming = reinterpret_cast<unsigned long long*>(work_.data() + work_incoming_);
-    const unsigned pool_bytes = (unsigned)align_up(max_pool_words_ * 2, 256);
-    const int nunits = (int)huff_units_.size();
-    unsigned int* host_changed = reinterpret_cast<unsigned int*>(pinned_.data() + h2d_bytes_);  // 256 spare bytes behind the staged data
-    const HuffUnit* dwunits = reinterpret_cast<const HuffUnit*>(device_.data() + huff_wunits_offset_);
-    auto write_passes = [&]() -> bool {
-        return launch_huff_scan(dimg, dlist, (int)huff_list_.size(), states, first_block, stream) == 0 &&
-               launch_huff_write(dimg, dwunits, (int)huff_wunits_.size(), states, first_block, pool_bytes, stream) == 0 &&
-               launch_huff_dc(dimg, ddc, (int)huff_dc_units_.size(), stream) == 0;
-    };
-    if (hipMemsetAsync(changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-    if (launch_destuff(dimg, reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(),
+    entropy_done_ = true;
+    if (huff_units_.empty()) return HIPJPEG_STATUS_SUCCESS;
+    EntropyLaunch L = entropy_launch_args();
+    if (hipMemsetAsync(L.changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_destuff(L.dimg, reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(),
                        reinterpret_cast<uint32_t*>(work_.data() + work_drops_), stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
-    if (launch_huff_sync(dimg, dunits, nunits, states, incoming, changed, 1, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
-    if (launch_huff_sync(dimg, dunits, nunits, states, incoming, changed, 0, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
-    if (!write_passes()) return HIPJPEG_STATUS_HIP_ERROR;
-    if (hipMemcpyAsync(host_changed, changed, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-    HuffImage* himg = reinterpret_cast<HuffImage*>(pinned_.data() + huff_desc_offset_);
-    if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-    if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 1, L.pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 0, L.pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (!entropy_write_passes(L, stream)) return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipMemcpyAsync(L.host_changed, L.changed, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipMemcpyAsync(L.himg, L.dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    entropy_pending_ = true;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+DecodeBatch::EntropyLaunch DecodeBatch::entropy_launch_args()
+{
+    EntropyLaunch L;
+    L.dimg = reinterpret_cast<HuffImage*>(device_.data() + huff_desc_offset_);
+    L.dunits = reinterpret_cast<const HuffUnit*>(device_.data() + huff_units_offset_);
+    L.dwunits = reinterpret_cast<const HuffUnit*>(device_.data() + huff_wunits_offset_);
+    L.ddc = reinterpret_cast<const HuffUnit*>(device_.data() + huff_dc_units_offset_);
+    L.dlist = reinterpret_cast<const uint32_t*>(device_.data() + huff_list_offset_);
+    L.states = reinterpret_cast<unsigned long long*>(work_.data());
+    L.first_block = reinterpret_cast<uint32_t*>(work_.data() + work_first_block_);
+    L.changed = reinterpret_cast<unsigned int*>(work_.data() + work_changed_);
+    L.incoming = reinterpret_cast<unsigned long long*>(work_.data() + work_incoming_);
+    L.pool_bytes = (unsigned)align_up(max_pool_words_ * 2, 256);
+    L.nunits = (int)huff_units_.size();
+    L.host_changed = reinterpret_cast<unsigned int*>(pinned_.data() + h2d_bytes_);  // 256 spare bytes behind the staged data
+    L.himg = reinterpret_cast<HuffImage*>(pinned_.data() + huff_desc_offset_);
+    return L;
+}
+
+bool DecodeBatch::entropy_write_passes(const EntropyLaunch& L, void* stream)
+{
+    return launch_huff_scan(L.dimg, L.dlist, (int)huff_list_.size(), L.states, L.first_block, stream) == 0 &&
+           launch_huff_write(L.dimg, L.dwunits, (int)huff_wunits_.size(), L.states, L.first_block, L.pool_bytes, stream) == 0 &&
+           launch_huff_dc(L.dimg, L.ddc, (int)huff_dc_units_.size(), stream) == 0;
+}
+
+hipjpegStatus_t DecodeBatch::wait_done()
+{
+    if (!in_flight_) return HIPJPEG_STATUS_SUCCESS;
+    return hipEventSynchronize((hipEvent_t)done_event_) == hipSuccess ? HIPJPEG_STATUS_SUCCESS : HIPJPEG_STATUS_HIP_ERROR;
+}
+
+// Waits for the work enqueued on `stream` and settles what the entropy kernels reported: extra synchronisation launches if
+// a correction crossed a whole workgroup, host entropy decoding for streams the kernels flagged (corrupt or truncated
+// data) -- after either, the pixel kernels run again.  Per-image statuses are final afterwards.
+hipjpegStatus_t DecodeBatch::resolve(void* stream)
+{
+    if (!entropy_pending_) return HIPJPEG_STATUS_SUCCESS;
+    hipStream_t s = (hipStream_t)stream;
+    // wait for THIS batch's work only (a later batch may already be queued on the same stream)
+    if (in_flight_ ? hipEventSynchronize((hipEvent_t)done_event_) != hipSuccess : hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    entropy_pending_ = false;
+    EntropyLaunch L = entropy_launch_args();
+    HuffImage* dimg = L.dimg;
+    const HuffUnit* dunits = L.dunits;
+    unsigned long long* states = L.states;
+    unsigned long long* incoming = L.incoming;
+    unsigned int* changed = L.changed;
+    unsigned int* host_changed = L.host_changed;
+    HuffImage* himg = L.himg;
+    const unsigned pool_bytes = L.pool_bytes;
+    const int nunits = L.nunits;
+    bool redo_pixels = false;
+    auto write_passes = [&]() -> bool { return entropy_write_passes(L, stream); };
     last_sync_launches_ = 2;
     sync_rounds_total_ = host_changed[2];
     sync_rounds_max_ = host_changed[3];
@@ -575,6 +626,7 @@ hipjpegStatus_t DecodeBatch::run_gpu_entropy(void* stream)
             if (!write_passes()) return HIPJPEG_STATUS_HIP_ERROR;
             if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
             if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+            redo_pixels = true;
         }
     }
     for (size_t g = 0; g < huff_images_.size(); g++) {
@@ -604,9 +656,41 @@ hipjpegStatus_t DecodeBatch::run_gpu_entropy(void* stream)
                 hipMemcpy(work_.data() + work_dc_diff_ + im.dc_plane_offset[c], dc.data(), nblk * 2, hipMemcpyHostToDevice) != hipSuccess)
                 return HIPJPEG_STATUS_HIP_ERROR;
         }
+        redo_pixels = true;
     }
-    entropy_done_ = true;
+    if (redo_pixels && pixels_launched_) {
+        // the pixel kernels already ran on coefficients that have just been replaced
+        if (launch_pixel_kernels(stream, -1) != 0 || hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    }
     return HIPJPEG_STATUS_SUCCESS;
+}
+
+int DecodeBatch::launch_pixel_kernels(void* stream, int which)
+{
+    const DecodeImage* dimg = reinterpret_cast<const DecodeImage*>(device_.data() + desc_offset_);
+    auto units_at = [&](size_t off) { return reinterpret_cast<const WorkUnit*>(device_.data() + off); };
+    static const int hs[kNumLumaVariants] = {0, 1, 2, 2, 1}, vs[kNumLumaVariants] = {0, 1, 1, 2, 2};
+    static const bool debug_sync = getenv("HIPJPEG_DEBUG_SYNC") != nullptr;
+    auto check = [&](const char* what, int n) {
+        if (!debug_sync) return;
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        fprintf(stderr, "[hipjpeg] %s units=%d -> %s\n", what, n, hipGetErrorString(e));
+    };
+    int rc = 0;
+    for (int e = 0; e < 2 && rc == 0 && (which < 0 || which == 0); e++) {
+        rc = launch_idct_plane(e == 1, dimg, units_at(unit_off_plane_[e]), (int)plane_units_[e].size(), stream);
+        check("idct_plane", (int)plane_units_[e].size());
+    }
+    for (int e = 0; e < 2; e++)
+        for (int k = 0; k < kNumLumaVariants && rc == 0 && (which < 0 || which == 1); k++) {
+            rc = launch_luma_color(e == 1, hs[k], vs[k], dimg, units_at(unit_off_luma_[e][k]), (int)luma_units_[e][k].size(), stream);
+            check("luma_color", (int)luma_units_[e][k].size());
+        }
+    if (rc == 0 && (which < 0 || which == 2)) {
+        rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
+        check("generic_color", (int)generic_units_.size());
+    }
+    return rc;
 }
 
 hipjpegStatus_t DecodeBatch::launch(void* stream, int which)
@@ -635,26 +719,19 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which)
                 device_.capacity(), (void*)planes_.data(), planes_.capacity(), unit_off_plane_[0], unit_off_generic_, coef_offset_, staging_bytes_);
         check("transfer", 0);
     }
-    int rc = 0;
+    last_stream_ = stream;
+    if (copied_event_ && copy_pending_) {
+        // the H2D copy went out on another stream: the kernels wait for it on the device, the host does not
+        if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)copied_event_, 0) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        copy_pending_ = false;
+    }
     if ((which < 0 && !entropy_done_) || which == 3) {
-        hipjpegStatus_t es = run_gpu_entropy(stream);
+        hipjpegStatus_t es = enqueue_gpu_entropy(stream);
         if (es != HIPJPEG_STATUS_SUCCESS) return es;
-        if (which == 3) return HIPJPEG_STATUS_SUCCESS;
+        if (which == 3) return resolve(stream);
     }
-    for (int e = 0; e < 2 && rc == 0 && (which < 0 || which == 0); e++) {
-        rc = launch_idct_plane(e == 1, dimg, units_at(unit_off_plane_[e]), (int)plane_units_[e].size(), stream);
-        check("idct_plane", (int)plane_units_[e].size());
-    }
-    for (int e = 0; e < 2; e++)
-        for (int k = 0; k < kNumLumaVariants && rc == 0 && (which < 0 || which == 1); k++) {
-            rc = launch_luma_color(e == 1, hs[k], vs[k], dimg, units_at(unit_off_luma_[e][k]), (int)luma_units_[e][k].size(), stream);
-            check("luma_color", (int)luma_units_[e][k].size());
-        }
-    if (rc == 0 && (which < 0 || which == 2)) {
-        rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
-        check("generic_color", (int)generic_units_.size());
-    }
-    if (rc != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_pixel_kernels(stream, which) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (which < 0) pixels_launched_ = true;
     if (!done_event_) {
         hipEvent_t ev;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;

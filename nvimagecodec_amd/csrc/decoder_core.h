@@ -86,10 +86,18 @@ public:
     // Phase 1b: after every entropy_stage returned: final per-image flags, drop failed images from the unit tables.
     void finalize(hipjpegStatus_t* statuses);
     // Phase 2: one async H2D copy of descriptors + coefficients.
-    hipjpegStatus_t transfer(void* stream);
+    // kernels_on_other_stream: the copy is issued on a stream of its own; launch() then makes the kernels' stream wait for
+    // it on the device (copy of batch n+1 overlaps the kernels of batch n)
+    hipjpegStatus_t transfer(void* stream, bool kernels_on_other_stream = false);
     // Phase 3: kernel launches.  which = -1: all; 0 idct_plane, 1 luma_color (every variant), 2 generic_color,
     // 3 GPU entropy stage (blocks until its result status has been read back).
     hipjpegStatus_t launch(void* stream, int which = -1);
+    // After launch(): waits for `stream` and settles the GPU entropy stage's verdicts (see decoder_core.cpp); image(i).status
+    // is final afterwards.  A no-op for batches without GPU-decoded streams.
+    hipjpegStatus_t resolve(void* stream);
+    // Blocks until the kernels of the last launch() have finished (the event recorded behind them).
+    hipjpegStatus_t wait_done();
+    void* last_stream() const { return last_stream_; }
     int gpu_entropy_images() const { return (int)huff_images_.size(); }
     int last_sync_launches() const { return last_sync_launches_; }
     uint64_t stream_bytes() const { return stream_bytes_total_; }
@@ -110,7 +118,24 @@ private:
     uint64_t coef_bytes_ = 0, output_bytes_ = 0;
     bool finalized_ = false;
     // ---- GPU entropy stage
-    hipjpegStatus_t run_gpu_entropy(void* stream);
+    struct EntropyLaunch {
+        HuffImage* dimg;
+        const HuffUnit *dunits, *dwunits, *ddc;
+        const uint32_t* dlist;
+        unsigned long long *states, *incoming;
+        uint32_t* first_block;
+        unsigned int *changed, *host_changed;
+        HuffImage* himg;
+        unsigned pool_bytes;
+        int nunits;
+    };
+    EntropyLaunch entropy_launch_args();
+    bool entropy_write_passes(const EntropyLaunch& L, void* stream);
+    hipjpegStatus_t enqueue_gpu_entropy(void* stream);
+    int launch_pixel_kernels(void* stream, int which);
+    bool entropy_pending_ = false, pixels_launched_ = false, copy_pending_ = false;
+    void* last_stream_ = nullptr;  // stream of the last launch()
+    void* copied_event_ = nullptr;  // hipEvent_t: H2D copy issued on a stream other than the kernels' 
     Buffer work_;  // device only: subsequence states, first-block indices, change counter
     std::vector<HuffImage> huff_images_;
     std::vector<HuffUnit> huff_units_, huff_dc_units_;

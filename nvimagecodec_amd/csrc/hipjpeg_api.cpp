@@ -28,6 +28,11 @@ struct hipjpegHandle {
     std::unique_ptr<DecodeBatch> batches[2];
     int current = 0;
     DecodeBatch& cur() { return *batches[current]; }
+    // pipelined submission (hipjpegDecodeBatchSubmit / Wait): pages in flight, oldest first, with the stream each runs on
+    int submitted[2] = {-1, -1};
+    void* submitted_stream[2] = {nullptr, nullptr};
+    int num_submitted = 0;
+    hipStream_t copy_stream = nullptr;  // H2D copies of submitted batches: they overlap the kernels of the batch before
     std::unique_ptr<EncodeBatch> encode;
 };
 
@@ -148,6 +153,7 @@ hipjpegStatus_t hipjpegDestroy(hipjpegHandle_t handle)
 {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     (void)hipSetDevice(handle->device_id);
+    if (handle->copy_stream) (void)hipStreamDestroy(handle->copy_stream);
     delete handle;
     return HIPJPEG_STATUS_SUCCESS;
 }
@@ -209,15 +215,54 @@ hipjpegStatus_t hipjpegDecodeBatch(hipjpegHandle_t handle, const uint8_t* const*
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     if ((st = hipjpegDecodeBatchTransfer(handle, stream)) != HIPJPEG_STATUS_SUCCESS) return st;
     st = hipjpegDecodeBatchDevice(handle, stream);
-    // the GPU entropy stage may have found problems the host never looked at (it only destuffed those streams)
+    // the GPU entropy stage may have found problems the host never looked at: wait for its verdicts (batches without
+    // GPU-decoded streams return without waiting)
+    if (st == HIPJPEG_STATUS_SUCCESS) st = handle->cur().resolve(stream);
     if (statuses)
         for (int i = 0; i < batch_size; i++) statuses[i] = handle->cur().image(i).status;
+    return st;
+}
+
+hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
+                                         const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags, void* stream)
+{
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if (handle->num_submitted >= 2) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // both pages in flight: Wait first
+    if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
+    if (!handle->copy_stream && hipStreamCreateWithFlags(&handle->copy_stream, hipStreamNonBlocking) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    hipjpegStatus_t st = hipjpegDecodeBatchHost(handle, data, lengths, batch_size, outputs, format, flags, nullptr);
+    if (st != HIPJPEG_STATUS_SUCCESS) return st;
+    DecodeBatch& b = handle->cur();
+    if ((st = b.transfer(handle->copy_stream, true)) != HIPJPEG_STATUS_SUCCESS) return st;
+    if ((st = b.launch(stream)) != HIPJPEG_STATUS_SUCCESS) return st;
+    handle->submitted[handle->num_submitted] = handle->current;
+    handle->submitted_stream[handle->num_submitted] = stream;
+    handle->num_submitted++;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegDecodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size)
+{
+    if (!handle || handle->num_submitted == 0) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    DecodeBatch& b = *handle->batches[handle->submitted[0]];
+    void* stream = handle->submitted_stream[0];
+    if (statuses && batch_size != b.size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    handle->submitted[0] = handle->submitted[1];
+    handle->submitted_stream[0] = handle->submitted_stream[1];
+    handle->num_submitted--;
+    if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
+    hipjpegStatus_t st = b.wait_done();
+    if (st == HIPJPEG_STATUS_SUCCESS) st = b.resolve(stream);
+    if (statuses)
+        for (int i = 0; i < batch_size; i++) statuses[i] = b.image(i).status;
     return st;
 }
 
 hipjpegStatus_t hipjpegDecodeBatchGetStatuses(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size)
 {
     if (!handle || !statuses || batch_size != handle->cur().size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    hipjpegStatus_t st = handle->cur().resolve(handle->cur().last_stream());
+    if (st != HIPJPEG_STATUS_SUCCESS) return st;
     for (int i = 0; i < batch_size; i++) statuses[i] = handle->cur().image(i).status;
     return HIPJPEG_STATUS_SUCCESS;
 }

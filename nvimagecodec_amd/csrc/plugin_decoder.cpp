@@ -284,6 +284,9 @@ void HipJpegDecoder::finish(Job* job)
     job->batch.finalize(job->statuses.data());
     if (gpu_ok) gpu_ok = job->batch.transfer(stream_) == HIPJPEG_STATUS_SUCCESS;
     if (gpu_ok) gpu_ok = job->batch.launch(stream_) == HIPJPEG_STATUS_SUCCESS;
+    // GPU-decoded streams: their verdicts come back from the device (blocks; the other job page keeps the host stage of
+    // the next batch going meanwhile).  Batches that went through the host entropy stage only do not wait here.
+    if (gpu_ok) gpu_ok = job->batch.resolve(stream_) == HIPJPEG_STATUS_SUCCESS;
     if (gpu_ok) gpu_ok = hipEventRecord(job->event, stream_) == hipSuccess;
     for (int i = 0; i < n; i++) job->statuses[i] = job->batch.image(i).status;  // incl. what the GPU entropy stage reported
     release_inputs(job);

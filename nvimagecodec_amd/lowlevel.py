@@ -80,6 +80,7 @@ class BatchDecoder:
         if st:
             raise N.HipJpegError(st, "hipjpegCreate")
         self._keep = None
+        self._inflight = []
 
     def close(self):
         if self._h:
@@ -162,6 +163,29 @@ class BatchDecoder:
                 if s:
                     raise N.HipJpegError(s, f"image {i}")
         return outs, statuses
+
+    # -- pipelined: submit() returns once everything is queued; wait() returns the statuses of the oldest submitted batch.
+    #    At most two batches in flight.  The caller keeps jpegs and outs alive until the matching wait().
+    def submit(self, jpegs, outs, fmt="rgb", fancy=True, stream=None, gpu_huffman=True):
+        ptrs, lens, O, statuses = self._marshal(jpegs, outs, fmt)
+        flags = (N.FLAG_FANCY_UPSAMPLING if fancy else 0) | (N.FLAG_GPU_HUFFMAN if gpu_huffman else 0)
+        st = N.load().hipjpegDecodeBatchSubmit(self._h, ptrs, lens, len(jpegs), O, _FORMATS[fmt], flags, self._stream_ptr(stream))
+        if st:
+            raise N.HipJpegError(st, "hipjpegDecodeBatchSubmit")
+        self._inflight.append((len(jpegs), (ptrs, lens, O, jpegs, outs)))
+
+    def wait(self, check=True):
+        n, _keep = self._inflight.pop(0)
+        statuses = (ctypes.c_int32 * n)()
+        st = N.load().hipjpegDecodeBatchWait(self._h, statuses, n)
+        if st:
+            raise N.HipJpegError(st, "hipjpegDecodeBatchWait")
+        statuses = list(statuses)
+        if check:
+            for i, s in enumerate(statuses):
+                if s:
+                    raise N.HipJpegError(s, f"image {i}")
+        return statuses
 
     # -- the three phases separately (bench.py times device_stage with coefficients resident in HBM)
     def host_stage(self, jpegs, outs, fmt="rgb", fancy=True, gpu_huffman=False):

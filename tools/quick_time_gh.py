@@ -25,4 +25,16 @@ for rep in range(3):
         dec.decode(jpegs, outs=outs, gpu_huffman=True)
     torch.cuda.synchronize(); t1 = time.time()
     print("end-to-end decode(gpu_huffman): %.1f ms/batch %.0f img/s" % ((t1 - t0) / 3 * 1e3, 3 * B / (t1 - t0)), flush=True)
-ref = oracle.decode(src[1]); print("parity", np.array_equal(outs[1].cpu().numpy(), ref))
+# pipelined: two batches in flight, two output sets
+outs2 = dec.allocate_outputs(jpegs)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.time()
+    K = 8
+    for i in range(K):
+        dec.submit(jpegs, outs if i % 2 == 0 else outs2)
+        if i > 0:
+            dec.wait()
+    dec.wait()
+    torch.cuda.synchronize(); t1 = time.time()
+    print("pipelined submit/wait: %.1f ms/batch %.0f img/s" % ((t1 - t0) / K * 1e3, K * B / (t1 - t0)), flush=True)
+ref = oracle.decode(src[1]); print("parity2", np.array_equal(outs2[1].cpu().numpy(), ref)); print("parity", np.array_equal(outs[1].cpu().numpy(), ref))
