@@ -14,7 +14,7 @@ for k, d in agg.items():
         continue
     fetch = 2 * 1024 * sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1)
     write = 1024 * sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1)
-    out["kernels"][k.split("(")[0].strip()] = {"fetch_bytes": int(fetch), "write_bytes": int(write)}
+    out["kernels"][k.replace("(anonymous namespace)::", "").split("(")[0].strip()] = {"fetch_bytes": int(fetch), "write_bytes": int(write)}
     out["hbm_bytes_per_step"] += int(fetch + write)
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
