@@ -95,6 +95,14 @@ def main():
                 name = f"r130x70_{sub}_{'prog' if prog else 'base'}_rst{rb}"
                 add_decode(name, pil_encode(img, 90, sub, prog, restart_marker_blocks=rb), True, sub=sub, progressive=prog, quality=90,
                            restart=rb, encoder="pillow")
+    # --- optimized Huffman tables (image-specific code lengths: long codes, second-level lookups of the GPU entropy stage)
+    for (w, h, seed) in ((64, 48, 41), (130, 70, 42), (320, 200, 43)):
+        img = synth_image(w, h, seed=seed)
+        for sub in ("444", "420", "gray"):
+            for q in (75, 98):
+                name = f"h{w}x{h}_{sub}_opt_q{q}"
+                add_decode(name, pil_encode(img, q, sub, False, optimize=True), w <= 130, sub=sub, progressive=False, quality=q, restart=0,
+                           encoder="pillow", optimize=True)
     # --- samplings Pillow cannot write: inputs from the oracle's encoder, goldens still from libjpeg-turbo's decoder
     for sub in ("440", "411", "410"):
         for (w, h) in ((50, 37), (64, 48), (17, 13)):

@@ -47,3 +47,25 @@ def test_corrupt_and_truncated_streams_are_reported():
     with pytest.raises(N.HipJpegError) as ei:
         lowlevel.entropy_decode_gpu_algorithm_host(jpeg[: len(jpeg) * 2 // 3] + b"\xff\xd9")
     assert ei.value.status in (4, 5)
+
+
+def _with_fill_byte(jpeg):
+    """FF 00 inside the scan -> FF FF 00: a fill byte in front of a stuffed FF.  libjpeg-turbo skips fill bytes, so the
+    stream still decodes to the same coefficients -- but the GPU stage's plain 'drop the 00 after an FF' rule does not
+    cover it, so such streams must stay on the host entropy stage."""
+    info = lowlevel.get_image_info(jpeg)
+    sos = jpeg.rfind(b"\xff\xda")
+    i = jpeg.find(b"\xff\x00", sos + 14)
+    assert info["num_scans"] == 1 and i > 0
+    return jpeg[:i] + b"\xff" + jpeg[i:]
+
+
+def test_streams_with_fill_bytes_stay_on_the_host_stage():
+    jpeg = oracle.encode(synth_image(200, 120, seed=5), "420", 95)
+    odd = _with_fill_byte(jpeg)
+    with pytest.raises(N.HipJpegError) as ei:
+        lowlevel.entropy_decode_gpu_algorithm_host(odd)
+    assert ei.value.status == 3
+    a, _ = oracle.decode_coefficients(jpeg)
+    b = lowlevel.entropy_decode_host(odd)[0]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
