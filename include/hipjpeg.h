@@ -87,6 +87,18 @@ typedef struct {
     uint32_t pitch[3];  /* bytes per row */
 } hipjpegOutput_t;
 
+/* Optional per-image geometry: region of interest and EXIF orientation, applied on the device after decoding.
+ * The output buffer then holds the region (all zeros = whole image) of the decoded image, brought upright according to
+ * `orientation` (EXIF tag 0x0112 values 1..8; 0 or 1 = leave as stored): its size is (x1-x0) x (y1-y0), swapped for
+ * orientations 5..8.  Mirrors nvimgcodecImageInfo_t::region (ref include/nvimgcodec.h:446-455; crop semantics of
+ * extensions/libjpeg_turbo/jpeg_mem.cpp:206-240: exactly the pixels of the full decode) and nvimgcodecOrientation_t as the
+ * nvJPEG plugin applies it (ref extensions/nvjpeg/cuda_decoder.cpp:443-478, type_convert.cpp:43-64).
+ * Not available for HIPJPEG_OUTPUT_YUV_PLANAR (subsampled planes): such images report HIPJPEG_STATUS_UNSUPPORTED. */
+typedef struct {
+    int32_t x0, y0, x1, y1; /* region in stored-image coordinates, end exclusive */
+    int32_t orientation;    /* EXIF orientation 1..8 (0 = 1) */
+} hipjpegTransform_t;
+
 typedef struct hipjpegHandle* hipjpegHandle_t;
 
 HIPJPEG_API const char* hipjpegStatusString(hipjpegStatus_t status);
@@ -119,6 +131,10 @@ HIPJPEG_API hipjpegStatus_t hipjpegDestroy(hipjpegHandle_t handle);
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatch(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
                                                const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags,
                                                hipjpegStatus_t* statuses, void* stream);
+
+/* Geometry for the NEXT batch handed to hipjpegDecodeBatch / Host / Submit: `transforms` = batch_size entries (copied), or
+ * NULL to go back to plain decoding.  Consumed by that one batch. */
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchSetTransforms(hipjpegHandle_t handle, const hipjpegTransform_t* transforms, int batch_size);
 
 /* The three phases separately (what hipjpegDecodeBatch does internally); used by bench.py to time the device
  * stage with the coefficient blocks already resident in HBM. */

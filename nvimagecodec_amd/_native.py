@@ -38,6 +38,11 @@ class EncodeParams(ctypes.Structure):
 CSS = {"444": 0, "422": 1, "420": 2, "440": 3, "411": 4, "410": 5, "gray": 6}
 
 
+class Transform(ctypes.Structure):
+    """hipjpegTransform_t: region of interest (stored-image coordinates, end exclusive; all zero = whole image) + EXIF orientation"""
+    _fields_ = [("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32), ("orientation", ctypes.c_int32)]
+
+
 class Output(ctypes.Structure):
     _fields_ = [("plane", ctypes.c_void_p * 3), ("pitch", ctypes.c_uint32 * 3)]
 
@@ -69,6 +74,7 @@ def load():
     L.hipjpegDecodeBatchDeviceKernel.argtypes = [vp, i32, vp]
     L.hipjpegDecodeBatchStats.argtypes = [vp, vp, vp, vp]
     L.hipjpegDecodeBatchGetStatuses.argtypes = [vp, vp, i32]
+    L.hipjpegDecodeBatchSetTransforms.argtypes = [vp, vp, i32]
     L.hipjpegDecodeBatchSubmit.argtypes = [vp, vp, vp, i32, vp, i32, ctypes.c_uint, vp]
     L.hipjpegDecodeBatchWait.argtypes = [vp, vp, i32]
     L.hipjpegDecodeBatchEntropyStats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]

@@ -300,6 +300,9 @@ class Decoder(_ExecMixin):
             info = A.init(A.ImageInfo, A.ST_IMAGE_INFO)
             _check(lib.nvimgcodecCodeStreamGetImageInfo(cs, C.byref(info)), "nvimgcodecCodeStreamGetImageInfo")
             h, w = info.plane_info[0].height, info.plane_info[0].width
+            # python/decoder.cpp:202-205: a quarter-turn orientation swaps the output's width and height
+            if params.apply_exif_orientation and (info.orientation.rotated // 90) % 2:
+                h, w = w, h
             # python/decoder.cpp:179-225: interleaved RGB u8 (or gray), row_stride = w * channels, device buffer
             gray = params.color_spec == ColorSpec.GRAY or (params.color_spec == ColorSpec.UNCHANGED and info.num_planes == 1)
             ch = 1 if gray else 3

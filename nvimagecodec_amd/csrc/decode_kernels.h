@@ -13,5 +13,7 @@ int launch_idct_plane(bool exact, const DecodeImage* images, const WorkUnit* uni
 int launch_luma_color(bool exact, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K3: per-pixel colour stage from planes (replication upsampling) for uncommon sampling layouts.
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+// Geometry pass (region of interest + EXIF orientation): WorkUnit{image = TransformImage index, block_base = first output row}.
+int launch_transform(const TransformImage* images, const WorkUnit* units, int nunits, void* stream);
 
 }  // namespace hipjpeg

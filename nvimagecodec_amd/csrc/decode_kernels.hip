@@ -577,6 +577,49 @@ __global__ __launch_bounds__(kThreads) void generic_color_kernel(const DecodeIma
     }
 }
 
+
+// Geometry pass: region of interest + EXIF orientation (DecodeBatch plans it for the images that ask for it; the pixel
+// kernels have written those images into an intermediate buffer in stored-image coordinates).
+// Upright pixel (ox, oy) comes from region pixel (u, v):
+//   1: (ox, oy)            2: (rw-1-ox, oy)        3: (rw-1-ox, rh-1-oy)   4: (ox, rh-1-oy)
+//   5: (oy, ox)            6: (oy, rh-1-ox)        7: (rw-1-oy, rh-1-ox)   8: (rw-1-oy, ox)
+// (EXIF 2.32 orientation tag; 5 = transpose, 6 = stored picture must be turned 90 degrees clockwise, 7 = transverse,
+//  8 = 270 degrees clockwise).  One workgroup = kTransformRowsPerUnit output rows; lanes walk along output rows, so the
+// writes are coalesced whatever the reads look like.
+__global__ __launch_bounds__(kThreads) void transform_kernel(const TransformImage* __restrict__ images, const WorkUnit* __restrict__ units)
+{
+    const WorkUnit wu = units[blockIdx.x];
+    const TransformImage& t = images[wu.image];
+    const int rw = t.rw, rh = t.rh, ow = t.out_w, o = t.orientation;
+    const int row_end = min((int)wu.block_base + kTransformRowsPerUnit, t.out_h);
+    for (int oy = (int)wu.block_base; oy < row_end; oy++) {
+        for (int ox = threadIdx.x; ox < ow; ox += kThreads) {
+            int u, v;
+            switch (o) {
+            case 2: u = rw - 1 - ox; v = oy; break;
+            case 3: u = rw - 1 - ox; v = rh - 1 - oy; break;
+            case 4: u = ox; v = rh - 1 - oy; break;
+            case 5: u = oy; v = ox; break;
+            case 6: u = oy; v = rh - 1 - ox; break;
+            case 7: u = rw - 1 - oy; v = rh - 1 - ox; break;
+            case 8: u = rw - 1 - oy; v = ox; break;
+            default: u = ox; v = oy; break;
+            }
+            const int sx = t.x0 + u, sy = t.y0 + v;
+            if (t.bpp == 3) {
+                const uint8_t* s = t.src[0] + (size_t)sy * t.src_pitch[0] + (size_t)sx * 3;
+                uint8_t* d = t.dst[0] + (size_t)oy * t.dst_pitch[0] + (size_t)ox * 3;
+                d[0] = s[0];
+                d[1] = s[1];
+                d[2] = s[2];
+            } else {
+                for (int p = 0; p < t.nplanes; p++)
+                    t.dst[p][(size_t)oy * t.dst_pitch[p] + ox] = t.src[p][(size_t)sy * t.src_pitch[p] + sx];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int launch_idct_plane(bool exact, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
@@ -618,6 +661,13 @@ int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int n
 {
     if (nunits <= 0) return 0;
     hipLaunchKernelGGL(generic_color_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    return (int)hipGetLastError();
+}
+
+int launch_transform(const TransformImage* images, const WorkUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    hipLaunchKernelGGL(transform_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
     return (int)hipGetLastError();
 }
 

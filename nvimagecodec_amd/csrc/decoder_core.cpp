@@ -151,7 +151,7 @@ bool choose_variant(const FrameInfo& f, OutFormat fmt, bool fancy, int* variant)
 
 hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
                                   hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
-                                  const hipjpegOutputFormat_t* formats, ForkJoinPool* pool)
+                                  const hipjpegOutputFormat_t* formats, ForkJoinPool* pool, const hipjpegTransform_t* transforms)
 {
     if (n < 0 || (n > 0 && (!data || !lengths || !outputs))) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     if ((int)format < 0 || (int)format > (int)HIPJPEG_OUTPUT_YUV_PLANAR) return HIPJPEG_STATUS_INVALID_ARGUMENT;
@@ -165,7 +165,9 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     huff_images_.clear();
     huff_to_image_.clear();
 
-    size_t max_units = 0, coef_total = 0, plane_total = 0;
+    size_t max_units = 0, coef_total = 0, plane_total = 0, max_xform_units = 0;
+    std::vector<size_t> xform_plane_off;  // per TransformImage plane, in order
+    xform_desc_.clear();
     size_t huff_stream_total = 0, huff_subseq_ub = 0, huff_pool_total = 0, huff_blocks_total = 0, huff_raw_total = 0, huff_chunks_total = 0;
     max_huff_units_ = max_huff_wunits_ = 0;
     max_pool_words_ = 0;
@@ -188,6 +190,27 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
         if (im.status == HIPJPEG_STATUS_SUCCESS) {
             for (int p = 0; p < (fmt == kOutPlanarYUV ? f.ncomp : nplanes_out); p++)
                 if (!outputs[i].plane[p]) im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
+        }
+        if (im.status == HIPJPEG_STATUS_SUCCESS && transforms) {
+            // region of interest / EXIF orientation: normalise, validate (crop semantics of the reference's CPU path,
+            // extensions/libjpeg_turbo/libjpeg_turbo_decoder.cpp:355-370: the region must lie inside the image)
+            hipjpegTransform_t t = transforms[i];
+            if (t.x0 == 0 && t.y0 == 0 && t.x1 == 0 && t.y1 == 0) {
+                t.x1 = f.width;
+                t.y1 = f.height;
+            }
+            if (t.orientation == 0) t.orientation = 1;
+            const bool whole = t.x0 == 0 && t.y0 == 0 && t.x1 == f.width && t.y1 == f.height;
+            if (t.orientation < 1 || t.orientation > 8 || t.x0 < 0 || t.y0 < 0 || t.x1 > f.width || t.y1 > f.height || t.x1 <= t.x0 || t.y1 <= t.y0)
+                im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
+            else if (!(whole && t.orientation == 1)) {
+                if (fmt == kOutPlanarYUV)
+                    im.status = HIPJPEG_STATUS_UNSUPPORTED;  // geometry on subsampled planes is not defined
+                else {
+                    im.has_transform = true;
+                    im.transform = t;
+                }
+            }
         }
         if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && gpu_entropy_eligible(f)) {
             im.gpu_entropy = true;
@@ -218,6 +241,36 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
         for (int p = 0; p < 3; p++) {
             d.out[p] = static_cast<uint8_t*>(outputs[i].plane[p]);
             d.out_pitch[p] = outputs[i].pitch[p];
+        }
+        if (im.has_transform) {
+            // the pixel kernels write a full-frame intermediate picture (same format, 16-byte aligned rows); the geometry
+            // pass copies the region, turned upright, into the caller's buffer
+            const int np = (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR || fmt == kOutY) ? 1 : 3;
+            const int bpp = (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR) ? 3 : 1;
+            TransformImage t;
+            memset(&t, 0, sizeof t);
+            const uint32_t ipitch = (uint32_t)align_up((size_t)f.width * bpp, 16);
+            for (int p = 0; p < np; p++) {
+                t.dst[p] = static_cast<uint8_t*>(outputs[i].plane[p]);
+                t.dst_pitch[p] = outputs[i].pitch[p];
+                t.src_pitch[p] = ipitch;
+                d.out_pitch[p] = ipitch;
+                xform_plane_off.push_back(plane_total);
+                plane_total += align_up((size_t)ipitch * f.height + 16, 256);
+            }
+            t.x0 = im.transform.x0;
+            t.y0 = im.transform.y0;
+            t.rw = im.transform.x1 - im.transform.x0;
+            t.rh = im.transform.y1 - im.transform.y0;
+            const bool swap = im.transform.orientation >= 5;
+            t.out_w = swap ? t.rh : t.rw;
+            t.out_h = swap ? t.rw : t.rh;
+            t.orientation = im.transform.orientation;
+            t.nplanes = np;
+            t.bpp = bpp;
+            im.xform_index = (int)xform_desc_.size();
+            xform_desc_.push_back(t);
+            max_xform_units += (size_t)(t.out_h + kTransformRowsPerUnit - 1) / kTransformRowsPerUnit;
         }
         for (int c = 0; c < f.ncomp; c++) {
             const Component& k = f.comp[c];
@@ -293,7 +346,9 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     huff_dc_units_offset_ = align_up(huff_wunits_offset_ + sizeof(HuffUnit) * max_huff_wunits_, 256);
     huff_list_offset_ = align_up(huff_dc_units_offset_ + sizeof(HuffUnit) * ng * 4, 256);
     huff_chunk_units_offset_ = align_up(huff_list_offset_ + sizeof(uint32_t) * ng, 256);
-    const size_t tables_base = align_up(huff_chunk_units_offset_ + sizeof(HuffUnit) * huff_chunks_total, 256);
+    xform_desc_offset_ = align_up(huff_chunk_units_offset_ + sizeof(HuffUnit) * huff_chunks_total, 256);
+    xform_units_offset_ = align_up(xform_desc_offset_ + sizeof(TransformImage) * xform_desc_.size(), 256);
+    const size_t tables_base = align_up(xform_units_offset_ + sizeof(WorkUnit) * max_xform_units, 256);
     const size_t streams_base = align_up(tables_base + huff_pool_total, 256);
     coef_offset_ = align_up(streams_base + huff_raw_total, 256);
     for (int pass = 0; pass < 2; pass++) {  // host-decoded images first, GPU-decoded ones behind the H2D boundary
@@ -354,6 +409,18 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
                 d.comp[c].dc_stride = 64;
             }
             if (plane_off[(size_t)i * 4 + c] != (size_t)-1) d.comp[c].plane = planes_.data() + plane_off[(size_t)i * 4 + c];
+        }
+    }
+    {
+        size_t k = 0;
+        for (int i = 0; i < n; i++) {
+            if (images_[i].status != HIPJPEG_STATUS_SUCCESS || !images_[i].has_transform) continue;
+            TransformImage& t = xform_desc_[images_[i].xform_index];
+            for (int p = 0; p < t.nplanes; p++, k++) {
+                uint8_t* base = planes_.data() + xform_plane_off[k];
+                t.src[p] = base;
+                desc_[i].out[p] = base;
+            }
         }
     }
     if (statuses)
@@ -433,9 +500,15 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         }
         if (im.variant >= 0) {
             // luma tiles: 32 blocks wide x 4 block rows (one block row per wave); rows that are pure MCU padding are skipped
-            const uint32_t real_rows = (uint32_t)(f.height + 7) / 8;
-            for (uint32_t by = 0; by < real_rows; by += kLumaTileH)
-                for (uint32_t bx = 0; bx < (uint32_t)f.comp[0].blocks_w; bx += kLumaTileW)
+            uint32_t real_rows = (uint32_t)(f.height + 7) / 8, first_row = 0, first_col = 0, end_col = (uint32_t)f.comp[0].blocks_w;
+            if (im.has_transform) {  // tiles that do not touch the region of interest are not decoded
+                first_row = (uint32_t)im.transform.y0 / 8 / kLumaTileH * kLumaTileH;
+                real_rows = std::min(real_rows, (uint32_t)(im.transform.y1 + 7) / 8);
+                first_col = (uint32_t)im.transform.x0 / 8 / kLumaTileW * kLumaTileW;
+                end_col = std::min(end_col, (uint32_t)(im.transform.x1 + 7) / 8);
+            }
+            for (uint32_t by = first_row; by < real_rows; by += kLumaTileH)
+                for (uint32_t bx = first_col; bx < end_col; bx += kLumaTileW)
                     luma_units_[exact32][im.variant].push_back(WorkUnit{(uint32_t)i, bx, by, 0u});
         } else if (im.variant == -1) {
             for (int y = 0; y < f.height; y++) generic_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});
@@ -455,6 +528,16 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[e][k], &unit_off_luma_[e][k]);
     }
     put(generic_units_, &unit_off_generic_);
+    // geometry pass
+    xform_units_.clear();
+    for (int i = 0; i < n; i++) {
+        const PlannedImage& im = images_[i];
+        if (im.status != HIPJPEG_STATUS_SUCCESS || !im.has_transform) continue;
+        const TransformImage& t = xform_desc_[im.xform_index];
+        for (int oy = 0; oy < t.out_h; oy += kTransformRowsPerUnit) xform_units_.push_back(WorkUnit{(uint32_t)im.xform_index, (uint32_t)oy, 0u, 0u});
+    }
+    if (!xform_desc_.empty()) memcpy(base + xform_desc_offset_, xform_desc_.data(), sizeof(TransformImage) * xform_desc_.size());
+    if (!xform_units_.empty()) memcpy(base + xform_units_offset_, xform_units_.data(), sizeof(WorkUnit) * xform_units_.size());
 
     // GPU entropy descriptors: batch-wide subsequence numbering, one workgroup per 256 subsequences of an image
     huff_units_.clear();
@@ -689,6 +772,11 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
     if (rc == 0 && (which < 0 || which == 2)) {
         rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
         check("generic_color", (int)generic_units_.size());
+    }
+    if (rc == 0 && (which < 0 || which == 4)) {
+        rc = launch_transform(reinterpret_cast<const TransformImage*>(device_.data() + xform_desc_offset_),
+                              reinterpret_cast<const WorkUnit*>(device_.data() + xform_units_offset_), (int)xform_units_.size(), stream);
+        check("transform", (int)xform_units_.size());
     }
     return rc;
 }

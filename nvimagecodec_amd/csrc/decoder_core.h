@@ -63,6 +63,9 @@ struct PlannedImage {
     int huff_index = -1;          // index into the HuffImage array
     size_t stream_offset = 0;     // staging offsets of the destuffed stream and the 8 expanded tables
     size_t tables_offset = 0;
+    bool has_transform = false;  // region of interest and/or EXIF orientation (geometry pass)
+    hipjpegTransform_t transform = {0, 0, 0, 0, 1};
+    int xform_index = -1;
     size_t pool_words = 0;      // lookup-table entries of the scan (GPU entropy path)
     size_t raw_offset = 0;      // staged copy of the scan's entropy-coded bytes
     uint32_t first_chunk = 0;   // first destuff chunk (batch-wide numbering)
@@ -80,7 +83,8 @@ public:
     // `formats` (optional) gives one output format per image; otherwise `format` applies to all.
     hipjpegStatus_t plan(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
                          hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
-                         const hipjpegOutputFormat_t* formats = nullptr, ForkJoinPool* pool = nullptr);
+                         const hipjpegOutputFormat_t* formats = nullptr, ForkJoinPool* pool = nullptr,
+                         const hipjpegTransform_t* transforms = nullptr);
     // Phase 1: entropy-decode image i into the pinned staging area.  Thread-safe for distinct i.
     void entropy_stage(int i);
     // Phase 1b: after every entropy_stage returned: final per-image flags, drop failed images from the unit tables.
@@ -145,6 +149,9 @@ private:
     size_t gpu_coef_begin_ = 0, gpu_coef_bytes_ = 0, total_subseq_ = 0, max_huff_units_ = 0, max_pool_words_ = 0;
     size_t work_first_block_ = 0, work_changed_ = 0, work_incoming_ = 0, work_dc_diff_ = 0, work_drops_ = 0, work_streams_ = 0;
     size_t huff_chunk_units_offset_ = 0, huff_wunits_offset_ = 0, max_huff_wunits_ = 0;
+    std::vector<TransformImage> xform_desc_;
+    std::vector<WorkUnit> xform_units_;
+    size_t xform_desc_offset_ = 0, xform_units_offset_ = 0;
     std::vector<HuffUnit> huff_wunits_;  // write kernel: kHuffWriteOwn subsequences per workgroup
     std::vector<HuffUnit> huff_chunk_units_;  // offsets into work_
     uint64_t stream_bytes_total_ = 0;

@@ -72,6 +72,22 @@ enum PlaneUnitMode : uint32_t {
     kToOutput = 1,  // write into DecodeImage::out[mode>>8], cropped to samp_w x samp_h
 };
 
+// Geometry pass (region of interest + EXIF orientation): copies from the intermediate full-frame picture the pixel kernels
+// wrote into the caller's buffer.  One descriptor per transformed image; work units = (descriptor index, first output row).
+struct alignas(16) TransformImage {
+    const uint8_t* src[3];  // intermediate planes, addressed in stored-image coordinates
+    uint8_t* dst[3];
+    uint32_t src_pitch[3];
+    uint32_t dst_pitch[3];
+    int32_t x0, y0;         // region origin in the stored image
+    int32_t rw, rh;         // region size (before orientation)
+    int32_t out_w, out_h;   // output size (after orientation)
+    int32_t orientation;    // EXIF 1..8
+    int32_t nplanes, bpp;   // planes, bytes per pixel of each (3 interleaved / 1)
+    int32_t pad;
+};
+constexpr int kTransformRowsPerUnit = 8;
+
 constexpr int kBlocksPerUnit = 128;  // idct_plane_kernel: 256 lanes, two lanes per block
 constexpr int kLumaTileW = 32, kLumaTileH = 4;  // luma_color_kernel tile in blocks (one block row per wave)
 

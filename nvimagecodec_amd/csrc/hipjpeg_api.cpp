@@ -29,6 +29,7 @@ struct hipjpegHandle {
     int current = 0;
     DecodeBatch& cur() { return *batches[current]; }
     // pipelined submission (hipjpegDecodeBatchSubmit / Wait): pages in flight, oldest first, with the stream each runs on
+    std::vector<hipjpegTransform_t> transforms;  // geometry for the next batch (hipjpegDecodeBatchSetTransforms)
     int submitted[2] = {-1, -1};
     void* submitted_stream[2] = {nullptr, nullptr};
     int num_submitted = 0;
@@ -167,7 +168,14 @@ hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const uint8_t* co
     DecodeBatch& b = handle->cur();
     static const bool timing = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;  // debug aid: host-stage phase times on stderr
     const auto t0 = std::chrono::steady_clock::now();
-    hipjpegStatus_t st = b.plan(data, lengths, batch_size, outputs, format, flags, statuses, nullptr, handle->pool.get());
+    const bool geometry = !handle->transforms.empty();
+    if (geometry && (int)handle->transforms.size() != batch_size) {
+        handle->transforms.clear();
+        return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    }
+    hipjpegStatus_t st = b.plan(data, lengths, batch_size, outputs, format, flags, statuses, nullptr, handle->pool.get(),
+                                geometry ? handle->transforms.data() : nullptr);
+    handle->transforms.clear();
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     const auto t1 = std::chrono::steady_clock::now();
     handle->pool->parallel_for(batch_size, [&](int i, int) { b.entropy_stage(i); });
@@ -179,6 +187,16 @@ hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const uint8_t* co
         fprintf(stderr, "[hipjpeg] host stage: plan %.2f ms, entropy/staging %.2f ms, finalize %.2f ms (%d threads)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3),
                 handle->pool->num_threads());
     }
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegDecodeBatchSetTransforms(hipjpegHandle_t handle, const hipjpegTransform_t* transforms, int batch_size)
+{
+    if (!handle || batch_size < 0) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if (transforms)
+        handle->transforms.assign(transforms, transforms + batch_size);
+    else
+        handle->transforms.clear();
     return HIPJPEG_STATUS_SUCCESS;
 }
 

@@ -169,6 +169,45 @@ HipJpegDecoder::~HipJpegDecoder()
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
+// What the geometry pass has to do for one sample.  Returns bit 0: the region cannot be used, bit 1: the orientation is not
+// one of the eight EXIF ones; *t = the transform to apply (x1 == 0: whole image, orientation 1: as stored).
+// nvimgcodecOrientation_t <-> EXIF: reference src/parsers/exif_orientation.h:36-57 (rotated counts counter-clockwise there)
+// and extensions/nvjpeg/type_convert.cpp:43-64; region = {start (y, x), end (y, x)}: cuda_decoder.cpp:469-476.
+static int sample_transform(const nvimgcodecImageInfo_t& info, const nvimgcodecImageInfo_t& cs_info, const nvimgcodecDecodeParams_t* params,
+                            hipjpegTransform_t* t)
+{
+    *t = hipjpegTransform_t{0, 0, 0, 0, 1};
+    int bad = 0;
+    if (params->enable_roi && info.region.ndim > 0) {
+        const nvimgcodecRegion_t& r = info.region;
+        const int W = (int)cs_info.plane_info[0].width, H = (int)cs_info.plane_info[0].height;
+        if (r.ndim != 2 || r.start[0] < 0 || r.start[1] < 0 || r.end[0] > H || r.end[1] > W || r.end[0] <= r.start[0] || r.end[1] <= r.start[1]) {
+            bad |= 1;
+        } else {
+            t->y0 = r.start[0];
+            t->x0 = r.start[1];
+            t->y1 = r.end[0];
+            t->x1 = r.end[1];
+        }
+    }
+    if (params->apply_exif_orientation) {
+        const nvimgcodecOrientation_t& o = info.orientation;
+        const int key = o.rotated * 4 + (o.flip_x ? 2 : 0) + (o.flip_y ? 1 : 0);
+        switch (key) {
+        case 0: t->orientation = 1; break;
+        case 2: t->orientation = 2; break;
+        case 180 * 4: t->orientation = 3; break;
+        case 1: t->orientation = 4; break;
+        case 90 * 4 + 1: t->orientation = 5; break;
+        case 270 * 4: t->orientation = 6; break;
+        case 270 * 4 + 1: t->orientation = 7; break;
+        case 90 * 4: t->orientation = 8; break;
+        default: bad |= 2;
+        }
+    }
+    return bad;
+}
+
 void HipJpegDecoder::single_can_decode(nvimgcodecProcessingStatus_t* status, nvimgcodecCodeStreamDesc_t* cs, nvimgcodecImageDesc_t* image,
                                        const nvimgcodecDecodeParams_t* params)
 {
@@ -217,8 +256,9 @@ void HipJpegDecoder::single_can_decode(nvimgcodecProcessingStatus_t* status, nvi
     case NVIMGCODEC_COLORSPEC_SYCC: break;
     default: *status |= NVIMGCODEC_PROCESSING_STATUS_COLOR_SPEC_UNSUPPORTED;
     }
-    hipjpegOutputFormat_t fmt;
-    if (!map_sample_format(info.sample_format, &fmt)) {
+    hipjpegOutputFormat_t fmt = HIPJPEG_OUTPUT_RGBI;
+    const bool fmt_ok = map_sample_format(info.sample_format, &fmt);
+    if (!fmt_ok) {
         *status |= NVIMGCODEC_PROCESSING_STATUS_SAMPLE_FORMAT_UNSUPPORTED;
     } else {
         const bool interleaved = fmt == HIPJPEG_OUTPUT_RGBI || fmt == HIPJPEG_OUTPUT_BGRI;
@@ -237,11 +277,19 @@ void HipJpegDecoder::single_can_decode(nvimgcodecProcessingStatus_t* status, nvi
     }
     for (uint32_t p = 0; p < info.num_planes && p < NVIMGCODEC_MAX_NUM_PLANES; ++p)
         if (info.plane_info[p].sample_type != NVIMGCODEC_SAMPLE_DATA_TYPE_UINT8) *status |= NVIMGCODEC_PROCESSING_STATUS_SAMPLE_TYPE_UNSUPPORTED;
-    // Not implemented in-kernel yet: region of interest and EXIF rotation.  Reporting them here sends the sample to the
-    // next decoder in the priority chain (reference src/decoder_worker.cpp:275-296).
-    if (params->enable_roi && info.region.ndim > 0) *status |= NVIMGCODEC_PROCESSING_STATUS_ROI_UNSUPPORTED;
-    if (params->apply_exif_orientation && (info.orientation.rotated != 0 || info.orientation.flip_x || info.orientation.flip_y))
-        *status |= NVIMGCODEC_PROCESSING_STATUS_ORIENTATION_UNSUPPORTED;
+    // Region of interest and EXIF orientation run as a geometry pass on the device (decoder_core.cpp).  What it cannot do
+    // is reported here, which sends the sample to the next decoder in the priority chain (reference
+    // src/decoder_worker.cpp:275-296): regions that are not 2-D or leave the image (extensions/libjpeg_turbo/
+    // libjpeg_turbo_decoder.cpp:355-370), orientations outside the eight EXIF ones (extensions/nvjpeg/type_convert.cpp:43-64),
+    // and either of them on subsampled planes.
+    hipjpegTransform_t t;
+    const int geometry = sample_transform(info, cs_info, params, &t);
+    if (geometry & 1) *status |= NVIMGCODEC_PROCESSING_STATUS_ROI_UNSUPPORTED;
+    if (geometry & 2) *status |= NVIMGCODEC_PROCESSING_STATUS_ORIENTATION_UNSUPPORTED;
+    if (!geometry && fmt_ok && fmt == HIPJPEG_OUTPUT_YUV_PLANAR && (t.orientation != 1 || t.x1 != 0)) {
+        if (t.x1 != 0) *status |= NVIMGCODEC_PROCESSING_STATUS_ROI_UNSUPPORTED;
+        if (t.orientation != 1) *status |= NVIMGCODEC_PROCESSING_STATUS_ORIENTATION_UNSUPPORTED;
+    }
 }
 
 nvimgcodecStatus_t HipJpegDecoder::canDecode(nvimgcodecProcessingStatus_t* status, nvimgcodecCodeStreamDesc_t** code_streams,
@@ -331,6 +379,8 @@ nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_stre
     std::vector<size_t> sizes(n, 0);
     std::vector<hipjpegOutput_t> outs(n);
     std::vector<hipjpegOutputFormat_t> formats(n, HIPJPEG_OUTPUT_RGBI);
+    std::vector<hipjpegTransform_t> geometry(n, hipjpegTransform_t{0, 0, 0, 0, 1});
+    bool any_geometry = false;
     memset(outs.data(), 0, sizeof(hipjpegOutput_t) * n);
 
     for (int i = 0; i < n; i++) {
@@ -354,6 +404,22 @@ nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_stre
         if (!map_sample_format(info.sample_format, &formats[i])) {
             s.early_status = NVIMGCODEC_PROCESSING_STATUS_SAMPLE_FORMAT_UNSUPPORTED;
             continue;
+        }
+        if ((params->enable_roi && info.region.ndim > 0) || params->apply_exif_orientation) {
+            nvimgcodecImageInfo_t cs_info;
+            memset(&cs_info, 0, sizeof cs_info);
+            cs_info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+            cs_info.struct_size = sizeof cs_info;
+            if (s.code_stream->getImageInfo(s.code_stream->instance, &cs_info) != NVIMGCODEC_STATUS_SUCCESS) {
+                s.early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+                continue;
+            }
+            const int bad = sample_transform(info, cs_info, params, &geometry[i]);
+            if (bad) {  // canDecode said so already; a caller that insists gets the same verdict (cuda_decoder.cpp:452-461)
+                s.early_status = (bad & 1) ? NVIMGCODEC_PROCESSING_STATUS_ROI_UNSUPPORTED : NVIMGCODEC_PROCESSING_STATUS_ORIENTATION_UNSUPPORTED;
+                continue;
+            }
+            any_geometry = any_geometry || geometry[i].x1 != 0 || geometry[i].orientation != 1;
         }
         // planes are laid out back to back inside `buffer` (reference cuda_decoder.cpp:532-538)
         uint8_t* p = static_cast<uint8_t*>(info.buffer);
@@ -391,7 +457,7 @@ nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_stre
     bool planned = hipSetDevice(device_) == hipSuccess &&
                    job->batch.plan(data.data(), sizes.data(), n, outs.data(), HIPJPEG_OUTPUT_RGBI,
                                    (fancy_ ? HIPJPEG_FLAG_FANCY_UPSAMPLING : 0u) | (gpu_huffman_ ? HIPJPEG_FLAG_GPU_HUFFMAN : 0u),
-                                   job->statuses.data(), formats.data()) == HIPJPEG_STATUS_SUCCESS;
+                                   job->statuses.data(), formats.data(), nullptr, any_geometry ? geometry.data() : nullptr) == HIPJPEG_STATUS_SUCCESS;
     if (!planned) {
         // batch-level failure: every sample is reported failed and an error code is returned (cuda_decoder.cpp:602-608)
         release_inputs(job);

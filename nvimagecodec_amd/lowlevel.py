@@ -94,17 +94,25 @@ class BatchDecoder:
             pass
 
     # -- output allocation mirrors python/decoder.cpp:179-225 of the reference: I_RGB u8, row_stride = w*3
-    def allocate_outputs(self, jpegs, fmt="rgb"):
+    def allocate_outputs(self, jpegs, fmt="rgb", transforms=None):
+        """transforms: optional list with one entry per image, None or (roi, orientation) with roi = (x0, y0, x1, y1) or
+        None and orientation = EXIF 1..8; the output then has the size of the region, turned upright."""
         torch = self._torch
         dev = torch.device("cuda", self.device)
         outs = []
-        for j in jpegs:
+        for i, j in enumerate(jpegs):
             try:
                 info = get_image_info(j)
             except N.HipJpegError:
                 outs.append(None)
                 continue
             h, w = info["height"], info["width"]
+            if transforms is not None and transforms[i] is not None:
+                roi, orientation = transforms[i]
+                if roi is not None:
+                    w, h = roi[2] - roi[0], roi[3] - roi[1]
+                if orientation >= 5:
+                    w, h = h, w
             if fmt in ("rgb", "bgr"):
                 outs.append(torch.empty((h, w, 3), dtype=torch.uint8, device=dev))
             elif fmt in ("rgb_planar", "bgr_planar"):
@@ -148,10 +156,31 @@ class BatchDecoder:
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         return ctypes.c_void_p(s.cuda_stream)
 
-    def decode(self, jpegs, fmt="rgb", fancy=True, outs=None, stream=None, check=True, gpu_huffman=False):
-        """Full pipeline.  Returns (outputs, statuses).  gpu_huffman=True: entropy-decode eligible streams on the GPU."""
+    def set_transforms(self, transforms, n):
+        """Geometry for the next batch (see allocate_outputs); None clears it."""
+        if transforms is None:
+            st = N.load().hipjpegDecodeBatchSetTransforms(self._h, None, 0)
+        else:
+            T = (N.Transform * n)()
+            for i, t in enumerate(transforms):
+                if t is None:
+                    T[i].orientation = 1
+                    continue
+                roi, orientation = t
+                if roi is not None:
+                    T[i].x0, T[i].y0, T[i].x1, T[i].y1 = [int(v) for v in roi]
+                T[i].orientation = int(orientation)
+            st = N.load().hipjpegDecodeBatchSetTransforms(self._h, T, n)
+        if st:
+            raise N.HipJpegError(st, "hipjpegDecodeBatchSetTransforms")
+
+    def decode(self, jpegs, fmt="rgb", fancy=True, outs=None, stream=None, check=True, gpu_huffman=False, transforms=None):
+        """Full pipeline.  Returns (outputs, statuses).  gpu_huffman=True: entropy-decode eligible streams on the GPU.
+        transforms: per-image (roi, orientation) or None -- region of interest and EXIF orientation applied on the device."""
         if outs is None:
-            outs = self.allocate_outputs(jpegs, fmt)
+            outs = self.allocate_outputs(jpegs, fmt, transforms)
+        if transforms is not None:
+            self.set_transforms(transforms, len(jpegs))
         ptrs, lens, O, statuses = self._marshal(jpegs, outs, fmt)
         flags = (N.FLAG_FANCY_UPSAMPLING if fancy else 0) | (N.FLAG_GPU_HUFFMAN if gpu_huffman else 0)
         st = N.load().hipjpegDecodeBatch(self._h, ptrs, lens, len(jpegs), O, _FORMATS[fmt], flags, statuses, self._stream_ptr(stream))

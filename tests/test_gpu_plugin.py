@@ -139,24 +139,18 @@ def test_planar_bgr_and_user_stream(torch_mod):
     lib.nvimgcodecInstanceDestroy(inst)
 
 
-def test_unsupported_requests_fall_back_to_next_decoder(torch_mod):
-    """ROI and CMYK-coloured requests are outside the HIP decoder: canDecode says so and the chain moves on, exactly like
-    nvjpeg -> libjpeg_turbo in the reference."""
-    torch = torch_mod
-    lib = A.bind(_native.load())
-    cpu = FakeDecoderPlugin("cpu_fallback", priority=A.PRIORITY_NORMAL, fill=0x42)
-    inst, dec = _setup(lib, extra_plugins=[cpu])
-    jpeg, rgb = _case("s64x48_420_base_q90")
+def _decode_region(lib, inst, dec, jpeg, region, shape):
+    """nvimgcodecDecoderDecode of one stream into a host buffer of `shape` with image_info.region = (y0, x0, y1, x1)"""
     arr = np.frombuffer(jpeg, dtype=np.uint8)
     cs = C.c_void_p()
     assert lib.nvimgcodecCodeStreamCreateFromHostMem(inst, C.byref(cs), arr.ctypes.data, arr.size) == 0
-    buf = np.zeros((24, 32, 3), dtype=np.uint8)
+    buf = np.zeros(shape, dtype=np.uint8)
     info = A.init(A.ImageInfo, A.ST_IMAGE_INFO, sample_format=A.SAMPLEFORMAT_I_RGB, color_spec=A.COLORSPEC_SRGB, num_planes=1,
                   buffer=buf.ctypes.data, buffer_size=buf.nbytes, buffer_kind=A.BUFFER_KIND_STRIDED_HOST)
     pi = info.plane_info[0]
-    pi.width, pi.height, pi.row_stride, pi.num_channels, pi.sample_type = 32, 24, 96, 3, A.SAMPLE_DATA_TYPE_UINT8
+    pi.width, pi.height, pi.row_stride, pi.num_channels, pi.sample_type = shape[1], shape[0], shape[1] * 3, 3, A.SAMPLE_DATA_TYPE_UINT8
     info.region.ndim = 2
-    info.region.start[0], info.region.start[1], info.region.end[0], info.region.end[1] = 8, 16, 32, 48
+    info.region.start[0], info.region.start[1], info.region.end[0], info.region.end[1] = region
     im = C.c_void_p()
     assert lib.nvimgcodecImageCreate(inst, C.byref(im), C.byref(info)) == 0
     dp = A.init(A.DecodeParams, A.ST_DECODE_PARAMS, enable_roi=1)
@@ -167,13 +161,51 @@ def test_unsupported_requests_fall_back_to_next_decoder(torch_mod):
     n = C.c_size_t()
     lib.nvimgcodecFutureGetProcessingStatus(fut, st, C.byref(n))
     lib.nvimgcodecFutureDestroy(fut)
-    assert st[0] == A.PS_SUCCESS and buf.flat[0] == 0x42 and cpu.count("decode") == 1
-    # canDecode API says the same thing when the format is forced
-    out = (C.c_uint32 * 1)()
     lib.nvimgcodecImageDestroy(im)
     lib.nvimgcodecCodeStreamDestroy(cs)
+    return st[0], buf
+
+
+def test_region_of_interest_on_the_device_and_fallback_for_what_is_not_supported(torch_mod):
+    """A region inside the image is decoded by the HIP decoder (the pixels of the full decode, like the reference CPU path's
+    crop, extensions/libjpeg_turbo/jpeg_mem.cpp:206-240).  A region that leaves the image is outside it: canDecode says so
+    and the chain moves on, exactly like nvjpeg -> libjpeg_turbo in the reference."""
+    lib = A.bind(_native.load())
+    cpu = FakeDecoderPlugin("cpu_fallback", priority=A.PRIORITY_NORMAL, fill=0x42)
+    inst, dec = _setup(lib, extra_plugins=[cpu])
+    jpeg, rgb = _case("s64x48_420_base_q90")
+    st, buf = _decode_region(lib, inst, dec, jpeg, (8, 16, 32, 48), (24, 32, 3))
+    assert st == A.PS_SUCCESS and cpu.count("decode") == 0
+    assert np.array_equal(buf, rgb[8:32, 16:48])
+    st, buf = _decode_region(lib, inst, dec, jpeg, (8, 16, 32, 80), (24, 64, 3))  # x1 = 80 > width 64
+    assert st == A.PS_SUCCESS and buf.flat[0] == 0x42 and cpu.count("decode") == 1
     lib.nvimgcodecDecoderDestroy(dec)
     lib.nvimgcodecInstanceDestroy(inst)
+
+
+def _with_exif_orientation(jpeg, orientation):
+    # APP1 Exif, little-endian TIFF, IFD0 with one entry: Orientation (0x0112) SHORT
+    tiff = b"II*\x00\x08\x00\x00\x00" + b"\x01\x00" + b"\x12\x01\x03\x00\x01\x00\x00\x00" + bytes([orientation]) + b"\x00\x00\x00" + b"\x00\x00\x00\x00"
+    payload = b"Exif\x00\x00" + tiff
+    return jpeg[:2] + b"\xff\xe1" + (len(payload) + 2).to_bytes(2, "big") + payload + jpeg[2:]
+
+
+def test_exif_orientation_is_applied_like_the_reference_python_decoder(torch_mod):
+    """python/decoder.cpp:202-205 sizes the output for the upright picture when apply_exif_orientation is set; the pixels
+    are the stored picture turned according to the EXIF tag (all eight values)."""
+    from nvimagecodec_amd import api
+    from test_gpu_geometry import upright
+    jpeg, rgb = _case("s50x37_420_base_q90")
+    with api.Decoder(max_num_cpu_threads=2) as dec:
+        imgs = dec.decode([_with_exif_orientation(jpeg, o) for o in range(1, 9)])
+        torch_mod.cuda.synchronize()
+        for o, im in zip(range(1, 9), imgs):
+            assert im is not None, o
+            assert np.array_equal(np.asarray(im.cpu()._array), upright(rgb, o)), o
+        # apply_exif_orientation=False: as stored
+        im = dec.decode(_with_exif_orientation(jpeg, 6), params=api.DecodeParams(apply_exif_orientation=False))
+        torch_mod.cuda.synchronize()
+        assert np.array_equal(np.asarray(im.cpu()._array), rgb)
 
 
 def test_cpu_only_device_is_refused_and_custom_allocators_are_used(torch_mod):
