@@ -186,6 +186,11 @@ HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchDevice(hipjpegHandle_t handle, con
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchRelaunch(hipjpegHandle_t handle, void* stream);
 /* D2H of the quantized coefficients, then Huffman coding + marker writing on the host thread pool (blocking). */
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchHost(hipjpegHandle_t handle, hipjpegStatus_t* statuses);
+/* Entropy stage with a choice: flags = HIPJPEG_FLAG_GPU_HUFFMAN codes every image that uses the Annex-K tables without
+ * restart markers on the GPU (lengths, prefix sums, bit packing, byte stuffing, file assembly -- only finished JPEG files
+ * cross PCIe); images with optimized tables or restart intervals, and everything when flags = 0, go through the host coder
+ * as in hipjpegEncodeBatchHost.  Blocking. */
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchEntropy(hipjpegHandle_t handle, unsigned flags, hipjpegStatus_t* statuses);
 /* Both of the above. */
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatch(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
                                                int batch_size, hipjpegStatus_t* statuses, void* stream);

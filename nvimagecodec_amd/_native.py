@@ -81,6 +81,7 @@ def load():
     L.hipjpegEncodeBatchDevice.argtypes = [vp, vp, vp, i32, vp, vp]
     L.hipjpegEncodeBatchRelaunch.argtypes = [vp, vp]
     L.hipjpegEncodeBatchHost.argtypes = [vp, vp]
+    L.hipjpegEncodeBatchEntropy.argtypes = [vp, ctypes.c_uint, vp]
     L.hipjpegEncodeBatch.argtypes = [vp, vp, vp, i32, vp, vp]
     L.hipjpegEncodeGetBitstream.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.hipjpegEncodeGetCoefficients.argtypes = [vp, i32, i32, ctypes.POINTER(vp), vp]

@@ -32,7 +32,8 @@ hipjpegStatus_t subsampling_factors(int subsampling, int* ncomp, int* hs, int* v
 }
 
 EncodeBatch::EncodeBatch(int device_id, const MemoryHooks* hooks)
-    : device_id_(device_id), pinned_desc_(Buffer::kPinned, hooks), device_(Buffer::kDevice, hooks), pinned_coef_(Buffer::kPinned, hooks)
+    : device_id_(device_id), pinned_desc_(Buffer::kPinned, hooks), device_(Buffer::kDevice, hooks), pinned_coef_(Buffer::kPinned, hooks),
+      henc_dev_(Buffer::kDevice, hooks), henc_dev2_(Buffer::kDevice, hooks), henc_pinned_(Buffer::kPinned, hooks), henc_out_(Buffer::kPinned, hooks)
 {
 }
 
@@ -172,6 +173,172 @@ hipjpegStatus_t EncodeBatch::fetch_coefficients()
     return HIPJPEG_STATUS_SUCCESS;
 }
 
+// GPU entropy coder.  Two short host round trips: after the length scan (the bit-buffer sizes) and after the layout (the
+// file sizes); everything else is queued on the stream the forward kernel ran on.
+hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
+{
+    const int n = (int)images_.size();
+    todo->assign(n, 0);
+    gpu_entropy_images_ = 0;
+    if (!launched_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if (hipSetDevice(device_id_) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream_;
+    std::vector<int> idx;  // images taken here
+    for (int i = 0; i < n; i++) {
+        PlannedEncode& im = images_[i];
+        im.gpu_bitstream = nullptr;
+        im.gpu_bitstream_len = 0;
+        if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
+        if (im.params.restart_interval == 0 && !im.params.optimized_huffman)
+            idx.push_back(i);
+        else
+            (*todo)[i] = 1;  // restart markers / per-image tables: the host coder
+    }
+    const int ng = (int)idx.size();
+    if (ng == 0) return HIPJPEG_STATUS_SUCCESS;
+
+    // ---- phase 1: descriptors, work units, code tables up; block lengths and their prefix sums
+    std::vector<HencImage> desc(ng);
+    std::vector<HencUnit> units;
+    size_t total_blocks = 0;
+    for (int g = 0; g < ng; g++) {
+        const PlannedEncode& im = images_[idx[g]];
+        const EncodeGeometry& eg = im.geom;
+        HencImage& h = desc[g];
+        memset(&h, 0, sizeof h);
+        for (int c = 0; c < eg.ncomp; c++) {
+            h.coef[c] = desc_[idx[g]].coef[c];
+            h.blocks_w[c] = (uint32_t)eg.blocks_w[c];
+            h.real_w[c] = (uint32_t)eg.real_w[c];
+            h.real_h[c] = (uint32_t)eg.real_h[c];
+        }
+        h.mcus_x = (uint32_t)eg.mcus_x;
+        h.mcus_y = (uint32_t)eg.mcus_y;
+        h.ncomp = (uint32_t)eg.ncomp;
+        h.hs = (uint32_t)eg.hs;
+        h.vs = (uint32_t)eg.vs;
+        h.bpm = eg.ncomp == 3 ? (uint32_t)(eg.hs * eg.vs + 2) : 1u;
+        h.total_blocks = h.mcus_x * h.mcus_y * h.bpm;
+        h.first_block = (uint32_t)total_blocks;
+        for (uint32_t b = 0; b < h.total_blocks; b += 256) units.push_back(HencUnit{(uint32_t)g, b});
+        total_blocks += (h.total_blocks + 63) & ~(size_t)63;
+    }
+    const size_t o_units = align_up(sizeof(HencImage) * (size_t)ng, 256);
+    const size_t o_tables = align_up(o_units + sizeof(HencUnit) * units.size(), 256);
+    const size_t up1 = align_up(o_tables + sizeof(StandardCodeTables), 256);  // uploaded part
+    const size_t o_bits = up1;
+    const size_t o_off = align_up(o_bits + total_blocks * 2, 256);
+    const size_t o_total = align_up(o_off + total_blocks * 4, 256);
+    const size_t dev1 = o_total + align_up((size_t)ng * 4, 256);
+    hipjpegStatus_t st;
+    if ((st = henc_dev_.reserve(dev1 + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    // pinned staging: phase-1 upload | totals | phase-2 upload (descriptors again, chunk units, headers) | lengths, offsets
+    std::vector<std::vector<uint8_t>> headers(ng);
+    size_t header_total = 0;
+    for (int g = 0; g < ng; g++) {
+        const PlannedEncode& im = images_[idx[g]];
+        write_standard_headers(im.geom, im.qlum, im.qchr, &headers[g]);
+        header_total += align_up(headers[g].size(), 16);
+    }
+    const size_t p_totals = up1;
+    const size_t p_up2 = align_up(p_totals + (size_t)ng * 4, 256);
+    // worst case for the chunk count: sized after the totals are known -> reserve generously from the block count
+    // (a block codes to at most 64 * (16 + 15) bits; in practice ~10 bytes) -- the exact size is re-checked below
+    if ((st = henc_pinned_.reserve(p_up2 + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    uint8_t* pin = henc_pinned_.data();
+    memcpy(pin, desc.data(), sizeof(HencImage) * (size_t)ng);
+    memcpy(pin + o_units, units.data(), sizeof(HencUnit) * units.size());
+    standard_code_tables(reinterpret_cast<StandardCodeTables*>(pin + o_tables));
+    uint8_t* dev = henc_dev_.data();
+    const HencImage* dimg = reinterpret_cast<const HencImage*>(dev);
+    const HencUnit* dunits = reinterpret_cast<const HencUnit*>(dev + o_units);
+    const StandardCodeTables* dtables = reinterpret_cast<const StandardCodeTables*>(dev + o_tables);
+    uint16_t* block_bits = reinterpret_cast<uint16_t*>(dev + o_bits);
+    uint32_t* block_off = reinterpret_cast<uint32_t*>(dev + o_off);
+    uint32_t* total_bits = reinterpret_cast<uint32_t*>(dev + o_total);
+    if (hipMemcpyAsync(dev, pin, up1, hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_henc_length(dimg, dunits, (int)units.size(), dtables, block_bits, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_henc_scan(dimg, ng, block_bits, block_off, total_bits, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    uint32_t* h_totals = reinterpret_cast<uint32_t*>(pin + p_totals);
+    if (hipMemcpyAsync(h_totals, total_bits, (size_t)ng * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+
+    // ---- phase 2: bit buffers, stuffing, file assembly
+    std::vector<HencUnit> chunk_units;
+    size_t raw_total = 0, arena_cap = 0, nchunks = 0;
+    std::vector<size_t> raw_off(ng), hdr_off(ng);
+    size_t hdr_total = 0;
+    for (int g = 0; g < ng; g++) {
+        HencImage& h = desc[g];
+        const uint32_t pad = (8 - (h_totals[g] & 7)) & 7;
+        h.raw_bytes = (h_totals[g] + pad) / 8;
+        h.first_chunk = (uint32_t)nchunks;
+        h.num_chunks = (h.raw_bytes + kHencChunk - 1) / kHencChunk;
+        for (uint32_t c = 0; c < h.num_chunks; c++) chunk_units.push_back(HencUnit{(uint32_t)g, c});
+        nchunks += h.num_chunks;
+        raw_off[g] = raw_total;
+        raw_total += align_up((size_t)h.raw_bytes + 16, 256);
+        h.header_bytes = (uint32_t)headers[g].size();
+        hdr_off[g] = hdr_total;
+        hdr_total += align_up(headers[g].size(), 16);
+        arena_cap += align_up((size_t)h.header_bytes + 2 * (size_t)h.raw_bytes + 2, 16);  // every byte could be 0xFF
+    }
+    const size_t q_units = align_up(sizeof(HencImage) * (size_t)ng, 256);
+    const size_t q_headers = align_up(q_units + sizeof(HencUnit) * chunk_units.size(), 256);
+    const size_t up2 = align_up(q_headers + hdr_total, 256);
+    const size_t q_ff = up2;
+    const size_t q_out = align_up(q_ff + nchunks * 4, 256);
+    const size_t q_len = align_up(q_out + nchunks * 4, 256);
+    const size_t q_foff = align_up(q_len + (size_t)ng * 4, 256);
+    const size_t q_raw = align_up(q_foff + (size_t)ng * 8, 256);
+    const size_t q_arena = align_up(q_raw + raw_total, 256);
+    if ((st = henc_dev2_.reserve(q_arena + arena_cap + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    // the pinned buffer is about to grow: keep what is still needed
+    const size_t p_len = align_up(p_up2 + up2, 256);
+    const size_t p_foff = align_up(p_len + (size_t)ng * 4, 256);
+    if ((st = henc_pinned_.reserve(p_foff + (size_t)ng * 8 + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    pin = henc_pinned_.data();
+    uint8_t* dev2 = henc_dev2_.data();
+    for (int g = 0; g < ng; g++) {
+        desc[g].raw = dev2 + q_raw + raw_off[g];
+        desc[g].header = dev2 + q_headers + hdr_off[g];
+        memcpy(pin + p_up2 + q_headers + hdr_off[g], headers[g].data(), headers[g].size());
+    }
+    memcpy(pin + p_up2, desc.data(), sizeof(HencImage) * (size_t)ng);
+    memcpy(pin + p_up2 + q_units, chunk_units.data(), sizeof(HencUnit) * chunk_units.size());
+    const HencImage* dimg2 = reinterpret_cast<const HencImage*>(dev2);
+    const HencUnit* dchunks = reinterpret_cast<const HencUnit*>(dev2 + q_units);
+    uint32_t* chunk_ff = reinterpret_cast<uint32_t*>(dev2 + q_ff);
+    uint32_t* chunk_out = reinterpret_cast<uint32_t*>(dev2 + q_out);
+    uint32_t* final_len = reinterpret_cast<uint32_t*>(dev2 + q_len);
+    unsigned long long* final_off = reinterpret_cast<unsigned long long*>(dev2 + q_foff);
+    uint8_t* arena = dev2 + q_arena;
+    if (hipMemcpyAsync(dev2, pin + p_up2, up2, hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipMemsetAsync(dev2 + q_raw, 0, raw_total, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_henc_write(dimg2, dunits, (int)units.size(), dtables, block_off, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_henc_count(dimg2, dchunks, (int)nchunks, chunk_ff, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_henc_layout(dimg2, ng, chunk_ff, chunk_out, final_len, final_off, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_henc_expand(dimg2, dchunks, (int)nchunks, chunk_out, final_len, final_off, arena, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    uint32_t* h_len = reinterpret_cast<uint32_t*>(pin + p_len);
+    unsigned long long* h_foff = reinterpret_cast<unsigned long long*>(pin + p_foff);
+    if (hipMemcpyAsync(h_len, final_len, (size_t)ng * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(h_foff, final_off, (size_t)ng * 8, hipMemcpyDeviceToHost, s) != hipSuccess)
+        return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    const size_t used = (size_t)h_foff[ng - 1] + align_up((size_t)h_len[ng - 1], 16);
+    if (used > arena_cap) return HIPJPEG_STATUS_HIP_ERROR;  // cannot happen: the capacity assumes every byte is stuffed
+    if ((st = henc_out_.reserve(used + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    if (hipMemcpyAsync(henc_out_.data(), arena, used, hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    for (int g = 0; g < ng; g++) {
+        PlannedEncode& im = images_[idx[g]];
+        im.gpu_bitstream = henc_out_.data() + h_foff[g];
+        im.gpu_bitstream_len = h_len[g];
+    }
+    gpu_entropy_images_ = (uint64_t)ng;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
 void EncodeBatch::entropy_stage(int i)
 {
     PlannedEncode& im = images_[i];
@@ -182,6 +349,8 @@ void EncodeBatch::entropy_stage(int i)
     opt.restart_interval = im.params.restart_interval;
     opt.optimized_huffman = im.params.optimized_huffman != 0;
     im.bitstream.clear();
+    im.gpu_bitstream = nullptr;
+    im.gpu_bitstream_len = 0;
     encode_jfif(im.geom, im.qlum, im.qchr, coef, opt, &im.bitstream);
 }
 

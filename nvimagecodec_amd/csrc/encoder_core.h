@@ -9,6 +9,7 @@
 #include "decoder_core.h"
 #include "encode_layout.h"
 #include "entropy_encode.h"
+#include "gpu_huffman_encode.h"
 
 namespace hipjpeg {
 
@@ -18,7 +19,11 @@ struct PlannedEncode {
     hipjpegEncodeParams_t params{};
     uint16_t qlum[64], qchr[64];
     size_t coef_offset[3] = {0, 0, 0};  // byte offsets inside the coefficient area
-    std::vector<uint8_t> bitstream;
+    std::vector<uint8_t> bitstream;          // host entropy coder's output
+    const uint8_t* gpu_bitstream = nullptr;  // GPU entropy coder's output (inside the batch's pinned arena), or null
+    size_t gpu_bitstream_len = 0;
+    const uint8_t* file() const { return gpu_bitstream ? gpu_bitstream : bitstream.data(); }
+    size_t file_size() const { return gpu_bitstream ? gpu_bitstream_len : bitstream.size(); }
 };
 
 class EncodeBatch {
@@ -32,6 +37,10 @@ public:
     // Coefficients D2H (on the stream used by device_stage), wait, then Huffman + markers for image i.
     hipjpegStatus_t fetch_coefficients();
     void entropy_stage(int i);
+    // GPU entropy coder (gpu_huffman_encode.h) for every image it can take -- Annex-K tables, no restart markers; blocking.
+    // todo[i] = true afterwards for the images that still need the host coder (entropy_stage).
+    hipjpegStatus_t gpu_entropy_stage(std::vector<char>* todo);
+    uint64_t gpu_entropy_images() const { return gpu_entropy_images_; }
     int size() const { return (int)images_.size(); }
     PlannedEncode& image(int i) { return images_[i]; }
     const int16_t* host_coef(int i, int c) const;
@@ -50,6 +59,8 @@ private:
     void* stream_ = nullptr;
     void* event_ = nullptr;
     bool launched_ = false, fetched_ = false;
+    Buffer henc_dev_, henc_dev2_, henc_pinned_, henc_out_;
+    uint64_t gpu_entropy_images_ = 0;
 };
 
 hipjpegStatus_t subsampling_factors(int subsampling, int* ncomp, int* hs, int* vs);

@@ -333,31 +333,11 @@ void compute_geometry(EncodeGeometry* g)
     }
 }
 
-void encode_jfif(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const int16_t* const coef[3],
-                 const EntropyEncodeOptions& opt, std::vector<uint8_t>* o)
+// Everything in front of the entropy-coded data: SOI .. SOS, in jcmarker.c's order.
+static void write_headers(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const HuffTable& dcl, const HuffTable& acl,
+                          const HuffTable& dcc, const HuffTable& acc, int restart_interval, std::vector<uint8_t>* o)
 {
-    HuffTable dcl, dcc, acl, acc;
-    dcl.set(kDcLumBits, kDcVals);
-    dcc.set(kDcChrBits, kDcVals);
-    acl.set(kAcLumBits, kAcLumVals);
-    acc.set(kAcChrBits, kAcChrVals);
-    const HuffTable* dct[3] = {&dcl, &dcc, &dcc};
-    const HuffTable* act[3] = {&acl, &acc, &acc};
-    BlockSource src{g, coef};
-    if (opt.optimized_huffman) {
-        long dc_freq[2][257], ac_freq[2][257];
-        memset(dc_freq, 0, sizeof dc_freq);
-        memset(ac_freq, 0, sizeof ac_freq);
-        walk_scan(g, src, opt.restart_interval, dct, act, nullptr, dc_freq, ac_freq);
-        gen_optimal_table(dc_freq[0], &dcl);
-        gen_optimal_table(ac_freq[0], &acl);
-        if (g.ncomp == 3) {
-            gen_optimal_table(dc_freq[1], &dcc);
-            gen_optimal_table(ac_freq[1], &acc);
-        }
-    }
     // marker order of jcmarker.c: SOI, APP0, DQT.., SOF0, DHT.., [DRI], SOS
-    o->reserve(o->size() + (size_t)g.width * g.height / 2 + 1024);
     put16(o, 0xFFD8);
     put16(o, 0xFFE0);
     put16(o, 16);
@@ -386,10 +366,10 @@ void encode_jfif(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_
         write_dht(o, 0x01, dcc);
         write_dht(o, 0x11, acc);
     }
-    if (opt.restart_interval) {
+    if (restart_interval) {
         put16(o, 0xFFDD);
         put16(o, 4);
-        put16(o, opt.restart_interval);
+        put16(o, restart_interval);
     }
     put16(o, 0xFFDA);
     put16(o, 6 + 2 * g.ncomp);
@@ -401,6 +381,62 @@ void encode_jfif(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_
     o->push_back(0);
     o->push_back(63);
     o->push_back(0);
+}
+
+void write_standard_headers(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], std::vector<uint8_t>* out)
+{
+    HuffTable dcl, dcc, acl, acc;
+    dcl.set(kDcLumBits, kDcVals);
+    dcc.set(kDcChrBits, kDcVals);
+    acl.set(kAcLumBits, kAcLumVals);
+    acc.set(kAcChrBits, kAcChrVals);
+    write_headers(g, qlum, qchr, dcl, acl, dcc, acc, 0, out);
+}
+
+void standard_code_tables(StandardCodeTables* t)
+{
+    HuffTable dc[2], ac[2];
+    dc[0].set(kDcLumBits, kDcVals);
+    dc[1].set(kDcChrBits, kDcVals);
+    ac[0].set(kAcLumBits, kAcLumVals);
+    ac[1].set(kAcChrBits, kAcChrVals);
+    for (int k = 0; k < 2; k++) {
+        for (int i = 0; i < 16; i++) {
+            t->dc_code[k][i] = (uint16_t)dc[k].code[i];
+            t->dc_size[k][i] = dc[k].size[i];
+        }
+        for (int i = 0; i < 256; i++) {
+            t->ac_code[k][i] = (uint16_t)ac[k].code[i];
+            t->ac_size[k][i] = ac[k].size[i];
+        }
+    }
+}
+
+void encode_jfif(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const int16_t* const coef[3],
+                 const EntropyEncodeOptions& opt, std::vector<uint8_t>* o)
+{
+    HuffTable dcl, dcc, acl, acc;
+    dcl.set(kDcLumBits, kDcVals);
+    dcc.set(kDcChrBits, kDcVals);
+    acl.set(kAcLumBits, kAcLumVals);
+    acc.set(kAcChrBits, kAcChrVals);
+    const HuffTable* dct[3] = {&dcl, &dcc, &dcc};
+    const HuffTable* act[3] = {&acl, &acc, &acc};
+    BlockSource src{g, coef};
+    if (opt.optimized_huffman) {
+        long dc_freq[2][257], ac_freq[2][257];
+        memset(dc_freq, 0, sizeof dc_freq);
+        memset(ac_freq, 0, sizeof ac_freq);
+        walk_scan(g, src, opt.restart_interval, dct, act, nullptr, dc_freq, ac_freq);
+        gen_optimal_table(dc_freq[0], &dcl);
+        gen_optimal_table(ac_freq[0], &acl);
+        if (g.ncomp == 3) {
+            gen_optimal_table(dc_freq[1], &dcc);
+            gen_optimal_table(ac_freq[1], &acc);
+        }
+    }
+    o->reserve(o->size() + (size_t)g.width * g.height / 2 + 1024);
+    write_headers(g, qlum, qchr, dcl, acl, dcc, acc, opt.restart_interval, o);
     BitWriter bw(o);
     walk_scan(g, src, opt.restart_interval, dct, act, &bw, nullptr, nullptr);
     bw.align();

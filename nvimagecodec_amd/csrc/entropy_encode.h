@@ -32,4 +32,15 @@ struct EntropyEncodeOptions {
 void encode_jfif(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const int16_t* const coef[3],
                  const EntropyEncodeOptions& opt, std::vector<uint8_t>* out);
 
+// For the GPU entropy coder (gpu_huffman_encode.hip): the Annex-K tables as (code, length) per symbol, [0] luma [1] chroma,
+// and the bytes of SOI .. SOS for those tables (no DRI).
+struct StandardCodeTables {
+    uint16_t dc_code[2][16];
+    uint16_t ac_code[2][256];
+    uint8_t dc_size[2][16];
+    uint8_t ac_size[2][256];
+};
+void standard_code_tables(StandardCodeTables* t);
+void write_standard_headers(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], std::vector<uint8_t>* out);
+
 }  // namespace hipjpeg

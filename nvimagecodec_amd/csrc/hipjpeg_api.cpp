@@ -308,17 +308,30 @@ hipjpegStatus_t hipjpegEncodeBatchRelaunch(hipjpegHandle_t handle, void* stream)
     return handle->encode->relaunch(stream);
 }
 
-hipjpegStatus_t hipjpegEncodeBatchHost(hipjpegHandle_t handle, hipjpegStatus_t* statuses)
+hipjpegStatus_t hipjpegEncodeBatchEntropy(hipjpegHandle_t handle, unsigned flags, hipjpegStatus_t* statuses)
 {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     EncodeBatch& b = *handle->encode;
-    hipjpegStatus_t st = b.fetch_coefficients();
-    if (st != HIPJPEG_STATUS_SUCCESS) return st;
-    handle->pool->parallel_for(b.size(), [&](int i, int) { b.entropy_stage(i); });
+    std::vector<char> todo(b.size(), 1);
+    hipjpegStatus_t st;
+    if (flags & HIPJPEG_FLAG_GPU_HUFFMAN) {
+        if ((st = b.gpu_entropy_stage(&todo)) != HIPJPEG_STATUS_SUCCESS) return st;
+    }
+    bool any = false;
+    for (int i = 0; i < b.size(); i++) any = any || (todo[i] && b.image(i).status == HIPJPEG_STATUS_SUCCESS);
+    if (any) {
+        // the host coder needs the coefficients on its side of PCIe
+        if ((st = b.fetch_coefficients()) != HIPJPEG_STATUS_SUCCESS) return st;
+        handle->pool->parallel_for(b.size(), [&](int i, int) {
+            if (todo[i]) b.entropy_stage(i);
+        });
+    }
     if (statuses)
         for (int i = 0; i < b.size(); i++) statuses[i] = b.image(i).status;
     return HIPJPEG_STATUS_SUCCESS;
 }
+
+hipjpegStatus_t hipjpegEncodeBatchHost(hipjpegHandle_t handle, hipjpegStatus_t* statuses) { return hipjpegEncodeBatchEntropy(handle, 0u, statuses); }
 
 hipjpegStatus_t hipjpegEncodeBatch(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
                                    int batch_size, hipjpegStatus_t* statuses, void* stream)
@@ -333,8 +346,8 @@ hipjpegStatus_t hipjpegEncodeGetBitstream(hipjpegHandle_t handle, int index, con
     if (!handle || !data || !length || index < 0 || index >= handle->encode->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     PlannedEncode& im = handle->encode->image(index);
     if (im.status != HIPJPEG_STATUS_SUCCESS) return im.status;
-    *data = im.bitstream.data();
-    *length = im.bitstream.size();
+    *data = im.file();
+    *length = im.file_size();
     return HIPJPEG_STATUS_SUCCESS;
 }
 

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <sstream>
 #include <vector>
 
 #include "encoder_core.h"
@@ -67,8 +68,13 @@ void init_info(nvimgcodecImageInfo_t* info, void* next = nullptr)
 
 class HipJpegEncoder {
 public:
-    HipJpegEncoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgcodecExecutionParams_t* ep, const char* /*options*/) : fw_(fw), ep_(ep), device_(ep->device_id)
+    HipJpegEncoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgcodecExecutionParams_t* ep, const char* options) : fw_(fw), ep_(ep), device_(ep->device_id)
     {
+        // "hipjpeg_encoder:gpu_huffman=0" keeps the entropy coder on the executor threads (default: on the GPU)
+        for_each_option(options, kEncoderId, [&](const std::string& key, const std::string& value) {
+            std::istringstream v(value);
+            if (key == "gpu_huffman") v >> gpu_huffman_;
+        });
         if (ep->device_allocator && ep->device_allocator->device_malloc && ep->device_allocator->device_free) {
             hooks_.device_malloc = reinterpret_cast<int (*)(void*, void**, size_t, void*)>(ep->device_allocator->device_malloc);
             hooks_.device_free = reinterpret_cast<int (*)(void*, void*, size_t, void*)>(ep->device_allocator->device_free);
@@ -129,6 +135,8 @@ private:
     MemoryHooks hooks_;
     int device_;
     bool ok_ = false;
+    bool gpu_huffman_ = true;       // entropy-code on the GPU what it can take (Annex-K tables, no restart markers)
+    std::vector<char> host_coder_;  // per sample of the current batch: still needs the host entropy coder
     hipStream_t stream_ = nullptr;
     hipEvent_t event_ = nullptr;
     std::unique_ptr<EncodeBatch> batch_;
@@ -214,14 +222,14 @@ void HipJpegEncoder::host_task(int /*tid*/, int idx, void* ctx)
         if (im.status != HIPJPEG_STATUS_SUCCESS) {
             ps = im.status == HIPJPEG_STATUS_UNSUPPORTED ? NVIMGCODEC_PROCESSING_STATUS_SAMPLING_UNSUPPORTED : NVIMGCODEC_PROCESSING_STATUS_FAIL;
         } else {
-            self->batch_->entropy_stage(idx);
+            if (self->host_coder_[idx]) self->batch_->entropy_stage(idx);  // else: the GPU entropy coder has produced the file already
             // cuda_encoder.cpp:383-388
             nvimgcodecIoStreamDesc_t* io = s.code_stream->io_stream;
             size_t written = 0;
-            if (io->reserve(io->instance, im.bitstream.size()) != NVIMGCODEC_STATUS_SUCCESS ||
+            if (io->reserve(io->instance, im.file_size()) != NVIMGCODEC_STATUS_SUCCESS ||
                 io->seek(io->instance, 0, SEEK_SET) != NVIMGCODEC_STATUS_SUCCESS ||
-                io->write(io->instance, &written, im.bitstream.data(), im.bitstream.size()) != NVIMGCODEC_STATUS_SUCCESS ||
-                written != im.bitstream.size() || io->flush(io->instance) != NVIMGCODEC_STATUS_SUCCESS)
+                io->write(io->instance, &written, const_cast<uint8_t*>(im.file()), im.file_size()) != NVIMGCODEC_STATUS_SUCCESS ||
+                written != im.file_size() || io->flush(io->instance) != NVIMGCODEC_STATUS_SUCCESS)
                 ps = NVIMGCODEC_PROCESSING_STATUS_FAIL;
         }
     }
@@ -295,7 +303,12 @@ nvimgcodecStatus_t HipJpegEncoder::encode(nvimgcodecImageDesc_t** images, nvimgc
     }
     std::vector<hipjpegStatus_t> statuses(n, HIPJPEG_STATUS_SUCCESS);
     if (gpu_ok) gpu_ok = batch_->device_stage(inputs.data(), eparams.data(), n, statuses.data(), stream_) == HIPJPEG_STATUS_SUCCESS;
-    if (gpu_ok) gpu_ok = batch_->fetch_coefficients() == HIPJPEG_STATUS_SUCCESS;  // blocks like cudaEventSynchronize in cuda_encoder.cpp:374-375
+    host_coder_.assign(n, 1);
+    if (gpu_ok && gpu_huffman_) gpu_ok = batch_->gpu_entropy_stage(&host_coder_) == HIPJPEG_STATUS_SUCCESS;  // blocks
+    bool any_host = false;
+    for (int i = 0; i < n; i++) any_host = any_host || host_coder_[i];
+    // the host coder needs the coefficients: blocks like cudaEventSynchronize in cuda_encoder.cpp:374-375
+    if (gpu_ok && any_host) gpu_ok = batch_->fetch_coefficients() == HIPJPEG_STATUS_SUCCESS;
     if (!gpu_ok) {
         for (int i = 0; i < n; i++) images[i]->imageReady(images[i]->instance, NVIMGCODEC_PROCESSING_STATUS_FAIL);
         {

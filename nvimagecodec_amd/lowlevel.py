@@ -282,10 +282,11 @@ def encode_from_coefficients_host(width, height, coefs_natural, subsampling="420
 class BatchEncoder:
     """hipjpegEncodeBatch* on one device; inputs are torch CUDA uint8 tensors ([H, W, 3] interleaved, [3, H, W] planar or [H, W] gray)."""
 
-    def __init__(self, device=0, num_threads=0):
+    def __init__(self, device=0, num_threads=0, gpu_huffman=False):
         import torch
         self._torch = torch
         self.device = int(device)
+        self.gpu_huffman = bool(gpu_huffman)
         self._h = ctypes.c_void_p()
         st = N.load().hipjpegCreate(ctypes.byref(self._h), self.device, int(num_threads))
         if st:
@@ -348,11 +349,15 @@ class BatchEncoder:
         if st:
             raise N.HipJpegError(st, "hipjpegEncodeBatchRelaunch")
 
-    def host_stage(self):
+    def host_stage(self, gpu_huffman=None):
+        """Entropy stage of the prepared batch.  gpu_huffman (default: the encoder's setting): code on the GPU what it can
+        take (Annex-K tables, no restart markers); the rest, or everything when False, on the host thread pool."""
+        if gpu_huffman is None:
+            gpu_huffman = self.gpu_huffman
         st_arr = (ctypes.c_int * self._n)()
-        st = N.load().hipjpegEncodeBatchHost(self._h, st_arr)
+        st = N.load().hipjpegEncodeBatchEntropy(self._h, N.FLAG_GPU_HUFFMAN if gpu_huffman else 0, st_arr)
         if st:
-            raise N.HipJpegError(st, "hipjpegEncodeBatchHost")
+            raise N.HipJpegError(st, "hipjpegEncodeBatchEntropy")
         return list(st_arr)
 
     def bitstreams(self):

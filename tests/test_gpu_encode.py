@@ -25,10 +25,12 @@ def torch_mod():
     return torch
 
 
-@pytest.fixture(scope="module")
-def enc(torch_mod):
+@pytest.fixture(scope="module", params=["host_huffman", "gpu_huffman"])
+def enc(torch_mod, request):
+    """Every test runs twice: entropy coding on the host thread pool, and on the GPU (gpu_huffman_encode.hip) -- the files
+    must be byte-identical either way."""
     from nvimagecodec_amd.lowlevel import BatchEncoder
-    e = BatchEncoder(0, num_threads=4)
+    e = BatchEncoder(0, num_threads=4, gpu_huffman=request.param == "gpu_huffman")
     yield e
     e.close()
 
