@@ -1098,10 +1098,17 @@ nvimgcodecStatus_t nvimgcodecImageGetImageInfo(nvimgcodecImage_t image, nvimgcod
 static nvimgcodecStatus_t finish_input_stream(nvimgcodecCodeStream* cs, nvimgcodecCodeStream_t* out)
 {
     cs->finish_setup();
-    nvimgcodecStatus_t st = cs->ensure_parsed();
-    if (st != NVIMGCODEC_STATUS_SUCCESS) {
+    // Creation only asks "which parser takes this stream": for JPEG that is the SOI signature (reference
+    // src/parsers/jpeg.cpp:130-145).  The marker walk happens on the first GetImageInfo and may still fail there
+    // (test/parsers/jpeg_test.cpp Error_GetInfo_NoSOF).
+    uint8_t soi[2] = {0, 0};
+    size_t got = 0;
+    cs->io->seek(0, SEEK_SET);
+    cs->io->read(&got, soi, 2);
+    cs->io->seek(0, SEEK_SET);
+    if (got != 2 || soi[0] != 0xFF || soi[1] != 0xD8) {
         delete cs;
-        return st;
+        return NVIMGCODEC_STATUS_CODESTREAM_UNSUPPORTED;
     }
     *out = cs;
     return NVIMGCODEC_STATUS_SUCCESS;
