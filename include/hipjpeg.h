@@ -147,7 +147,7 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, voi
  * so a caller can bracket each with events.  hipjpegDecodeBatchDevice == entropy (if any image uses it), then 0, 1, 2. */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handle, int which, void* stream);
 /* Pipelined submission.  Submit = host stage + H2D copy (on an internal copy stream) + every kernel on `stream`, without
- * waiting for anything on the device; at most two batches may be in flight (the handle's two staging pages).  Wait = block
+ * waiting for anything on the device; at most three batches may be in flight (the handle's three staging pages).  Wait = block
  * until the OLDEST submitted batch has finished and return its final per-image statuses.  The host stage of batch n+1 and
  * its H2D copy overlap the kernels of batch n.  Outputs and `data` of a submitted batch must stay valid until its Wait. */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,

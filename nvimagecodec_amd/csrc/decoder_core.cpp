@@ -389,7 +389,8 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     work_first_block_ = align_up(total_subseq_ * 8, 256);
     work_changed_ = work_first_block_ + align_up(total_subseq_ * 4, 256);
     work_incoming_ = work_changed_ + 256;
-    work_dc_diff_ = align_up(work_incoming_ + max_huff_units_ * 8, 256);
+    work_tail_ = align_up(work_incoming_ + max_huff_units_ * 8, 256);  // tail tasks (256 B per unit) + counts
+    work_dc_diff_ = align_up(work_tail_ + max_huff_units_ * 260, 256);
     work_drops_ = align_up(work_dc_diff_ + huff_blocks_total * 2, 256);
     work_streams_ = align_up(work_drops_ + huff_chunks_total * 4, 256);
     if (ng && (st = work_.reserve(work_streams_ + huff_stream_total + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
@@ -622,8 +623,14 @@ hipjpegStatus_t DecodeBatch::enqueue_gpu_entropy(void* stream)
     if (launch_destuff(L.dimg, reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(),
                        reinterpret_cast<uint32_t*>(work_.data() + work_drops_), stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
-    if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 1, L.pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
-    if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 0, L.pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    static const int tail_after = getenv("HIPJPEG_TAIL_AFTER") ? atoi(getenv("HIPJPEG_TAIL_AFTER")) : 2;  // tuning aid; 0 = no tail kernel
+    uint8_t* tail_tasks = work_.data() + work_tail_;
+    uint32_t* tail_count = reinterpret_cast<uint32_t*>(work_.data() + work_tail_ + (size_t)max_huff_units_ * 256);
+    if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 1, tail_after > 0 ? tail_after : 1 << 20,
+                         tail_after > 0 ? tail_tasks : nullptr, tail_after > 0 ? tail_count : nullptr, L.pool_bytes, stream) != 0)
+        return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 0, 1 << 20, nullptr, nullptr, L.pool_bytes, stream) != 0)
+        return HIPJPEG_STATUS_HIP_ERROR;
     if (!entropy_write_passes(L, stream)) return HIPJPEG_STATUS_HIP_ERROR;
     if (hipMemcpyAsync(L.host_changed, L.changed, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     if (hipMemcpyAsync(L.himg, L.dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
@@ -690,13 +697,15 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
     sync_rounds_max_ = host_changed[3];
     static const bool debug_stats = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;
     if (debug_stats)
-        fprintf(stderr, "[hipjpeg] entropy: %d workgroups, launch 1 rounds avg %.2f max %u; launch 2: %u rounds in total, max %u, %u boundary changes\n", nunits,
-                (double)sync_rounds_total_ / nunits, sync_rounds_max_, host_changed[4], host_changed[5], host_changed[0]);
+        fprintf(stderr, "[hipjpeg] entropy: %d workgroups, launch 1 rounds avg %.2f max %u, tail rounds avg %.2f max %u; launch 2: %u rounds in total, max %u, %u boundary changes\n",
+                nunits, (double)sync_rounds_total_ / nunits, sync_rounds_max_, (double)host_changed[6] / nunits, host_changed[7], host_changed[4],
+                host_changed[5], host_changed[0]);
     bool converged = *host_changed == 0;
     if (!converged) {
         for (int pass = 0; pass < 64 && !converged; pass++) {
             if (hipMemsetAsync(changed, 0, sizeof(unsigned int), s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-            if (launch_huff_sync(dimg, dunits, nunits, states, incoming, changed, 0, pool_bytes, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+            if (launch_huff_sync(dimg, dunits, nunits, states, incoming, changed, 0, 1 << 20, nullptr, nullptr, pool_bytes, stream) != 0)
+                return HIPJPEG_STATUS_HIP_ERROR;
             if (hipMemcpyAsync(host_changed, changed, sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
             if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
             last_sync_launches_++;

@@ -357,7 +357,8 @@ __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __
 // anything; otherwise the ripple starts from its first subsequence.
 __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
                                                              unsigned long long* __restrict__ states, unsigned long long* __restrict__ incoming,
-                                                             unsigned int* __restrict__ counters, int first_pass)
+                                                             unsigned int* __restrict__ counters, int first_pass, int max_rounds,
+                                                             uint8_t* __restrict__ tail_tasks, uint32_t* __restrict__ tail_count)
 {
     __shared__ WgShared sh;
     extern __shared__ uint16_t dyn_pool[];
@@ -412,7 +413,16 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
         }
         __syncthreads();  // every start state has been read before any end state is replaced
         if (task >= 0) sh.end[task] = now;
-        if (compact_tasks(sh, moved && task + 1 < n_rows, task + 1, &task) == 0) break;
+        const int pending = compact_tasks(sh, moved && task + 1 < n_rows, task + 1, &task);
+        if (pending == 0 || rounds >= max_rounds) {
+            // what is left goes to the tail kernel: few subsequences per round, one lane busy per chain -- not worth holding
+            // 47 KB of LDS for
+            if (tail_count) {
+                if (t < pending) tail_tasks[(size_t)blockIdx.x * kThreads + t] = (uint8_t)task;
+                if (t == 0) tail_count[blockIdx.x] = (uint32_t)pending;
+            }
+            break;
+        }
     }
     __syncthreads();
     if (owner) {
@@ -427,6 +437,120 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
         // statistics: correction rounds (sum, maximum) of the first launch / of the later launches
         atomicAdd(counters + (first_pass ? 2 : 4), (unsigned)rounds);
         atomicMax(counters + (first_pass ? 3 : 5), (unsigned)rounds);
+    }
+}
+
+// ---- tail corrections ---------------------------------------------------------------------------------------------------
+// After pass 0 and the first correction round most subsequences are settled; what remains are chains: a decoder that has
+// not yet found the MCU phase hands a wrong end state to its successor, which must be decoded again, and so on for a few
+// thousand bits.  Each link is one full single-lane decode, strictly after the previous one.  This kernel walks those chains
+// with ONE wave per group of 255 subsequences and little LDS (each lane stages just the row it is decoding), so that seven
+// groups per CU make progress at once instead of three workgroups of the big kernel idling on their barriers.
+constexpr int kTailThreads = 64;
+constexpr int kTailRowWords = kSubseqWords + kStagedExtra;
+
+struct TailShared {
+    unsigned long long end[kThreads];  // end states of the group's rows ([0] = state entering the group)
+    uint32_t rows[kTailThreads * kTailRowWords];
+    uint32_t tsel[10];
+    uint8_t list[2][kThreads];         // subsequences to decode this round / next round
+    uint32_t count[2];
+};
+
+struct TailEnv {
+    uint32_t row_base;  // LDS byte address of this lane's row buffer
+    uint32_t word0;     // image word index of its first word
+    uint32_t pool;
+    const HJ_LDS uint32_t* tsel;
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return *(const HJ_LDS uint32_t*)(uintptr_t)(row_base + ((i - word0) << 2)); }
+    __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
+    __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
+    {
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + t + ((w >> (31 - kHuffFastBits)) & ((2u << kHuffFastBits) - 2)));
+    }
+    __device__ __forceinline__ uint32_t lookup2(uint32_t e, uint32_t w) const
+    {
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0x1FFu) << 7) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
+    }
+};
+
+__global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+                                                                 unsigned long long* __restrict__ states, const unsigned long long* __restrict__ incoming,
+                                                                 unsigned int* __restrict__ counters, const uint8_t* __restrict__ tail_tasks,
+                                                                 const uint32_t* __restrict__ tail_count)
+{
+    __shared__ TailShared sh;
+    extern __shared__ uint16_t dyn_pool[];
+    HJ_LDS uint16_t* pool = (HJ_LDS uint16_t*)dyn_pool;
+    const uint32_t pending = tail_count[blockIdx.x];
+    if (pending == 0) return;  // uniform
+    const HuffUnit u = units[blockIdx.x];
+    const HuffImage& im = images[u.image];
+    const HuffGeom geom = make_geom(im);
+    const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
+    if (u.first >= nsub) return;
+    unsigned long long* gstate = states + im.first_subseq;
+    const int t = threadIdx.x;
+    const int n_rows = (int)min((uint32_t)kThreads, nsub - u.first + 1);
+    stage_pool<kTailThreads>(pool, im);
+    stage_constants(sh.tsel, nullptr, nullptr, im, false);
+    for (int r = t; r < n_rows; r += kTailThreads) sh.end[r] = r == 0 ? incoming[blockIdx.x] : gstate[u.first - 1 + r];
+    for (uint32_t i = t; i < pending; i += kTailThreads) sh.list[0][i] = tail_tasks[(size_t)blockIdx.x * kThreads + i];
+    if (t == 0) sh.count[0] = pending;
+    __syncthreads();
+
+    TailEnv env;
+    env.row_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&sh.rows[t * kTailRowWords];
+    env.pool = (uint32_t)(uintptr_t)pool;
+    env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
+    const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
+    const uint32_t gwords = im.stream_words;
+    int rounds = 0, cur = 0;
+    for (int round = 0; round < kThreads + 2; round++) {
+        const uint32_t n = sh.count[cur];
+        if (n == 0) break;
+        rounds++;
+        if (t == 0) sh.count[cur ^ 1] = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < n; base += kTailThreads) {
+            const bool busy = base + t < n;
+            const int task = busy ? (int)sh.list[cur][base + t] : 0;
+            unsigned long long now = 0;
+            bool moved = false;
+            if (busy) {
+                // stage the row: 32 words + the reader's look-ahead, straight from the destuffed stream
+                env.word0 = (u.first - 1 + task) * kSubseqWords;
+                HJ_LDS uint32_t* row = (HJ_LDS uint32_t*)(uintptr_t)env.row_base;
+#pragma unroll
+                for (int i = 0; i < kTailRowWords / 4; i++) {
+                    const uint32_t d = env.word0 + 4 * i;
+                    const u32x4 x = *(const HJ_GLOBAL u32x4*)(g + min(d, (gwords - 1) & ~3u));
+                    const bool ok = d < gwords;
+                    row[4 * i + 0] = ok ? __builtin_bswap32(x.x) : ~0u;
+                    row[4 * i + 1] = ok ? __builtin_bswap32(x.y) : ~0u;
+                    row[4 * i + 2] = ok ? __builtin_bswap32(x.z) : ~0u;
+                    row[4 * i + 3] = ok ? __builtin_bswap32(x.w) : ~0u;
+                }
+                const SubseqState p = unpack_state(sh.end[task - 1]);
+                now = pack_state(decode_subsequence(geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8));
+                moved = ((now ^ sh.end[task]) & kSyncMask) != 0;
+            }
+            __syncthreads();  // one wave: orders the LDS traffic, costs next to nothing
+            if (busy) sh.end[task] = now;
+            const bool more = busy && moved && task + 1 < n_rows;
+            const unsigned long long mask = __ballot(more);
+            if (more) sh.list[cur ^ 1][sh.count[cur ^ 1] + __popcll(mask & ((1ull << t) - 1))] = (uint8_t)(task + 1);
+            __syncthreads();
+            if (t == 0) sh.count[cur ^ 1] += (uint32_t)__popcll(mask);
+            __syncthreads();
+        }
+        cur ^= 1;
+    }
+    __syncthreads();
+    for (int r = 1 + t; r < n_rows; r += kTailThreads) gstate[u.first - 1 + r] = sh.end[r];
+    if (t == 0) {
+        atomicAdd(counters + 6, (unsigned)rounds);
+        atomicMax(counters + 7, (unsigned)rounds);
     }
 }
 
@@ -636,11 +760,14 @@ int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, 
 }
 
 int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
-                     unsigned int* changed, int first_pass, unsigned pool_bytes, void* stream)
+                     unsigned int* changed, int first_pass, int max_rounds, uint8_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream)
 {
     if (nunits <= 0) return 0;
     hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
-                       first_pass);
+                       first_pass, max_rounds, tail_tasks, tail_count);
+    if (tail_count)
+        hipLaunchKernelGGL(huff_tail_kernel, dim3(nunits), dim3(kTailThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
+                           tail_tasks, tail_count);
     return (int)hipGetLastError();
 }
 

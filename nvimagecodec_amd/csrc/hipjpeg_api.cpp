@@ -23,15 +23,17 @@ struct hipjpegHandle {
     int device_id = 0;
     MemoryHooks hooks;
     std::unique_ptr<ForkJoinPool> pool;
-    // two batches, used alternately: the host stage of batch k+1 can fill its pinned area while the device is still
-    // consuming batch k (same idea as the reference's two pinned pages per thread, cuda_decoder.h:50-53)
-    std::unique_ptr<DecodeBatch> batches[2];
+    // three batch pages, used in turn: the host stage and H2D copy of batches k+1 and k+2 proceed while the device is still
+    // consuming batch k (same idea as the reference's two pinned pages per thread, cuda_decoder.h:50-53; the third page
+    // keeps the copy engine a whole batch ahead of the kernels)
+    static constexpr int kPages = 3;
+    std::unique_ptr<DecodeBatch> batches[kPages];
     int current = 0;
     DecodeBatch& cur() { return *batches[current]; }
     // pipelined submission (hipjpegDecodeBatchSubmit / Wait): pages in flight, oldest first, with the stream each runs on
     std::vector<hipjpegTransform_t> transforms;  // geometry for the next batch (hipjpegDecodeBatchSetTransforms)
-    int submitted[2] = {-1, -1};
-    void* submitted_stream[2] = {nullptr, nullptr};
+    int submitted[kPages] = {-1, -1, -1};
+    void* submitted_stream[kPages] = {nullptr, nullptr, nullptr};
     int num_submitted = 0;
     hipStream_t copy_stream = nullptr;  // H2D copies of submitted batches: they overlap the kernels of the batch before
     std::unique_ptr<EncodeBatch> encode;
@@ -143,8 +145,7 @@ hipjpegStatus_t hipjpegCreate(hipjpegHandle_t* handle, int device_id, int num_ho
     if (!h) return HIPJPEG_STATUS_ALLOC_FAILED;
     h->device_id = device_id;
     h->pool.reset(new ForkJoinPool(num_host_threads));
-    h->batches[0].reset(new DecodeBatch(device_id, &h->hooks));
-    h->batches[1].reset(new DecodeBatch(device_id, &h->hooks));
+    for (auto& b : h->batches) b.reset(new DecodeBatch(device_id, &h->hooks));
     h->encode.reset(new EncodeBatch(device_id, &h->hooks));
     *handle = h;
     return HIPJPEG_STATUS_SUCCESS;
@@ -164,7 +165,7 @@ hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const uint8_t* co
                                        hipjpegStatus_t* statuses)
 {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    handle->current ^= 1;
+    handle->current = (handle->current + 1) % hipjpegHandle::kPages;
     DecodeBatch& b = handle->cur();
     static const bool timing = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;  // debug aid: host-stage phase times on stderr
     const auto t0 = std::chrono::steady_clock::now();
@@ -245,7 +246,7 @@ hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* 
                                          const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags, void* stream)
 {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    if (handle->num_submitted >= 2) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // both pages in flight: Wait first
+    if (handle->num_submitted >= hipjpegHandle::kPages) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // every page in flight: Wait first
     if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
     if (!handle->copy_stream && hipStreamCreateWithFlags(&handle->copy_stream, hipStreamNonBlocking) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     hipjpegStatus_t st = hipjpegDecodeBatchHost(handle, data, lengths, batch_size, outputs, format, flags, nullptr);
@@ -265,8 +266,10 @@ hipjpegStatus_t hipjpegDecodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* 
     DecodeBatch& b = *handle->batches[handle->submitted[0]];
     void* stream = handle->submitted_stream[0];
     if (statuses && batch_size != b.size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    handle->submitted[0] = handle->submitted[1];
-    handle->submitted_stream[0] = handle->submitted_stream[1];
+    for (int k = 1; k < handle->num_submitted; k++) {
+        handle->submitted[k - 1] = handle->submitted[k];
+        handle->submitted_stream[k - 1] = handle->submitted_stream[k];
+    }
     handle->num_submitted--;
     if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
     hipjpegStatus_t st = b.wait_done();

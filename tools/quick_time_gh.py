@@ -27,14 +27,18 @@ for rep in range(3):
     print("end-to-end decode(gpu_huffman): %.1f ms/batch %.0f img/s" % ((t1 - t0) / 3 * 1e3, 3 * B / (t1 - t0)), flush=True)
 # pipelined: two batches in flight, two output sets
 outs2 = dec.allocate_outputs(jpegs)
+outs3 = dec.allocate_outputs(jpegs)
+ring = [outs, outs2, outs3]
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.time()
-    K = 8
+    K = 30
+    ts = tw = 0.0
     for i in range(K):
-        dec.submit(jpegs, outs if i % 2 == 0 else outs2)
-        if i > 0:
-            dec.wait()
-    dec.wait()
+        a = time.time(); dec.submit(jpegs, ring[i % 3]); b = time.time(); ts += b - a
+        if i > 1:
+            dec.wait(); tw += time.time() - b
+    dec.wait(); dec.wait()
+    print("   host: submit %.2f ms, wait %.2f ms per batch" % (ts / K * 1e3, tw / (K - 2) * 1e3))
     torch.cuda.synchronize(); t1 = time.time()
     print("pipelined submit/wait: %.1f ms/batch %.0f img/s" % ((t1 - t0) / K * 1e3, K * B / (t1 - t0)), flush=True)
 ref = oracle.decode(src[1]); print("parity2", np.array_equal(outs2[1].cpu().numpy(), ref)); print("parity", np.array_equal(outs[1].cpu().numpy(), ref))
