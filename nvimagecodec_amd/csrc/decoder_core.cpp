@@ -169,6 +169,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     std::vector<size_t> xform_plane_off;  // per TransformImage plane, in order
     xform_desc_.clear();
     size_t huff_stream_total = 0, huff_subseq_ub = 0, huff_pool_total = 0, huff_blocks_total = 0, huff_raw_total = 0, huff_chunks_total = 0;
+    size_t huff_blockpos_total = 0;
     max_huff_units_ = max_huff_wunits_ = 0;
     max_pool_words_ = 0;
     std::vector<size_t> plane_off((size_t)n * 4, (size_t)-1);
@@ -325,7 +326,9 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
                 im.dc_plane_offset[c] = huff_blocks_total * 2;
                 huff_blocks_total += ((size_t)f.comp[c].blocks_w * f.comp[c].blocks_h + 31) & ~(size_t)31;
             }
-            max_huff_wunits_ += (nsub + kHuffWriteOwn - 1) / kHuffWriteOwn;
+            max_huff_wunits_ += ((size_t)f.mcus_x * f.mcus_y + kHuffMcusPerWg - 1) / kHuffMcusPerWg + 1;
+            im.block_pos_offset = huff_blockpos_total * 4;
+            huff_blockpos_total += (f.total_blocks() + 63) & ~(size_t)63;
         }
         coef_bytes_ += f.total_blocks() * 128;
         if (fmt == kOutPlanarYUV) {
@@ -391,7 +394,8 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     work_incoming_ = work_changed_ + 256;
     work_tail_ = align_up(work_incoming_ + max_huff_units_ * 8, 256);  // tail tasks (256 B per unit) + counts
     work_dc_diff_ = align_up(work_tail_ + max_huff_units_ * 260, 256);
-    work_drops_ = align_up(work_dc_diff_ + huff_blocks_total * 2, 256);
+    work_block_pos_ = align_up(work_dc_diff_ + huff_blocks_total * 2, 256);
+    work_drops_ = align_up(work_block_pos_ + huff_blockpos_total * 4, 256);
     work_streams_ = align_up(work_drops_ + huff_chunks_total * 4, 256);
     if (ng && (st = work_.reserve(work_streams_ + huff_stream_total + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     huff_images_.assign(ng, HuffImage());
@@ -563,7 +567,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         h.pool = reinterpret_cast<const uint16_t*>(device_.data() + im.tables_offset);
         h.dc_diff = reinterpret_cast<int16_t*>(work_.data() + work_dc_diff_ + im.dc_diff_offset);
         for (int c = 0; c < im.frame.ncomp; c++) h.dc_plane[c] = reinterpret_cast<int16_t*>(work_.data() + work_dc_diff_ + im.dc_plane_offset[c]);
-        for (uint32_t j = 0; j < h.num_subseq; j += kHuffWriteOwn) huff_wunits_.push_back(HuffUnit{(uint32_t)g, j});
+        h.block_pos = reinterpret_cast<uint32_t*>(work_.data() + work_block_pos_ + im.block_pos_offset);
+        for (uint32_t m = 0; m < h.mcus_x * h.mcus_y; m += kHuffMcusPerWg) huff_wunits_.push_back(HuffUnit{(uint32_t)g, m});
         for (int c = 0; c < im.frame.ncomp; c++) h.coef[c] = reinterpret_cast<int16_t*>(device_.data() + im.coef_offset[c]);
         h.first_subseq = first_subseq;
         first_subseq += h.num_subseq;
@@ -660,7 +665,7 @@ DecodeBatch::EntropyLaunch DecodeBatch::entropy_launch_args()
 bool DecodeBatch::entropy_write_passes(const EntropyLaunch& L, void* stream)
 {
     return launch_huff_scan(L.dimg, L.dlist, (int)huff_list_.size(), L.states, L.first_block, stream) == 0 &&
-           launch_huff_write(L.dimg, L.dwunits, (int)huff_wunits_.size(), L.states, L.first_block, L.pool_bytes, stream) == 0 &&
+           launch_huff_write(L.dimg, L.dunits, L.nunits, L.dwunits, (int)huff_wunits_.size(), L.states, L.first_block, L.pool_bytes, stream) == 0 &&
            launch_huff_dc(L.dimg, L.ddc, (int)huff_dc_units_.size(), stream) == 0;
 }
 

@@ -69,6 +69,7 @@ struct PlannedImage {
     size_t pool_words = 0;      // lookup-table entries of the scan (GPU entropy path)
     size_t raw_offset = 0;      // staged copy of the scan's entropy-coded bytes
     uint32_t first_chunk = 0;   // first destuff chunk (batch-wide numbering)
+    size_t block_pos_offset = 0;  // bytes into the block-position scratch
     size_t dc_diff_offset = 0;
     size_t dc_plane_offset[4] = {0, 0, 0, 0};  // bytes into the same scratch: compact DC planes per component  // bytes into the DC-difference scratch
     uint32_t stream_bytes = 0;
@@ -147,12 +148,12 @@ private:
     std::vector<int> huff_to_image_;
     size_t huff_desc_offset_ = 0, huff_units_offset_ = 0, huff_dc_units_offset_ = 0, huff_list_offset_ = 0, h2d_bytes_ = 0;
     size_t gpu_coef_begin_ = 0, gpu_coef_bytes_ = 0, total_subseq_ = 0, max_huff_units_ = 0, max_pool_words_ = 0;
-    size_t work_first_block_ = 0, work_changed_ = 0, work_incoming_ = 0, work_tail_ = 0, work_dc_diff_ = 0, work_drops_ = 0, work_streams_ = 0;
+    size_t work_first_block_ = 0, work_changed_ = 0, work_incoming_ = 0, work_tail_ = 0, work_dc_diff_ = 0, work_block_pos_ = 0, work_drops_ = 0, work_streams_ = 0;
     size_t huff_chunk_units_offset_ = 0, huff_wunits_offset_ = 0, max_huff_wunits_ = 0;
     std::vector<TransformImage> xform_desc_;
     std::vector<WorkUnit> xform_units_;
     size_t xform_desc_offset_ = 0, xform_units_offset_ = 0;
-    std::vector<HuffUnit> huff_wunits_;  // write kernel: kHuffWriteOwn subsequences per workgroup
+    std::vector<HuffUnit> huff_wunits_;  // block kernel: kHuffMcusPerWg MCUs per workgroup
     std::vector<HuffUnit> huff_chunk_units_;  // offsets into work_
     uint64_t stream_bytes_total_ = 0;
     int last_sync_launches_ = 0;

@@ -24,8 +24,10 @@ int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, 
 int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
                      unsigned int* changed, int first_pass, int max_rounds, uint8_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream);
 int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages, const unsigned long long* states, uint32_t* first_block, void* stream);
-int launch_huff_write(HuffImage* images, const HuffUnit* units, int nunits, const unsigned long long* states, const uint32_t* first_block,
-                      unsigned pool_bytes, void* stream);
+// Write pass: position kernel over the sync units, then the block kernel over block_units ({image, first MCU}, kHuffMcusPerWg
+// MCUs each).
+int launch_huff_write(HuffImage* images, const HuffUnit* sync_units, int nsync_units, const HuffUnit* block_units, int nblock_units,
+                      const unsigned long long* states, const uint32_t* first_block, unsigned pool_bytes, void* stream);
 int launch_huff_dc(const HuffImage* images, const HuffUnit* units, int nunits, void* stream);
 
 }  // namespace hipjpeg

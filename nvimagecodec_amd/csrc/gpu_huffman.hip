@@ -16,7 +16,8 @@
 //   huff_sync_kernel   pass 0 + workgroup-local synchronisation loop in LDS; publishes end states; counts the workgroups
 //                      whose LAST end state moved (the only state another workgroup consumes)
 //   huff_scan_kernel   per image: exclusive scan of completed-block counts -> first block index of every subsequence
-//   huff_write_kernel  final decode with coefficient stores (DC differences to a compact array)
+//   huff_pos_kernel    where every block starts (walk from the converged states)
+//   huff_blocks_kernel one lane per block: decode into LDS, store whole 128-byte lines (DC differences to a compact array)
 //   huff_dc_kernel     per (image, component): DC differences -> DC values, stored into the blocks
 #include <hip/hip_runtime.h>
 
@@ -581,39 +582,83 @@ __global__ __launch_bounds__(kThreads) void huff_scan_kernel(HuffImage* __restri
         fb[i] = run;
         run += (uint32_t)(st[i] >> 48);
     }
-    if (threadIdx.x == kThreads - 1 && s_sum[kThreads - 1] < im.total_blocks) im.status = 2;  // the stream ends before the last block
+    if (threadIdx.x == kThreads - 1) {
+        im.decoded_blocks = s_sum[kThreads - 1];
+        if (s_sum[kThreads - 1] < im.total_blocks) im.status = 2;  // the stream ends before the last block
+    }
 }
 
-// ---- write pass -----------------------------------------------------------------------------------------------------------
-// 128 lanes, one subsequence each (no halo).  Besides the stream rows (two extra rows for the last lane's overshoot into the
-// successor workgroup's range) every lane has a 128-byte block buffer in LDS: coefficients land there, and a finished block
-// leaves as eight 16-byte stores -- one full 128-byte line, written once.  (Scattered 2-byte stores into a zeroed arena cost
-// 2.5x the arena size in partial-line HBM writes, plus the memset.)
-constexpr int kWThreads = kHuffWriteOwn;
-constexpr int kWRows = kWThreads + 2;  // a block is at most 31 + 63 * 31 bits: it ends less than two subsequences past its start
-constexpr int kBlockBufBytes = 144;  // 128 + 16: 16-byte aligned rows whose starts are spread over the banks
+// ---- write pass, step 1: where the blocks start -----------------------------------------------------------------------------
+// Same workgroup shape as the sync kernel (lane 0 idles): every lane walks its subsequence from the converged start state
+// and records the bit position of each block that starts inside it.
+__global__ __launch_bounds__(kThreads) void huff_pos_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+                                                            const unsigned long long* __restrict__ states, const uint32_t* __restrict__ first_block)
+{
+    __shared__ WgShared sh;
+    extern __shared__ uint16_t dyn_pool[];
+    HJ_LDS uint16_t* pool = (HJ_LDS uint16_t*)dyn_pool;
+    const HuffUnit u = units[blockIdx.x];
+    const HuffImage& im = images[u.image];
+    const HuffGeom geom = make_geom(im);
+    const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
+    if (u.first >= nsub) return;
+    stage_rows<kThreads, kThreads>(sh.stream, im, (int)u.first - 1);
+    stage_pool<kThreads>(pool, im);
+    stage_constants(sh.tsel, nullptr, nullptr, im, false);
+    __syncthreads();
+    const int t = threadIdx.x;
+    const uint32_t j = u.first - 1 + t;
+    if (t == 0 || j >= nsub) return;
+    const DevEnv env = make_env(sh, pool, u.first);
+    const unsigned long long* st = states + im.first_subseq;
+    uint32_t begin = 0;
+    int z = 0, k = 0;
+    if (j > 0) {
+        const SubseqState p = unpack_state(st[j - 1]);
+        begin = p.end_bit;
+        z = p.zk & 255;
+        k = p.zk >> 8;
+    }
+    HJ_GLOBAL uint32_t* out = (HJ_GLOBAL uint32_t*)im.block_pos;
+    const uint32_t total_blocks = im.total_blocks;
+    position_subsequence(geom, env, begin, (j + 1) * kSubseqBits, z, k, first_block[im.first_subseq + j], [&](uint32_t block, uint32_t pos) {
+        if (block < total_blocks) out[block] = pos;
+    });
+}
 
-struct WriteShared {
-    uint32_t stream[staged_lds_words(kWRows)];
-    __attribute__((aligned(16))) uint8_t blocks[kWThreads * kBlockBufBytes];
+// ---- write pass, step 2: one lane per block -----------------------------------------------------------------------------------
+// 256 consecutive blocks (scan order) of one image per workgroup.  The bitstream span they cover is staged in LDS (the
+// blocks of a 1080p q90 image average ~80 bits; a span that does not fit is read from memory instead), every lane decodes
+// its block into a 128-byte LDS buffer, and the finished blocks leave as whole 128-byte lines, eight lanes per block --
+// each line written once, no memset, no partial-line traffic.  Lanes idle once their block is done: chroma blocks are
+// short, luma blocks long; the wave runs as long as its longest block.
+constexpr int kBThreads = kHuffBlocksPerWg;
+constexpr int kBStreamWords = 4096;
+constexpr int kBlockBufBytes = 144;  // 128 + 16: 16-byte aligned buffers whose starts are spread over the banks
+
+struct BlockShared {
+    uint32_t stream[kBStreamWords];
+    __attribute__((aligned(16))) uint8_t blocks[kBThreads * kBlockBufBytes];
+    int16_t* dst[kBThreads];
     KSlot kslot[10];
     uint32_t tsel[10];
     uint32_t zz[16];  // zigzag permutation, 4 entries per word
+    uint32_t span[2]; // first staged word, number of staged words (0: the span does not fit, read from memory)
 };
 
-struct WriteEnv {
-    uint32_t stream_base;  // LDS byte address of the staged rows
-    uint32_t word0;        // image word index of the first staged word
-    uint32_t pool;
-    uint32_t buf;          // LDS byte address of this lane's block buffer
-    int16_t* dc_diff;
+struct BlockEnv {
+    uint32_t stream_base, word0, staged;  // LDS byte address of the staged words, image index of the first, how many
+    const uint32_t* gstream;
+    uint32_t gwords;
+    uint32_t pool, buf;
     const HJ_LDS uint32_t* tsel;
     const HJ_LDS KSlot* kslot;
     const HJ_LDS uint8_t* zz;
     __device__ __forceinline__ uint32_t word(uint32_t i) const
     {
-        const uint32_t local = i - word0;  // always inside the staged range: see kWRows
-        return *(const HJ_LDS uint32_t*)(uintptr_t)(stream_base + ((local + (local >> 5)) << 2));
+        const uint32_t local = i - word0;
+        if (local < staged) return *(const HJ_LDS uint32_t*)(uintptr_t)(stream_base + (local << 2));
+        return i < gwords ? __builtin_bswap32(((const HJ_GLOBAL uint32_t*)gstream)[i]) : ~0u;
     }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
     __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
@@ -633,65 +678,90 @@ struct WriteEnv {
     }
     __device__ __forceinline__ int zigzag(int z) const { return zz[z]; }
     __device__ __forceinline__ void put(int index, int value) const { *(HJ_LDS int16_t*)(uintptr_t)(buf + index * 2) = (int16_t)value; }
-    __device__ __forceinline__ void flush(int16_t* dst, uint32_t block) const
-    {
-        ((HJ_GLOBAL int16_t*)dc_diff)[block] = *(const HJ_LDS int16_t*)(uintptr_t)(buf + 128);
-        *(HJ_LDS int16_t*)(uintptr_t)(buf + 128) = 0;
-        HJ_LDS u32x4* b = (HJ_LDS u32x4*)(uintptr_t)buf;
-        u32x4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = b[i];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            __builtin_nontemporal_store(v[i], (HJ_GLOBAL u32x4*)dst + i);  // explicitly global: a flat store would tie up the LDS counter
-            b[i] = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
 };
 
-__global__ __launch_bounds__(kWThreads) void huff_write_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
-                                                               const unsigned long long* __restrict__ states, const uint32_t* __restrict__ first_block)
+__global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units)
 {
-    __shared__ WriteShared sh;
+    __shared__ BlockShared sh;
     extern __shared__ uint16_t dyn_pool[];
     HJ_LDS uint16_t* pool = (HJ_LDS uint16_t*)dyn_pool;
-    const HuffUnit u = units[blockIdx.x];
+    const HuffUnit u = units[blockIdx.x];  // first = first MCU of the workgroup's kHuffMcusPerWg MCUs
     HuffImage& im = images[u.image];
     const HuffGeom geom = make_geom(im);
-    const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
-    if (u.first >= nsub) return;
+    const uint32_t bpm = geom.blocks_per_mcu;
+    const uint32_t nblocks = min(im.total_blocks, im.decoded_blocks);  // a truncated stream: the scan kernel has flagged it
+    const uint32_t b_first = u.first * bpm;
+    if (b_first >= nblocks) return;
     const int t = threadIdx.x;
-    stage_rows<kWThreads, kWRows>(sh.stream, im, (int)u.first);
-    stage_pool<kWThreads>(pool, im);
-    stage_constants(sh.tsel, sh.kslot, sh.zz, im, true);
-    {
-        HJ_LDS u32x4* b = (HJ_LDS u32x4*)&sh.blocks[t * kBlockBufBytes];
-#pragma unroll
-        for (int i = 0; i < kBlockBufBytes / 16; i++) b[i] = u32x4{0u, 0u, 0u, 0u};
+    const uint32_t mcus = min((uint32_t)kHuffMcusPerWg, geom.mcus_x * geom.mcus_y - u.first);
+    const uint32_t items = mcus * bpm;
+    if (t == 0) {
+        // the span of the stream these blocks cover: from the first block's word to the start of the block behind the last
+        const uint32_t b_end = b_first + items;
+        const uint32_t end_bit = b_end < nblocks ? im.block_pos[b_end] : geom.total_bits;
+        const uint32_t w_lo = im.block_pos[b_first] >> 5, w_hi = (end_bit >> 5) + kStagedExtra;
+        sh.span[0] = w_lo;
+        sh.span[1] = (w_hi - w_lo <= (uint32_t)kBStreamWords) ? w_hi - w_lo : 0u;
     }
+    stage_pool<kBThreads>(pool, im);
+    stage_constants(sh.tsel, sh.kslot, sh.zz, im, true);
+    HJ_LDS u32x4* my_buf = (HJ_LDS u32x4*)&sh.blocks[t * kBlockBufBytes];
+#pragma unroll
+    for (int i = 0; i < kBlockBufBytes / 16; i++) my_buf[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
-    const uint32_t j = u.first + t;
-    if (j >= nsub) return;
-    WriteEnv env;
+    const uint32_t w_lo = sh.span[0], staged = sh.span[1];
+    {
+        const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
+        const uint32_t gwords = im.stream_words;
+        for (uint32_t i = t; i < staged; i += kBThreads) sh.stream[i] = w_lo + i < gwords ? __builtin_bswap32(g[w_lo + i]) : ~0u;
+    }
+    BlockEnv env;
     env.stream_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)sh.stream;
-    env.word0 = u.first * kSubseqWords;
+    env.word0 = w_lo;
+    env.staged = staged;
+    env.gstream = reinterpret_cast<const uint32_t*>(im.stream);
+    env.gwords = im.stream_words;
     env.pool = (uint32_t)(uintptr_t)pool;
     env.buf = (uint32_t)(uintptr_t)(HJ_LDS uint8_t*)&sh.blocks[t * kBlockBufBytes];
-    env.dc_diff = geom.dc_diff;
     env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
     env.kslot = (const HJ_LDS KSlot*)sh.kslot;
     env.zz = (const HJ_LDS uint8_t*)sh.zz;
-    const unsigned long long* st = states + im.first_subseq;
-    uint32_t begin = 0;
-    int z = 0, k = 0;
-    if (j > 0) {
-        const SubseqState p = unpack_state(st[j - 1]);
-        begin = p.end_bit;
-        z = p.zk & 255;
-        k = p.zk >> 8;
-    }
     uint32_t err = 0;
-    write_subsequence(geom, env, begin, (j + 1) * kSubseqBits, z, k, make_cursor(geom, env, first_block[im.first_subseq + j], k), &err);
+    // Work items are ordered by MCU position first: item i is position i / mcus of MCU i % mcus, so that the 256 lanes of
+    // a round hold blocks of the same component -- luma blocks run ~4x longer than chroma blocks, and a wave takes as long
+    // as its longest block.
+    for (uint32_t base = 0; base < items; base += kBThreads) {
+        __syncthreads();  // staged stream (first round) / zeroed buffers (later rounds) are in place
+        const uint32_t item = base + t;
+        int16_t* dst = nullptr;
+        if (item < items) {
+            const uint32_t k = item / mcus, mcu = u.first + (item - k * mcus);
+            const uint32_t b = mcu * bpm + k;
+            if (b < nblocks) {
+                const uint32_t my = mcu / geom.mcus_x, mx = mcu - my * geom.mcus_x;
+                dst = env.block_ptr((int)k, mx, my);
+                const int dc = decode_block(geom, env, im.block_pos[b], (int)k, &err);
+                ((HJ_GLOBAL int16_t*)geom.dc_diff)[b] = (int16_t)dc;
+            }
+        }
+        sh.dst[t] = dst;
+        __syncthreads();
+        // eight lanes per block, 16 bytes each: every store instruction writes eight whole lines
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int blk = (t & ~63) + 8 * i + ((t & 63) >> 3), chunk = t & 7;
+            int16_t* p = sh.dst[blk];
+            if (p) {
+                const u32x4 v = *(const HJ_LDS u32x4*)&sh.blocks[blk * kBlockBufBytes + chunk * 16];
+                __builtin_nontemporal_store(v, (HJ_GLOBAL u32x4*)p + chunk);
+            }
+        }
+        if (base + kBThreads < items) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; i++) my_buf[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
     if (err) im.status = 1;  // benign race: every writer stores the same value
 }
 
@@ -778,11 +848,12 @@ int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages,
     return (int)hipGetLastError();
 }
 
-int launch_huff_write(HuffImage* images, const HuffUnit* units, int nunits, const unsigned long long* states, const uint32_t* first_block,
-                      unsigned pool_bytes, void* stream)
+int launch_huff_write(HuffImage* images, const HuffUnit* sync_units, int nsync_units, const HuffUnit* block_units, int nblock_units,
+                      const unsigned long long* states, const uint32_t* first_block, unsigned pool_bytes, void* stream)
 {
-    if (nunits <= 0) return 0;
-    hipLaunchKernelGGL(huff_write_kernel, dim3(nunits), dim3(kWThreads), pool_bytes, (hipStream_t)stream, images, units, states, first_block);
+    if (nsync_units <= 0) return 0;
+    hipLaunchKernelGGL(huff_pos_kernel, dim3(nsync_units), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, sync_units, states, first_block);
+    if (nblock_units > 0) hipLaunchKernelGGL(huff_blocks_kernel, dim3(nblock_units), dim3(kBThreads), pool_bytes, (hipStream_t)stream, images, block_units);
     return (int)hipGetLastError();
 }
 

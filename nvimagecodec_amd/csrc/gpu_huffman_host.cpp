@@ -215,14 +215,8 @@ struct HostEnv {
         return im->coef[hk.comp] + ((size_t)hk.blk0 + (size_t)my * hk.stride_y + (size_t)mx * hk.stride_x) * 64;
     }
     int zigzag(int z) const { return kZigzagDeviceGpuHost[z]; }
-    int16_t* buf;  // block buffer: 64 coefficients + the DC difference
+    int16_t* buf;  // block buffer: 64 coefficients
     void put(int index, int value) const { buf[index] = (int16_t)value; }
-    void flush(int16_t* dst, uint32_t block) const
-    {
-        memcpy(dst, buf, 128);
-        im->dc_diff[block] = buf[64];
-        memset(buf, 0, 130);
-    }
 };
 }  // namespace
 
@@ -244,7 +238,7 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
         im.coef[c] = coef[c];
         memset(coef[c], 0x5A, (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 128);  // every block must be written by the write pass
     }
-    int16_t block_buffer[65] = {0};
+    int16_t block_buffer[64] = {0};
     const HostEnv env{&im, block_buffer};
     const HuffGeom geom = make_geom(im);
     const uint32_t ns = im.num_subseq;
@@ -275,11 +269,23 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
         acc += cur[i].nblocks;
     }
     if (acc < im.total_blocks) return 2;
-    // write pass
+    // write pass, step 1: block start positions
+    std::vector<uint32_t> block_pos(im.total_blocks, 0xFFFFFFFFu);
     for (uint32_t i = 0; i < ns; i++) {
         const uint32_t begin = i == 0 ? 0 : cur[i - 1].end_bit;
         const int z = i == 0 ? 0 : (cur[i - 1].zk & 255), k = i == 0 ? 0 : (cur[i - 1].zk >> 8);
-        write_subsequence(geom, env, begin, (i + 1) * kSubseqBits, z, k, make_cursor(geom, env, first_block[i], k), &err);
+        position_subsequence(geom, env, begin, (i + 1) * kSubseqBits, z, k, first_block[i], [&](uint32_t block, uint32_t pos) {
+            if (block < im.total_blocks) block_pos[block] = pos;
+        });
+    }
+    // step 2: every block on its own
+    for (uint32_t b = 0; b < im.total_blocks; b++) {
+        if (block_pos[b] == 0xFFFFFFFFu) return 2;
+        int k;
+        int16_t* dst = block_address(geom, env, b, &k);
+        memset(block_buffer, 0, sizeof block_buffer);
+        dc_diff[b] = (int16_t)decode_block(geom, env, block_pos[b], k, &err);
+        memcpy(dst, block_buffer, 128);
     }
     if (err) return 1;
     // DC integration, per component in MCU (scan) order

@@ -15,9 +15,9 @@
 //              is exact).
 //   count      each pass also counts the blocks completed in the subsequence; an exclusive scan gives every lane the
 //              index of its first block.
-//   write      the lanes decode once more; each assembles the blocks that start in its subsequence and stores them whole
-//              (column-major block layout, DC position left zero); DC differences go to a compact per-image array in scan
-//              order.
+//   write      step 1: the lanes walk their subsequences once more and record where every block starts; step 2: one lane
+//              per BLOCK decodes it from its start position into a buffer and the blocks are stored whole (column-major
+//              block layout, DC position left zero); DC differences go to a compact per-image array in scan order.
 //   dc         a per-component scan in MCU order turns DC differences into DC values, stored as one compact plane per
 //              component (raster block order) that the IDCT kernels read next to the coefficient blocks.
 // All decisions are integer/bit exact; the result is compared with the host entropy decoder and the oracle in tests/.
@@ -39,7 +39,8 @@ constexpr int kHuffFastBits = 10;      // first-level lookup width
 constexpr int kHuffSubBits = 16 - kHuffFastBits;
 constexpr int kStreamSlackBytes = 32;  // readable bytes after the last real byte of a destuffed stream
 constexpr int kHuffOwn = 255;          // subsequences per workgroup of the sync/write kernels (256 lanes, one is the halo)
-constexpr int kHuffWriteOwn = 128;     // subsequences (= lanes) per workgroup of the write kernel
+constexpr int kHuffBlocksPerWg = 256;   // lanes per workgroup of the block pass (one block per lane per round)
+constexpr int kHuffMcusPerWg = 128;     // MCUs a workgroup of the block pass covers
 constexpr int kDestuffChunk = 16384;   // raw bytes one workgroup of the destuff kernels handles
 constexpr int kMaxPoolWords = 12288;   // uint16 entries of lookup tables per image the kernels accept (24 KB of LDS)
 
@@ -82,7 +83,10 @@ struct alignas(16) HuffImage {
     uint32_t status;         // written by the kernels: 0 ok, 1 = invalid code inside the real data, 2 = block count mismatch
     uint32_t first_chunk;    // index of this image's first kDestuffChunk-byte chunk in the batch-wide drop-count array
     const uint8_t* raw;      // the scan's entropy-coded bytes as they are in the file (byte-stuffed), padded to 16 bytes
-    uint32_t raw_bytes, pad0;
+    uint32_t raw_bytes;
+    uint32_t decoded_blocks; // blocks the converged decoders completed (scan kernel); < total_blocks = truncated stream
+    uint32_t* block_pos;     // total_blocks bit positions: where every block starts (position pass -> block pass)
+    uint64_t pad0;
     HuffK k[10];
     uint32_t blocks_w[4];
     uint8_t comp_h[4], comp_v[4], comp_k0[4], pad1[4];  // comp_k0 = first position k of the component inside the MCU
@@ -127,12 +131,6 @@ HJ_HD HuffGeom make_geom(const HuffImage& im)
     g.dc_diff = im.dc_diff;
     return g;
 }
-
-// Where the write pass is: block index in scan order, MCU coordinates, and the block being filled.
-struct HuffCursor {
-    uint32_t block, mx, my;
-    int16_t* blk;  // nullptr = past the last block of the scan
-};
 
 // MSB-first bit reader over 32-bit words fetched through Env::word(index): `hi` always holds the next 32 bits of the stream
 // (a symbol is at most 16 code + 15 value bits), `lo` the bits behind them.  The word that may be needed next is requested
@@ -211,85 +209,89 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
     return st;
 }
 
-// Write pass.  The subsequence's lane OWNS the blocks whose first (DC) symbol starts in [begin, limit): it decodes each of
-// them to its end -- past `limit` for the last one -- collects the coefficients in a block buffer and flushes whole blocks,
-// so that every block is stored exactly once, by one lane, as one 128-byte line.  A block already in progress at `begin`
-// (z != 0) belongs to the predecessor: its symbols are decoded to find the next block boundary but not stored.
-// DC differences go to dc_diff[scan-order block index].
-// Env additionally supplies:
-//   int16_t* block_ptr(int k, mx, my)    address of the block at position k of MCU (mx, my)
-//   int      zigzag(int z)               device-layout index of zigzag position z
-//   void     put(int index, int value)   store into the (zero-initialised) block buffer; index 64 = the DC difference
-//   void     flush(int16_t* dst, block)  copy the 64 coefficients to dst and the DC difference to dc_diff[block] (scan-order
-//                                        block index), zero the buffer again
-// `cur` is the cursor of the block that contains the first symbol.
-template <class Env>
-HJ_HD void write_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, HuffCursor cur, uint32_t* error)
+// Write pass, step 1 -- where the blocks start.  Same walk as decode_subsequence from the converged start state; calls
+// rec(block, pos) for every block whose first (DC) symbol starts in [begin, limit): `block` = scan-order index, `pos` = bit
+// position.  `block0` is the index of the block in progress at `begin` (the scan's prefix sum of completed blocks).
+template <class Env, class Rec>
+HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, uint32_t block0, const Rec& rec)
 {
-    uint32_t pos = begin;
+    uint32_t pos = begin, block = block0;
     const uint32_t end = limit < im.total_bits ? limit : im.total_bits;
     const int bpm = (int)im.blocks_per_mcu;
     uint32_t tsel = env.tables(k);
     uint32_t tcur = z == 0 ? (tsel & 0xFFFFu) : (tsel >> 16);
-    bool own = z == 0;
+    if (z == 0 && pos < end) rec(block, pos);
+    BitReader br;
+    br.start(env, pos);
+    while (pos < end) {
+        const uint32_t fetched = env.word(br.next);
+        uint32_t e = env.lookup1(tcur, br.hi);
+        if ((e >> 9) == kZadvLong) e = env.lookup2(e, br.hi);
+        pos += e & 31u;
+        br.consume(e & 31u, fetched);
+        z += (int)(e >> 9);
+        tcur = tsel >> 16;
+        if (z >= 64) {
+            z = 0;
+            block++;
+            if (++k == bpm) k = 0;
+            tsel = env.tables(k);
+            tcur = tsel & 0xFFFFu;
+            if (pos < end) rec(block, pos);
+        }
+    }
+}
+
+// Write pass, step 2 -- one block, from its start position: every block is an independent piece of work once step 1 has
+// found where it begins.  Coefficients go to env.put(device-layout index, value) (a zero-initialised 64-entry buffer);
+// returns the DC difference.  *error is set for an invalid code, a run past position 63, or a stream that ends inside the
+// block.  k = the block's position inside its MCU (selects the tables).
+// Env additionally supplies:  int zigzag(int z)  and  void put(int index, int value).
+template <class Env>
+HJ_HD int decode_block(const HuffGeom& im, const Env& env, uint32_t pos, int k, uint32_t* error)
+{
+    const uint32_t tsel = env.tables(k);
+    uint32_t tcur = tsel & 0xFFFFu;
+    int z = 0, dc = 0;
     uint32_t err = 0;
     BitReader br;
     br.start(env, pos);
-    while (pos < im.total_bits && (pos < end || (own && z != 0))) {
+    while (pos < im.total_bits && z < 64) {
         const uint32_t fetched = env.word(br.next);
         const uint32_t w = br.hi;
-        const bool is_dc = z == 0;
         uint32_t e = env.lookup1(tcur, w);
         if ((e >> 9) == kZadvLong) e = env.lookup2(e, w);
         const uint32_t total = e & 31u, zadv = e >> 9;
-        {
-            // straight-line arithmetic and ONE predicated store: lanes of a wave sit at unrelated points of their blocks.
-            // The DC difference travels in slot 64 of the block buffer and leaves with the flush.
-            const bool live = own && cur.blk != nullptr;
-            const uint32_t nb_raw = (e >> 5) & 15u;
-            const bool bad_code = nb_raw >= total;  // "no such code"
-            const uint32_t nb = bad_code ? 0u : nb_raw;
-            // nb value bits follow the code; values below 2^(nb-1) are the negative half (JPEG "EXTEND")
-            const uint32_t v = ((w << (total - nb)) >> 1) >> (31 - nb);
-            const int val = v < ((1u << nb) >> 1) ? (int)v - (int)(1u << nb) + 1 : (int)v;
-            const uint32_t zpos = (uint32_t)z + zadv - 1;
-            const bool ac = !is_dc && nb != 0;
-            err |= (uint32_t)(live & (bad_code | (ac & (zpos > 63))));  // invalid code / run past the end of the block
-            if (live & (is_dc | (ac & (zpos <= 63)))) env.put(is_dc ? 64 : env.zigzag((int)(zpos & 63)), val);
-        }
+        const uint32_t nb_raw = (e >> 5) & 15u;
+        const bool bad_code = nb_raw >= total;  // "no such code"
+        const uint32_t nb = bad_code ? 0u : nb_raw;
+        // nb value bits follow the code; values below 2^(nb-1) are the negative half (JPEG "EXTEND")
+        const uint32_t v = ((w << (total - nb)) >> 1) >> (31 - nb);
+        const int val = v < ((1u << nb) >> 1) ? (int)v - (int)(1u << nb) + 1 : (int)v;
+        const uint32_t zpos = (uint32_t)z + zadv - 1;
+        const bool is_dc = z == 0;
+        const bool ac = !is_dc && nb != 0;
+        err |= (uint32_t)(bad_code | (ac & (zpos > 63)));
+        dc = is_dc ? val : dc;
+        if (ac & (zpos <= 63)) env.put(env.zigzag((int)(zpos & 63)), val);
         pos += total;
         br.consume(total, fetched);
         z += (int)zadv;
         tcur = tsel >> 16;
-        if (z >= 64) {
-            if (own && cur.blk) env.flush(cur.blk, cur.block);
-            own = true;  // whatever starts now starts inside the lane's range, or the loop ends
-            z = 0;
-            if (++k == bpm) k = 0;
-            tsel = env.tables(k);
-            tcur = tsel & 0xFFFFu;
-            cur.block++;
-            if (k == 0 && ++cur.mx == im.mcus_x) {
-                cur.mx = 0;
-                cur.my++;
-            }
-            cur.blk = cur.my < im.mcus_y ? env.block_ptr(k, cur.mx, cur.my) : nullptr;
-        }
     }
+    if (z < 64) err = 1;  // the stream ended inside the block
     if (err) *error = 1;
+    return dc;
 }
 
-// Cursor for the block with scan-order index `block` whose position inside the MCU is k.
+// Address of scan-order block `block`: env.block_ptr(k, mx, my) with k = block % blocks_per_mcu, (mx, my) = its MCU.
 template <class Env>
-HJ_HD HuffCursor make_cursor(const HuffGeom& im, const Env& env, uint32_t block, int k)
+HJ_HD int16_t* block_address(const HuffGeom& im, const Env& env, uint32_t block, int* k_out)
 {
-    HuffCursor c;
-    c.block = block;
-    const uint32_t mcu = block / im.blocks_per_mcu;  // == (block - k) / blocks_per_mcu
-    c.my = mcu / im.mcus_x;
-    c.mx = mcu - c.my * im.mcus_x;
-    c.blk = c.my < im.mcus_y ? env.block_ptr(k, c.mx, c.my) : nullptr;
-    return c;
+    const uint32_t mcu = block / im.blocks_per_mcu, k = block - mcu * im.blocks_per_mcu;
+    const uint32_t my = mcu / im.mcus_x, mx = mcu - my * im.mcus_x;
+    *k_out = (int)k;
+    return env.block_ptr((int)k, mx, my);
 }
 
 }  // namespace hipjpeg
