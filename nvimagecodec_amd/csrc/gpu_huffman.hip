@@ -777,21 +777,24 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
     const uint32_t bpm = im.blocks_per_mcu, k0 = im.comp_k0[c];
     const uint32_t mcus = im.mcus_x * im.mcus_y;
     const uint32_t n = mcus * bpc;
-    int16_t* plane = im.dc_plane[c];
-    const int16_t* diff = im.dc_diff;
+    HJ_GLOBAL int16_t* plane = (HJ_GLOBAL int16_t*)im.dc_plane[c];
+    const HJ_GLOBAL int16_t* diff = (const HJ_GLOBAL int16_t*)im.dc_diff;
     const uint32_t bw = im.blocks_w[c], mcus_x = im.mcus_x;
+    // entry s of the component (MCU order) sits at diff[(s / bpc) * bpm + k0 + s % bpc]; every lane takes a contiguous run
     const uint32_t per = (n + kThreads - 1) / kThreads;
     const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    auto index_of = [&](uint32_t s) {
+        const uint32_t mcu = s / bpc;
+        return mcu * bpm + k0 + (s - mcu * bpc);
+    };
+    constexpr int kBatch = 8;  // independent loads in flight per lane
     int sum = 0;
-    {
-        uint32_t mcu = lo / bpc, jj = lo - mcu * bpc;
-        for (uint32_t s = lo; s < hi; s++) {
-            sum += diff[mcu * bpm + k0 + jj];
-            if (++jj == bpc) {
-                jj = 0;
-                mcu++;
-            }
-        }
+    for (uint32_t s = lo; s < hi; s += kBatch) {
+        int d[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) d[i] = s + i < hi ? (int)diff[index_of(s + i)] : 0;
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) sum += d[i];
     }
     s_sum[threadIdx.x] = sum;
     __syncthreads();
@@ -802,18 +805,18 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
         __syncthreads();
     }
     int run = threadIdx.x ? s_sum[threadIdx.x - 1] : 0;
-    uint32_t mcu = lo / bpc, jj = lo - mcu * bpc;
-    uint32_t my = mcu / mcus_x, mx = mcu - my * mcus_x;
-    for (uint32_t s = lo; s < hi; s++) {
-        run += diff[mcu * bpm + k0 + jj];
-        const uint32_t dy = jj / h, dx = jj - dy * h;
-        plane[(my * v + dy) * bw + (mx * h + dx)] = (int16_t)run;
-        if (++jj == bpc) {
-            jj = 0;
-            mcu++;
-            if (++mx == mcus_x) {
-                mx = 0;
-                my++;
+    for (uint32_t s = lo; s < hi; s += kBatch) {
+        int d[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) d[i] = s + i < hi ? (int)diff[index_of(s + i)] : 0;
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) {
+            run += d[i];
+            if (s + i < hi) {
+                const uint32_t mcu = (s + i) / bpc, jj = (s + i) - mcu * bpc;
+                const uint32_t my = mcu / mcus_x, mx = mcu - my * mcus_x;
+                const uint32_t dy = jj / h, dx = jj - dy * h;
+                plane[(my * v + dy) * bw + (mx * h + dx)] = (int16_t)run;
             }
         }
     }
