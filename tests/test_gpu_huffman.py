@@ -100,3 +100,49 @@ def test_config1_batch_1080p_gpu_huffman_repeated(dec):
             if j not in refs:
                 refs[j] = oracle.decode(j)
             assert np.array_equal(o.cpu().numpy(), refs[j])
+
+
+def test_randomly_damaged_streams_never_disagree_with_the_host_path(dec):
+    """Deterministic fuzzing: bit flips, byte overwrites, truncations and spliced scans in one batch.  Whatever the damage,
+    the GPU entropy stage must end in the same verdict (decodable or not) as the host entropy stage, and where both decode
+    the pixels must be identical -- and no kernel may fault on the way."""
+    import random
+    import torch
+    rng = random.Random(20240607)
+    bases = [oracle.encode(synth_image(w, h, seed=s), sub, q) for (w, h, sub, q, s) in
+             ((640, 360, "420", 90, 1), (321, 243, "422", 75, 2), (200, 200, "444", 95, 3), (512, 64, "gray", 60, 4))]
+    jpegs = []
+    for _ in range(48):
+        b = bytearray(rng.choice(bases))
+        sos = bytes(b).rfind(b"\xff\xda") + 14
+        kind = rng.randrange(5)
+        if kind == 0:    # flip a few bits inside the scan
+            for _ in range(rng.randrange(1, 6)):
+                i = rng.randrange(sos, len(b) - 2)
+                b[i] ^= 1 << rng.randrange(8)
+        elif kind == 1:  # overwrite a run of bytes
+            i = rng.randrange(sos, len(b) - 40)
+            for k in range(rng.randrange(1, 32)):
+                b[i + k] = rng.randrange(256)
+        elif kind == 2:  # truncate, keep an EOI
+            b = b[: rng.randrange(sos + 1, len(b) - 2)] + b"\xff\xd9"
+        elif kind == 3:  # drop a chunk from the middle of the scan
+            i = rng.randrange(sos, len(b) - 200)
+            del b[i : i + rng.randrange(1, 150)]
+        else:            # append garbage scan data before the EOI
+            b = b[:-2] + bytes(rng.randrange(256) for _ in range(rng.randrange(1, 300))) + b"\xff\xd9"
+        jpegs.append(bytes(b))
+    outs_g = dec.allocate_outputs(jpegs)
+    _, st_gpu = dec.decode(jpegs, outs=outs_g, gpu_huffman=True, check=False)
+    torch.cuda.synchronize()
+    got = [o.cpu().numpy().copy() if o is not None else None for o in outs_g]
+    _, st_cpu = dec.decode(jpegs, outs=outs_g, gpu_huffman=False, check=False)
+    torch.cuda.synchronize()
+    assert [s == 0 for s in st_gpu] == [s == 0 for s in st_cpu]
+    for i, (s, o) in enumerate(zip(st_cpu, outs_g)):
+        if s == 0:
+            assert np.array_equal(got[i], o.cpu().numpy()), i
+    # the decoder is still healthy afterwards
+    outs, _ = dec.decode(bases[:2], gpu_huffman=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(bases[0]))
