@@ -314,8 +314,8 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
     unsigned long long* final_off = reinterpret_cast<unsigned long long*>(dev2 + q_foff);
     uint8_t* arena = dev2 + q_arena;
     if (hipMemcpyAsync(dev2, pin + p_up2, up2, hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-    if (hipMemsetAsync(dev2 + q_raw, 0, raw_total, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-    if (launch_henc_write(dimg2, dunits, (int)units.size(), dtables, block_off, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_henc_zero(dev2 + q_raw, raw_total, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_henc_write(dimg2, dunits, (int)units.size(), dtables, block_off, block_bits, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_henc_count(dimg2, dchunks, (int)nchunks, chunk_ff, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_henc_layout(dimg2, ng, chunk_ff, chunk_out, final_len, final_off, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_henc_expand(dimg2, dchunks, (int)nchunks, chunk_out, final_len, final_off, arena, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;

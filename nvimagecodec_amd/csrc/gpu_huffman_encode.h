@@ -7,8 +7,9 @@
 //   length   one lane per block (scan order): code length of the block (DC difference + run/size symbols + value bits)
 //   scan     per image: exclusive prefix sum of the lengths -> bit offset of every block, total bits
 //   -- the host reads the totals, lays out one zeroed bit buffer per image --
-//   write    one lane per block: emit the bits at the block's offset (whole 32-bit words stored, the two ragged ends OR-ed
-//            in atomically); the lane of an image's last block pads the final byte with ones (jchuff.c flush_bits)
+//   write    one lane per block: emit the bits at the block's offset -- assembled per workgroup in an LDS window with LDS
+//            atomics, copied out as whole words, only the window's two end words OR-ed into memory atomically; the lane
+//            of an image's last block pads the final byte with ones (jchuff.c flush_bits)
 //   count    per 4 KB chunk of the bit buffer: number of 0xFF bytes (each needs a stuffed 0x00 behind it)
 //   layout   per image: prefix sum of those counts -> where each chunk lands; file length; files packed back to back
 //   expand   per chunk: stuffed bytes to their final place; the first chunk also lays down SOI..SOS, the last one EOI
@@ -45,7 +46,8 @@ struct HencUnit {
 int launch_henc_length(const HencImage* images, const HencUnit* units, int nunits, const StandardCodeTables* tables, uint16_t* block_bits, void* stream);
 int launch_henc_scan(const HencImage* images, int nimages, const uint16_t* block_bits, uint32_t* block_off, uint32_t* total_bits, void* stream);
 int launch_henc_write(const HencImage* images, const HencUnit* units, int nunits, const StandardCodeTables* tables, const uint32_t* block_off,
-                      void* stream);
+                      const uint16_t* block_bits, void* stream);
+int launch_henc_zero(void* p, size_t bytes, void* stream);  // bytes rounded up to 16; p 16-byte aligned
 int launch_henc_count(const HencImage* images, const HencUnit* chunk_units, int nchunks, uint32_t* chunk_ff, void* stream);
 int launch_henc_layout(const HencImage* images, int nimages, const uint32_t* chunk_ff, uint32_t* chunk_out, uint32_t* final_len,
                        unsigned long long* final_off, void* stream);

@@ -88,24 +88,40 @@ __device__ __forceinline__ int dc_value(const HencImage& im, int c, uint32_t bx,
 
 __device__ __forceinline__ int bit_length(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
 
-// Bit sink of the write kernel: bits go to 32-bit words of the image's bit buffer starting at bit `off`.  Words this block
-// fills completely are stored; the word it shares with its predecessor (if it starts inside one) and the word it leaves
-// unfinished are OR-ed in atomically -- the buffer starts out zeroed, so the order of the two writers does not matter.
+// Bit sink of the write kernel.  The workgroup's 256 blocks cover one contiguous bit range of the image's bit buffer; that
+// range is assembled in LDS (zeroed, bits OR-ed in with ds_or -- LDS atomics are cheap) and then copied out as whole words,
+// coalesced.  Only the first and the last word of the range can be shared with a neighbouring workgroup: those two go out
+// with a global atomic OR (the bit buffer starts out zeroed).  A range that does not fit the window (very high bit rates)
+// falls back to OR-ing every word into the global buffer directly.
+constexpr int kWindowWords = 4096;  // 16 KB: 256 blocks x 64 bytes on average
+
 struct Emitter {
-    uint32_t* words;
+    uint32_t* gwords;             // the image's bit buffer
+    HJ_LDS uint32_t* window;      // LDS window (LDS address 0 is a valid place for it: never test this pointer)
+    bool use_window;              // false: write through to gwords
+    uint32_t window_word0;        // index (in gwords) of window[0]
     unsigned long long acc;
-    uint32_t n;       // valid bits at the low end of acc
-    uint32_t widx;    // next word
-    bool shared;      // the next word to go out starts with another block's bits
-    uint32_t emitted; // bits of this block so far
-    __device__ __forceinline__ void start(uint8_t* raw, uint32_t off)
+    uint32_t n;        // valid bits at the low end of acc
+    uint32_t widx;     // next word (index into gwords)
+    uint32_t emitted;  // bits of this block so far
+    __device__ __forceinline__ void start(uint8_t* raw, uint32_t off, HJ_LDS uint32_t* win, bool use_win, uint32_t win_word0)
     {
-        words = reinterpret_cast<uint32_t*>(raw);
+        gwords = reinterpret_cast<uint32_t*>(raw);
+        window = win;
+        use_window = use_win;
+        window_word0 = win_word0;
         acc = 0;
         n = off & 31;
         widx = off >> 5;
-        shared = n != 0;
         emitted = 0;
+    }
+    __device__ __forceinline__ void out(uint32_t w)  // w: bits in stream order, most significant first
+    {
+        if (use_window)
+            __hip_atomic_fetch_or(&window[widx - window_word0], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+            atomicOr(&gwords[widx], __builtin_bswap32(w));
+        widx++;
     }
     __device__ __forceinline__ void put(uint32_t bits, uint32_t size)  // size <= 16, bits already masked
     {
@@ -113,19 +129,13 @@ struct Emitter {
         n += size;
         emitted += size;
         if (n >= 32) {
-            const uint32_t w = __builtin_bswap32((uint32_t)(acc >> (n - 32)));
-            if (shared)
-                atomicOr(&words[widx], w);
-            else
-                words[widx] = w;
-            shared = false;
-            widx++;
+            out((uint32_t)(acc >> (n - 32)));
             n -= 32;
         }
     }
     __device__ __forceinline__ void finish()
     {
-        if (n > 0) atomicOr(&words[widx], __builtin_bswap32((uint32_t)(acc << (32 - n))));
+        if (n > 0) out((uint32_t)(acc << (32 - n)));
     }
 };
 
@@ -250,30 +260,68 @@ __global__ __launch_bounds__(kThreads) void henc_scan_kernel(const HencImage* __
     if (threadIdx.x == kThreads - 1) total_bits[blockIdx.x] = s_sum[kThreads - 1];
 }
 
+// Zeroes the bit buffers (16 bytes per lane).
+__global__ __launch_bounds__(kThreads) void henc_zero_kernel(uint4* __restrict__ p, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 __global__ __launch_bounds__(kThreads) void henc_write_kernel(const HencImage* __restrict__ images, const HencUnit* __restrict__ units,
-                                                              const StandardCodeTables* __restrict__ tables, const uint32_t* __restrict__ block_off)
+                                                              const StandardCodeTables* __restrict__ tables, const uint32_t* __restrict__ block_off,
+                                                              const uint16_t* __restrict__ block_bits)
 {
     __shared__ LdsTables T;
+    __shared__ uint32_t window[kWindowWords];
+    __shared__ uint32_t span[2];  // first word of the workgroup's range, number of words (0: does not fit the window)
     load_tables(&T, tables);
-    __syncthreads();
     const HencUnit u = units[blockIdx.x];
     const HencImage& im = images[u.image];
-    const uint32_t s = u.first + threadIdx.x;
-    if (s >= im.total_blocks) return;
-    uint4 q[8];
-    bool real;
-    int diff, ti;
-    fetch_block(im, s, q, &real, &diff, &ti);
-    const uint32_t off = block_off[im.first_block + s];
-    Emitter em;
-    em.start(im.raw, off);
-    code_block<true>(q, real, diff, (const HJ_LDS LdsTables*)&T, ti, &em);
-    if (s == im.total_blocks - 1) {
-        // jchuff.c flush_bits: the last byte of the scan is filled up with one-bits
-        const uint32_t padn = (8 - ((off + em.emitted) & 7)) & 7;
-        if (padn) em.put((1u << padn) - 1, padn);
+    const int t = threadIdx.x;
+    const uint32_t s = u.first + t;
+    const bool live = s < im.total_blocks;
+    if (t == 0) {
+        const uint32_t last = min(u.first + kThreads, im.total_blocks) - 1;
+        const uint32_t first_bit = block_off[im.first_block + u.first];
+        // one past the range's last bit; the image's last block is followed by up to 7 padding bits.  The range must not be
+        // overestimated: its last word is the one that may be shared with the next workgroup.
+        const uint32_t end_bit = block_off[im.first_block + last] + block_bits[im.first_block + last] + (last == im.total_blocks - 1 ? 7u : 0u);
+        const uint32_t w0 = first_bit >> 5, w1 = (end_bit - 1) >> 5;
+        span[0] = w0;
+        span[1] = (w1 - w0 + 1 <= (uint32_t)kWindowWords) ? w1 - w0 + 1 : 0u;
     }
-    em.finish();
+    __syncthreads();
+    const uint32_t w0 = span[0], nwin = span[1];
+    for (uint32_t i = t; i < nwin; i += kThreads) window[i] = 0;
+    __syncthreads();
+    if (live) {
+        uint4 q[8];
+        bool real;
+        int diff, ti;
+        fetch_block(im, s, q, &real, &diff, &ti);
+        const uint32_t off = block_off[im.first_block + s];
+        Emitter em;
+        em.start(im.raw, off, (HJ_LDS uint32_t*)window, nwin != 0, w0);
+        code_block<true>(q, real, diff, (const HJ_LDS LdsTables*)&T, ti, &em);
+        if (s == im.total_blocks - 1) {
+            // jchuff.c flush_bits: the last byte of the scan is filled up with one-bits
+            const uint32_t padn = (8 - ((off + em.emitted) & 7)) & 7;
+            if (padn) em.put((1u << padn) - 1, padn);
+        }
+        em.finish();
+    }
+    __syncthreads();
+    if (nwin) {
+        uint32_t* g = reinterpret_cast<uint32_t*>(im.raw);
+        for (uint32_t i = t; i < nwin; i += kThreads) {
+            const uint32_t w = __builtin_bswap32(window[i]);
+            if (i == 0 || i == nwin - 1) {
+                if (w) atomicOr(&g[w0 + i], w);  // may be shared with the neighbouring workgroup
+            } else {
+                g[w0 + i] = w;
+            }
+        }
+    }
 }
 
 // 0x80 in every byte of x that is 0xFF
@@ -443,10 +491,18 @@ int launch_henc_scan(const HencImage* images, int nimages, const uint16_t* block
 }
 
 int launch_henc_write(const HencImage* images, const HencUnit* units, int nunits, const StandardCodeTables* tables, const uint32_t* block_off,
-                      void* stream)
+                      const uint16_t* block_bits, void* stream)
 {
     if (nunits <= 0) return 0;
-    hipLaunchKernelGGL(henc_write_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units, tables, block_off);
+    hipLaunchKernelGGL(henc_write_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units, tables, block_off, block_bits);
+    return (int)hipGetLastError();
+}
+
+int launch_henc_zero(void* p, size_t bytes, void* stream)
+{
+    const size_t n16 = (bytes + 15) / 16;
+    if (n16 == 0) return 0;
+    hipLaunchKernelGGL(henc_zero_kernel, dim3((unsigned)((n16 + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream, static_cast<uint4*>(p), n16);
     return (int)hipGetLastError();
 }
 
