@@ -566,8 +566,15 @@ __global__ __launch_bounds__(kThreads) void huff_scan_kernel(HuffImage* __restri
     const uint32_t n = (im.total_bits + kSubseqBits - 1) / kSubseqBits;
     const uint32_t per = (n + kThreads - 1) / kThreads;
     const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    constexpr int kBatch = 8;  // independent loads in flight per lane
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += (uint32_t)(st[i] >> 48);
+    for (uint32_t i = lo; i < hi; i += kBatch) {
+        uint32_t d[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) d[k] = i + k < hi ? (uint32_t)(st[i + k] >> 48) : 0u;
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) sum += d[k];
+    }
     s_sum[threadIdx.x] = sum;
     __syncthreads();
     // Hillis-Steele inclusive scan over 256 partial sums

@@ -242,8 +242,15 @@ __global__ __launch_bounds__(kThreads) void henc_scan_kernel(const HencImage* __
     const uint32_t n = im.total_blocks;
     const uint32_t per = (n + kThreads - 1) / kThreads;
     const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    constexpr int kBatch = 8;  // independent loads in flight per lane
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += bits[i];
+    for (uint32_t i = lo; i < hi; i += kBatch) {
+        uint32_t d[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) d[k] = i + k < hi ? bits[i + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) sum += d[k];
+    }
     s_sum[threadIdx.x] = sum;
     __syncthreads();
     for (int d = 1; d < kThreads; d <<= 1) {
@@ -253,9 +260,15 @@ __global__ __launch_bounds__(kThreads) void henc_scan_kernel(const HencImage* __
         __syncthreads();
     }
     uint32_t run = threadIdx.x ? s_sum[threadIdx.x - 1] : 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        off[i] = run;
-        run += bits[i];
+    for (uint32_t i = lo; i < hi; i += kBatch) {
+        uint32_t d[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) d[k] = i + k < hi ? bits[i + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            if (i + k < hi) off[i + k] = run;
+            run += d[k];
+        }
     }
     if (threadIdx.x == kThreads - 1) total_bits[blockIdx.x] = s_sum[kThreads - 1];
 }
