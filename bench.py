@@ -233,11 +233,18 @@ def main():
         t0 = time.perf_counter()
         enc.host_stage(gpu_huffman=True)
         t_encg = time.perf_counter() - t0
+        enc.submit(outs, "420", 90, "rgb", gpu_huffman=True)   # warm: allocates the two pipeline pages
+        enc.submit(outs, "420", 90, "rgb", gpu_huffman=True)
+        enc.wait(fetch=False)
+        enc.wait(fetch=False)
+        enc_batches = 12
         t0 = time.perf_counter()
-        for _ in range(3):
-            enc.device_stage(outs, "420", 90, "rgb")
-            enc.host_stage(gpu_huffman=True)
-        t_enc_e2e = (time.perf_counter() - t0) / 3
+        for i in range(enc_batches):
+            enc.submit(outs, "420", 90, "rgb", gpu_huffman=True)
+            if i > 0:
+                enc.wait(fetch=False)
+        enc.wait(fetch=False)
+        t_enc_e2e = (time.perf_counter() - t0) / enc_batches
         est = enc.stats()
         encode_info = {"workload": "configs[2]: batch=256 1920x1080 RGB -> JPEG q90 4:2:0", "device_stage_ms": round(enc_ms, 4),
                        "device_stage_images_per_s": round(BATCH / enc_ms * 1e3, 1),
@@ -245,7 +252,8 @@ def main():
                        "host_huffman_images_per_s": round(BATCH / t_ench, 1), "host_threads": host_threads,
                        "gpu_huffman_stage_ms": round(t_encg * 1e3, 3), "gpu_huffman_images_per_s": round(BATCH / t_encg, 1),
                        "end_to_end_images_per_s": round(BATCH / t_enc_e2e, 1),
-                       "end_to_end_includes": "RGB in HBM -> JPEG files in host memory: forward kernel + GPU entropy coder + D2H of the files"}
+                       "end_to_end_includes": "RGB in HBM -> JPEG files in host memory: forward kernel + GPU entropy coder + D2H of the files, "
+                                              "two batches in flight (hipjpegEncodeBatchSubmit/Wait)"}
         enc.close()
     except Exception as e:  # the decode line must not be lost because the encode extra failed
         encode_info = {"error": repr(e)}

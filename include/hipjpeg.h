@@ -194,7 +194,16 @@ HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchEntropy(hipjpegHandle_t handle, un
 /* Both of the above. */
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatch(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
                                                int batch_size, hipjpegStatus_t* statuses, void* stream);
-/* Bitstream of image i of the last encoded batch; valid until the next encode call on this handle. */
+/* Pipelined encoding: Submit queues a whole batch (forward kernel + entropy stage per `flags` as in
+ * hipjpegEncodeBatchEntropy + copy of the files to host memory) and returns at once; it runs on an internal stream, ordered
+ * behind the work already queued on `stream` (the producer of the pixels).  Wait blocks until the OLDEST submitted batch is
+ * complete, returns its statuses and makes it the batch hipjpegEncodeGetBitstream talks about.  At most two batches in
+ * flight; the bitstreams of a waited batch stay valid until the second Submit after it.  The copy of one batch's files
+ * overlaps the kernels of the next. */
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchSubmit(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
+                                                     int batch_size, unsigned flags, void* stream);
+HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size);
+/* Bitstream of image i of the last encoded (or waited-for) batch; valid until the next encode call on this handle. */
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeGetBitstream(hipjpegHandle_t handle, int index, const uint8_t** data, size_t* length);
 /* Quantized coefficients of (image, component) after hipjpegEncodeBatchHost: zigzag-ordered int16[64] blocks over the
  * MCU-padded grid (only the real_w x real_h area is defined).  For tests and for callers with their own entropy coder. */

@@ -82,6 +82,8 @@ def load():
     L.hipjpegEncodeBatchRelaunch.argtypes = [vp, vp]
     L.hipjpegEncodeBatchHost.argtypes = [vp, vp]
     L.hipjpegEncodeBatchEntropy.argtypes = [vp, ctypes.c_uint, vp]
+    L.hipjpegEncodeBatchSubmit.argtypes = [vp, vp, vp, i32, ctypes.c_uint, vp]
+    L.hipjpegEncodeBatchWait.argtypes = [vp, vp, i32]
     L.hipjpegEncodeBatch.argtypes = [vp, vp, vp, i32, vp, vp]
     L.hipjpegEncodeGetBitstream.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.hipjpegEncodeGetCoefficients.argtypes = [vp, i32, i32, ctypes.POINTER(vp), vp]

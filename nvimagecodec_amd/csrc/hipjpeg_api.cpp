@@ -14,6 +14,7 @@
 #include "thread_pool.h"
 
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 
@@ -37,6 +38,19 @@ struct hipjpegHandle {
     int num_submitted = 0;
     hipStream_t copy_stream = nullptr;  // H2D copies of submitted batches: they overlap the kernels of the batch before
     std::unique_ptr<EncodeBatch> encode;
+    EncodeBatch* encode_view = nullptr;  // the batch hipjpegEncodeGetBitstream / GetCoefficients / Stats talk about
+    // pipelined encoding (hipjpegEncodeBatchSubmit / Wait): two pages, each driven by its own host thread on its own
+    // stream, so that the D2H copy and the two short host round trips of one batch overlap the kernels of the other
+    struct EncodePage {
+        std::unique_ptr<EncodeBatch> batch;
+        hipStream_t stream = nullptr;
+        hipEvent_t ready = nullptr;
+        std::future<hipjpegStatus_t> result;
+        std::vector<hipjpegEncodeInput_t> inputs;
+        std::vector<hipjpegEncodeParams_t> params;
+    };
+    EncodePage encode_pages[2];
+    int encode_next = 0, encode_oldest = 0, encode_in_flight = 0;
 };
 
 extern "C" {
@@ -147,6 +161,7 @@ hipjpegStatus_t hipjpegCreate(hipjpegHandle_t* handle, int device_id, int num_ho
     h->pool.reset(new ForkJoinPool(num_host_threads));
     for (auto& b : h->batches) b.reset(new DecodeBatch(device_id, &h->hooks));
     h->encode.reset(new EncodeBatch(device_id, &h->hooks));
+    h->encode_view = h->encode.get();
     *handle = h;
     return HIPJPEG_STATUS_SUCCESS;
 }
@@ -156,6 +171,12 @@ hipjpegStatus_t hipjpegDestroy(hipjpegHandle_t handle)
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     (void)hipSetDevice(handle->device_id);
     if (handle->copy_stream) (void)hipStreamDestroy(handle->copy_stream);
+    for (auto& pg : handle->encode_pages) {
+        if (pg.result.valid()) (void)pg.result.get();
+        pg.batch.reset();
+        if (pg.ready) (void)hipEventDestroy(pg.ready);
+        if (pg.stream) (void)hipStreamDestroy(pg.stream);
+    }
     delete handle;
     return HIPJPEG_STATUS_SUCCESS;
 }
@@ -302,6 +323,7 @@ hipjpegStatus_t hipjpegEncodeBatchDevice(hipjpegHandle_t handle, const hipjpegEn
                                          int batch_size, hipjpegStatus_t* statuses, void* stream)
 {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    handle->encode_view = handle->encode.get();
     return handle->encode->device_stage(inputs, params, batch_size, statuses, stream);
 }
 
@@ -344,10 +366,66 @@ hipjpegStatus_t hipjpegEncodeBatch(hipjpegHandle_t handle, const hipjpegEncodeIn
     return hipjpegEncodeBatchHost(handle, statuses);
 }
 
+hipjpegStatus_t hipjpegEncodeBatchSubmit(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params, int batch_size,
+                                         unsigned flags, void* stream)
+{
+    if (!handle || batch_size < 0 || (batch_size > 0 && (!inputs || !params))) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if (handle->encode_in_flight >= 2) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // both pages busy: Wait first
+    if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
+    hipjpegHandle::EncodePage& pg = handle->encode_pages[handle->encode_next];
+    if (!pg.batch) {
+        pg.batch.reset(new EncodeBatch(handle->device_id, &handle->hooks));
+        if (hipStreamCreateWithFlags(&pg.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&pg.ready, hipEventDisableTiming) != hipSuccess)
+            return HIPJPEG_STATUS_HIP_ERROR;
+    }
+    pg.inputs.assign(inputs, inputs + batch_size);
+    pg.params.assign(params, params + batch_size);
+    // the page's stream must see the producer's pixels
+    if (hipEventRecord(pg.ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(pg.stream, pg.ready, 0) != hipSuccess)
+        return HIPJPEG_STATUS_HIP_ERROR;
+    const int device = handle->device_id;
+    hipjpegHandle::EncodePage* page = &pg;
+    pg.result = std::async(std::launch::async, [page, device, flags]() -> hipjpegStatus_t {
+        if (hipSetDevice(device) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
+        EncodeBatch& b = *page->batch;
+        hipjpegStatus_t st = b.device_stage(page->inputs.data(), page->params.data(), (int)page->inputs.size(), nullptr, page->stream);
+        if (st != HIPJPEG_STATUS_SUCCESS) return st;
+        std::vector<char> todo(b.size(), 1);
+        if ((flags & HIPJPEG_FLAG_GPU_HUFFMAN) && (st = b.gpu_entropy_stage(&todo)) != HIPJPEG_STATUS_SUCCESS) return st;
+        bool any = false;
+        for (int i = 0; i < b.size(); i++) any = any || (todo[i] && b.image(i).status == HIPJPEG_STATUS_SUCCESS);
+        if (any) {
+            if ((st = b.fetch_coefficients()) != HIPJPEG_STATUS_SUCCESS) return st;
+            for (int i = 0; i < b.size(); i++)
+                if (todo[i]) b.entropy_stage(i);
+        }
+        return HIPJPEG_STATUS_SUCCESS;
+    });
+    handle->encode_next ^= 1;
+    handle->encode_in_flight++;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+hipjpegStatus_t hipjpegEncodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size)
+{
+    if (!handle || handle->encode_in_flight == 0) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    hipjpegHandle::EncodePage& pg = handle->encode_pages[handle->encode_oldest];
+    handle->encode_oldest ^= 1;
+    handle->encode_in_flight--;
+    const hipjpegStatus_t st = pg.result.get();
+    handle->encode_view = pg.batch.get();
+    if (statuses) {
+        if (batch_size != pg.batch->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+        for (int i = 0; i < batch_size; i++) statuses[i] = pg.batch->image(i).status;
+    }
+    return st;
+}
+
 hipjpegStatus_t hipjpegEncodeGetBitstream(hipjpegHandle_t handle, int index, const uint8_t** data, size_t* length)
 {
-    if (!handle || !data || !length || index < 0 || index >= handle->encode->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    PlannedEncode& im = handle->encode->image(index);
+    if (!handle || !data || !length || index < 0 || index >= handle->encode_view->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    PlannedEncode& im = handle->encode_view->image(index);
     if (im.status != HIPJPEG_STATUS_SUCCESS) return im.status;
     *data = im.file();
     *length = im.file_size();
@@ -356,13 +434,13 @@ hipjpegStatus_t hipjpegEncodeGetBitstream(hipjpegHandle_t handle, int index, con
 
 hipjpegStatus_t hipjpegEncodeGetCoefficients(hipjpegHandle_t handle, int index, int component, const int16_t** coef, int32_t grid[4])
 {
-    if (!handle || !coef || !grid || index < 0 || index >= handle->encode->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    PlannedEncode& im = handle->encode->image(index);
+    if (!handle || !coef || !grid || index < 0 || index >= handle->encode_view->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    PlannedEncode& im = handle->encode_view->image(index);
     if (im.status != HIPJPEG_STATUS_SUCCESS) return im.status;
     if (component < 0 || component >= im.geom.ncomp) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    hipjpegStatus_t st = handle->encode->fetch_coefficients();
+    hipjpegStatus_t st = handle->encode_view->fetch_coefficients();
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
-    *coef = handle->encode->host_coef(index, component);
+    *coef = handle->encode_view->host_coef(index, component);
     grid[0] = im.geom.blocks_w[component];
     grid[1] = im.geom.blocks_h[component];
     grid[2] = im.geom.real_w[component];
@@ -373,9 +451,9 @@ hipjpegStatus_t hipjpegEncodeGetCoefficients(hipjpegHandle_t handle, int index, 
 hipjpegStatus_t hipjpegEncodeBatchStats(hipjpegHandle_t handle, int32_t* num_units, uint64_t* pixel_bytes, uint64_t* coef_bytes)
 {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    if (num_units) *num_units = handle->encode->num_units();
-    if (pixel_bytes) *pixel_bytes = handle->encode->pixel_bytes();
-    if (coef_bytes) *coef_bytes = handle->encode->coef_bytes();
+    if (num_units) *num_units = handle->encode_view->num_units();
+    if (pixel_bytes) *pixel_bytes = handle->encode_view->pixel_bytes();
+    if (coef_bytes) *coef_bytes = handle->encode_view->coef_bytes();
     return HIPJPEG_STATUS_SUCCESS;
 }
 

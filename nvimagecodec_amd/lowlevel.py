@@ -287,6 +287,7 @@ class BatchEncoder:
         self._torch = torch
         self.device = int(device)
         self.gpu_huffman = bool(gpu_huffman)
+        self._inflight = []
         self._h = ctypes.c_void_p()
         st = N.load().hipjpegCreate(ctypes.byref(self._h), self.device, int(num_threads))
         if st:
@@ -343,6 +344,27 @@ class BatchEncoder:
         if st:
             raise N.HipJpegError(st, "hipjpegEncodeBatchDevice")
         return list(st_arr)
+
+    # -- pipelined: submit() queues forward kernel + entropy stage + copy of the files and returns; wait() completes the
+    #    oldest submitted batch and returns (statuses, bitstreams).  At most two batches in flight.
+    def submit(self, images, subsampling="420", quality=90, input_format="rgb", restart_interval=0, optimized_huffman=False, stream=None,
+               gpu_huffman=None):
+        if gpu_huffman is None:
+            gpu_huffman = self.gpu_huffman
+        I, P = self._marshal(images, subsampling, quality, input_format, restart_interval, optimized_huffman)
+        st = N.load().hipjpegEncodeBatchSubmit(self._h, I, P, self._n, N.FLAG_GPU_HUFFMAN if gpu_huffman else 0, self._stream_ptr(stream))
+        if st:
+            raise N.HipJpegError(st, "hipjpegEncodeBatchSubmit")
+        self._inflight.append((self._n, self._keep))
+
+    def wait(self, fetch=True):
+        n, _keep = self._inflight.pop(0)
+        st_arr = (ctypes.c_int * n)()
+        st = N.load().hipjpegEncodeBatchWait(self._h, st_arr, n)
+        if st:
+            raise N.HipJpegError(st, "hipjpegEncodeBatchWait")
+        self._n = n
+        return list(st_arr), (self.bitstreams() if fetch else None)
 
     def relaunch(self, stream=None):
         st = N.load().hipjpegEncodeBatchRelaunch(self._h, self._stream_ptr(stream))

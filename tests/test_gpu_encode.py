@@ -140,3 +140,21 @@ def test_optimized_huffman_and_bad_params(enc, torch_mod):
     g = torch.from_numpy(np.ascontiguousarray(im[:, :, 0])).cuda()
     st = enc.device_stage([g], "420", 90, input_format="gray")
     assert st == [3]  # UNSUPPORTED
+
+
+def test_pipelined_submit_wait(enc, torch_mod):
+    """hipjpegEncodeBatchSubmit / Wait: two batches in flight, results identical to the one-shot call, in submission order."""
+    torch = torch_mod
+    batches = [[synth_image(97 + 16 * k, 61 + 8 * k, seed=10 * k + j) for j in range(5)] for k in range(5)]
+    dev = [[torch.from_numpy(im).cuda() for im in b] for b in batches]
+    subs = ["420", "444", "422", "420", "440"]
+    results = []
+    for k, d in enumerate(dev):
+        enc.submit(d, subs[k], 80 + k)
+        if k > 0:
+            results.append(enc.wait())
+    results.append(enc.wait())
+    for k, (statuses, streams) in enumerate(results):
+        assert statuses == [0] * 5
+        for im, s in zip(batches[k], streams):
+            assert s == oracle.encode(im, subs[k], 80 + k), k
