@@ -4,6 +4,8 @@ libhipjpeg_ext.so exports.  Device memory and streams are torch-ROCm objects; ev
    Python -> nvimgcodecDecoderDecode -> priority chain -> hipjpeg_decoder plugin -> HIP kernels.
 """
 import ctypes as C
+import os
+import sys
 import enum
 
 import numpy as np
@@ -278,6 +280,9 @@ class Decoder(_ExecMixin):
         return res[0] if single else res
 
     def _decode_sources(self, sources, params, cuda_stream):
+        import time as _t
+        _dbg = os.environ.get("HIPJPEG_DEBUG_TIMING")
+        _t0 = _t.perf_counter()
         torch = self._torch
         lib, inst = _api()
         params = params or DecodeParams()
@@ -318,6 +323,7 @@ class Decoder(_ExecMixin):
             images.append(im)
             outs.append(t)
         valid = [i for i in range(n) if streams[i] is not None]
+        _t1 = _t.perf_counter()
         results = [None] * n
         if valid:
             cs_arr = (C.c_void_p * len(valid))(*[streams[i] for i in valid])
@@ -325,7 +331,9 @@ class Decoder(_ExecMixin):
             dp = A.init(A.DecodeParams, A.ST_DECODE_PARAMS, apply_exif_orientation=int(params.apply_exif_orientation), enable_roi=0)
             fut = C.c_void_p()
             _check(lib.nvimgcodecDecoderDecode(self._h, cs_arr, im_arr, len(valid), C.byref(dp), C.byref(fut)), "nvimgcodecDecoderDecode")
+            _t2 = _t.perf_counter()
             _check(lib.nvimgcodecFutureWaitForAll(fut), "nvimgcodecFutureWaitForAll")
+            _t3 = _t.perf_counter()
             st = (C.c_uint32 * len(valid))()
             size = C.c_size_t()
             lib.nvimgcodecFutureGetProcessingStatus(fut, st, C.byref(size))
@@ -337,6 +345,9 @@ class Decoder(_ExecMixin):
         for i in valid:
             lib.nvimgcodecImageDestroy(images[i])
             lib.nvimgcodecCodeStreamDestroy(streams[i])
+        if _dbg and valid:
+            _t4 = _t.perf_counter()
+            print("[api] setup %.2f ms, DecoderDecode %.2f ms, wait %.2f ms, teardown %.2f ms" % ((_t1 - _t0) * 1e3, (_t2 - _t1) * 1e3, (_t3 - _t2) * 1e3, (_t4 - _t3) * 1e3), file=sys.stderr)
         return results
 
 

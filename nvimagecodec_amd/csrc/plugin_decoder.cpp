@@ -17,11 +17,13 @@
 #include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
 #include "decoder_core.h"
 #include "plugin_common.h"
+#include "thread_pool.h"
 #include "plugin_objects.h"
 
 namespace hipjpeg_ext {
@@ -113,6 +115,9 @@ private:
     hipStream_t stream_ = nullptr;
     std::unique_ptr<Job> jobs_[2];
     int next_job_ = 0;
+    // Header parsing of a batch (a marker walk through every file) runs on these threads inside decode(): the framework's
+    // executor only takes per-sample tasks that report through imageReady, and the batch layout needs every header first.
+    std::unique_ptr<hipjpeg::ForkJoinPool> parse_pool_;
     std::mutex decode_mutex_;  // decode() may be entered from the framework's worker thread and from a fallback re-dispatch
 };
 
@@ -124,6 +129,11 @@ HipJpegDecoder::HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgc
         if (key == "fancy_upsampling") v >> fancy_;
         if (key == "gpu_huffman") v >> gpu_huffman_;
     });
+    {
+        int threads = 0;
+        if (ep->executor && ep->executor->getNumThreads) threads = ep->executor->getNumThreads(ep->executor->instance);
+        parse_pool_.reset(new hipjpeg::ForkJoinPool(threads > 0 ? threads : 0));
+    }
     if (ep->device_allocator && ep->device_allocator->device_malloc && ep->device_allocator->device_free) {
         hooks_.device_malloc = reinterpret_cast<int (*)(void*, void**, size_t, void*)>(ep->device_allocator->device_malloc);
         hooks_.device_free = reinterpret_cast<int (*)(void*, void*, size_t, void*)>(ep->device_allocator->device_free);
@@ -364,6 +374,8 @@ nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_stre
 {
     if (!code_streams || !images || !params) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
     if (batch_size < 1) return NVIMGCODEC_STATUS_INVALID_PARAMETER;
+    static const bool timing = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;  // debug aid: phase times of decode() on stderr
+    const auto t_enter = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> serial(decode_mutex_);
     Job* job = jobs_[next_job_].get();
     next_job_ ^= 1;
@@ -454,10 +466,11 @@ nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_stre
         sizes[i] = size;
     }
 
+    const auto t_marshal = std::chrono::steady_clock::now();
     bool planned = hipSetDevice(device_) == hipSuccess &&
                    job->batch.plan(data.data(), sizes.data(), n, outs.data(), HIPJPEG_OUTPUT_RGBI,
                                    (fancy_ ? HIPJPEG_FLAG_FANCY_UPSAMPLING : 0u) | (gpu_huffman_ ? HIPJPEG_FLAG_GPU_HUFFMAN : 0u),
-                                   job->statuses.data(), formats.data(), nullptr, any_geometry ? geometry.data() : nullptr) == HIPJPEG_STATUS_SUCCESS;
+                                   job->statuses.data(), formats.data(), parse_pool_.get(), any_geometry ? geometry.data() : nullptr) == HIPJPEG_STATUS_SUCCESS;
     if (!planned) {
         // batch-level failure: every sample is reported failed and an error code is returned (cuda_decoder.cpp:602-608)
         release_inputs(job);
@@ -471,6 +484,7 @@ nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_stre
         return NVIMGCODEC_STATUS_EXTENSION_EXECUTION_FAILED;
     }
 
+    const auto t_plan = std::chrono::steady_clock::now();
     job->remaining.store(n);
     nvimgcodecExecutorDesc_t* ex = ep_->executor;
     if (n == 1 || !ex) {
@@ -479,6 +493,12 @@ nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_stre
         for (int i = 0; i < n; i++) {
             if (ex->launch(ex->instance, device_, i, job, &HipJpegDecoder::host_task) != NVIMGCODEC_STATUS_SUCCESS) host_task(0, i, job);
         }
+    }
+    if (timing) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hipjpeg] plugin decode(%d): wait for a job page + marshal %.2f ms, plan %.2f ms, hand to executor %.2f ms\n", n,
+                ms(t_enter, t_marshal), ms(t_marshal, t_plan), ms(t_plan, t_end));
     }
     return NVIMGCODEC_STATUS_SUCCESS;
 }
