@@ -44,14 +44,81 @@ def make_inputs():
         return [encode_jpeg_host_reference(im, "420", 90) for im in imgs], "synthetic (product encoder)"
     except Exception:
         pass
+    try:
+        return [_pil_encode(im, 90, "420") for im in imgs], "synthetic (seeded images, libjpeg-turbo/Pillow-encoded q90 4:2:0)"
+    except ImportError:
+        return _product_encode(imgs, "420", 90), "synthetic (seeded images, encoded by this package's GPU encoder q90 4:2:0)"
+
+
+def _pil_encode(im, quality, sub, progressive=False):
     import io
     from PIL import Image
-    out = []
-    for im in imgs:
-        b = io.BytesIO()
-        Image.fromarray(im).save(b, "JPEG", quality=90, subsampling=2)
-        out.append(b.getvalue())
-    return out, "synthetic (seeded images, libjpeg-turbo/Pillow-encoded q90 4:2:0)"
+    b = io.BytesIO()
+    Image.fromarray(im).save(b, "JPEG", quality=quality, subsampling={"444": 0, "422": 1, "420": 2}[sub], progressive=progressive)
+    return b.getvalue()
+
+
+def _product_encode(imgs, sub, quality):
+    import torch
+    from nvimagecodec_amd.lowlevel import BatchEncoder
+    enc = BatchEncoder(device=torch.cuda.current_device(), num_threads=2, gpu_huffman=True)
+    out = enc.encode([torch.from_numpy(im).cuda() for im in imgs], sub, quality, "rgb")
+    enc.close()
+    return out
+
+
+def other_configs(dec, host_threads):
+    """BASELINE.json configs[3] and configs[4] for the record (never part of `value`): end-to-end images/s from host JPEG bytes
+    to pixels in HBM on this GPU's share of the work."""
+    import torch
+    from nvimagecodec_amd.synth import synth_image
+    res = {}
+    # configs[3]: mixed shapes 480p..4K, 50/50 4:2:0 / 4:2:2, this GPU's 256 of the 2048 images; pipelined GPU-entropy path
+    shapes = [(640, 480), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160)]
+    srcs = []
+    for k in range(10):
+        w, h = shapes[k % 5]
+        im = synth_image(w, h, seed=500 + k)
+        try:
+            srcs.append(_pil_encode(im, 90, "420" if k < 5 else "422"))
+        except ImportError:
+            srcs.append(_product_encode([im], "420" if k < 5 else "422", 90)[0])
+    order = [(7 * i + 3) % 10 for i in range(BATCH)]  # fixed pseudo-random draw
+    mixed = [srcs[k] for k in order]
+    ring = [dec.allocate_outputs(mixed, "rgb") for _ in range(3)]
+    dec.submit(mixed, ring[0])
+    dec.wait()
+    torch.cuda.synchronize()
+    nb = 6
+    t0 = time.perf_counter()
+    for i in range(nb):
+        dec.submit(mixed, ring[i % 3])
+        if i > 1:
+            dec.wait()
+    dec.wait()
+    dec.wait()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / nb
+    mp = sum(shapes[k % 5][0] * shapes[k % 5][1] for k in order) / 1e6
+    res["config3_mixed_shapes"] = {"workload": "configs[3], one GPU's share: batch=256 mixed 480p-4K, 4:2:0/4:2:2 -> I_RGB", "images_per_s": round(BATCH / t, 1),
+                                   "mp_per_s": round(mp / t, 1), "path": "GPU entropy stage, three batches in flight"}
+    del ring
+    # configs[4]: progressive 4:4:4 -> planar RGB; progressive scans take the host entropy stage
+    try:
+        prog = [_pil_encode(synth_image(WIDTH, HEIGHT, seed=900 + k), 90, "444", progressive=True) for k in range(4)]
+        batch = [prog[i % 4] for i in range(128)]
+        outs = dec.allocate_outputs(batch, "rgb_planar")
+        dec.decode(batch, fmt="rgb_planar", outs=outs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec.decode(batch, fmt="rgb_planar", outs=outs)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        res["config4_progressive_444"] = {"workload": "configs[4]: batch=128 1920x1080 progressive 4:4:4 -> P_RGB", "images_per_s": round(128 / t, 1),
+                                          "path": "host entropy stage (%d threads) + multi-scan coefficient accumulate + device stage" % host_threads}
+    except ImportError:
+        res["config4_progressive_444"] = {"skipped": "no progressive encoder available on this box to make inputs"}
+    return res
 
 
 def usable_cpus():
@@ -258,6 +325,12 @@ def main():
     except Exception as e:  # the decode line must not be lost because the encode extra failed
         encode_info = {"error": repr(e)}
 
+    # ---- the other decode configs of BASELINE.json, for the record
+    try:
+        others = other_configs(dec, host_threads) if rank == 0 else None
+    except Exception as e:
+        others = {"error": repr(e)}
+
     # ---- parity spot-check of what the timed kernels wrote (cheap: one image) -- the checker, never the thing measured
     parity = None
     if rank == 0:
@@ -306,6 +379,7 @@ def main():
                             "note": "kernels of the entropy stage on a batch whose bitstreams are resident in HBM (destuff, 2 sync launches, "
                                     "scan, write, DC), host-timed incl. the verdict read-back"},
             "encode": encode_info,
+            "other_configs": others,
             "parity_vs_oracle": parity,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -137,8 +137,9 @@ __device__ __forceinline__ void fetch_half_block(const DecodeComponent& cd, int 
     const u32x4* src = reinterpret_cast<const u32x4*>(comp_coef) + (size_t)wave_first_block * 8;
     const int nchunks = min(kBlocksPerWave, block_limit - wave_first_block) * 8;  // valid 16-byte chunks (may be <= 0)
     const int my_block = wave_first_block + (lane >> 1);
+    const bool dc_apart = cd.dc_stride != 64;  // wave-uniform: host-decoded images carry the DC inside the block already
     unsigned dc = 0;
-    if (my_block < block_limit) dc = (unsigned short)cd.dc[__umul24((unsigned)my_block, cd.dc_stride)];
+    if (dc_apart && my_block < block_limit) dc = (unsigned short)cd.dc[my_block];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int g = k * 64 + lane;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void fetch_half_block(const DecodeComponent& cd, int 
     const char* mine = lds_wave + (lane >> 1) * kLdsBlockStride + (lane & 1) * 64;
 #pragma unroll
     for (int j = 0; j < 4; j++) cols[j] = *reinterpret_cast<const u32x4*>(mine + j * 16);
-    if (!(lane & 1)) cols[0].x = (cols[0].x & 0xFFFF0000u) | dc;
+    if (dc_apart && !(lane & 1)) cols[0].x = (cols[0].x & 0xFFFF0000u) | dc;
 }
 
 // Dequantize + column pass of this lane's four columns, exchange with the partner lane, and assemble the row-pass inputs.

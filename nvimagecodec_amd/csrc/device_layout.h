@@ -39,8 +39,8 @@ struct alignas(16) DecodeComponent {
     uint16_t blocks_w, blocks_h;  // MCU-padded block grid
     uint16_t samp_w, samp_h;      // true component size in samples
     uint16_t h, v;                // sampling factors
-    // Where the DC coefficient of block b is: dc[b * dc_stride].  Host entropy stage: inside the block (dc == coef,
-    // stride 64); GPU entropy stage: a compact plane of DC values (stride 1), position 0 of the blocks holds zero.
+    // Where the DC coefficient of block b is.  Host entropy stage: inside the block (dc_stride == 64, dc unused); GPU entropy
+    // stage: dc[b] in a compact plane of DC values (dc_stride == 1), position 0 of the blocks holds zero.
     const int16_t* dc;
     uint32_t dc_stride, pad0;
     // Quantizers as the kernels consume them: qpair[p][j*8 + r] = q(row r, column 4p+j), with odd rows NEGATED for p == 1
