@@ -100,6 +100,7 @@ DecodeBatch::DecodeBatch(int device_id, const MemoryHooks* hooks)
 DecodeBatch::~DecodeBatch()
 {
     if (copied_event_) (void)hipEventDestroy((hipEvent_t)copied_event_);
+    if (entropy_event_) (void)hipEventDestroy((hipEvent_t)entropy_event_);
     if (done_event_) {
         if (in_flight_) (void)hipEventSynchronize((hipEvent_t)done_event_);
         (void)hipEventDestroy((hipEvent_t)done_event_);
@@ -795,7 +796,7 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
     return rc;
 }
 
-hipjpegStatus_t DecodeBatch::launch(void* stream, int which)
+hipjpegStatus_t DecodeBatch::launch(void* stream, int which, void* entropy_stream)
 {
     if (!finalized_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     const DecodeImage* dimg = reinterpret_cast<const DecodeImage*>(device_.data() + desc_offset_);
@@ -822,15 +823,29 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which)
         check("transfer", 0);
     }
     last_stream_ = stream;
+    // With an entropy stream the (latency-bound) entropy kernels of this batch run beside the (VALU-bound) pixel kernels of
+    // the batch before it; the pixel kernels on `stream` wait for them on the device.
+    void* es_stream = (entropy_stream && which < 0 && !entropy_done_ && !huff_units_.empty()) ? entropy_stream : stream;
     if (copied_event_ && copy_pending_) {
         // the H2D copy went out on another stream: the kernels wait for it on the device, the host does not
-        if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)copied_event_, 0) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipStreamWaitEvent((hipStream_t)es_stream, (hipEvent_t)copied_event_, 0) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (es_stream != stream && hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)copied_event_, 0) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
         copy_pending_ = false;
     }
     if ((which < 0 && !entropy_done_) || which == 3) {
-        hipjpegStatus_t es = enqueue_gpu_entropy(stream);
+        hipjpegStatus_t es = enqueue_gpu_entropy(es_stream);
         if (es != HIPJPEG_STATUS_SUCCESS) return es;
         if (which == 3) return resolve(stream);
+        if (es_stream != stream) {
+            if (!entropy_event_) {
+                hipEvent_t ev;
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+                entropy_event_ = ev;
+            }
+            if (hipEventRecord((hipEvent_t)entropy_event_, (hipStream_t)es_stream) != hipSuccess ||
+                hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)entropy_event_, 0) != hipSuccess)
+                return HIPJPEG_STATUS_HIP_ERROR;
+        }
     }
     if (launch_pixel_kernels(stream, which) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (which < 0) pixels_launched_ = true;

@@ -96,7 +96,8 @@ public:
     hipjpegStatus_t transfer(void* stream, bool kernels_on_other_stream = false);
     // Phase 3: kernel launches.  which = -1: all; 0 idct_plane, 1 luma_color (every variant), 2 generic_color,
     // 3 GPU entropy stage (blocks until its result status has been read back).
-    hipjpegStatus_t launch(void* stream, int which = -1);
+    // entropy_stream (optional): a second stream for the GPU entropy stage, see launch() in decoder_core.cpp
+    hipjpegStatus_t launch(void* stream, int which = -1, void* entropy_stream = nullptr);
     // After launch(): waits for `stream` and settles the GPU entropy stage's verdicts (see decoder_core.cpp); image(i).status
     // is final afterwards.  A no-op for batches without GPU-decoded streams.
     hipjpegStatus_t resolve(void* stream);
@@ -140,7 +141,8 @@ private:
     int launch_pixel_kernels(void* stream, int which);
     bool entropy_pending_ = false, pixels_launched_ = false, copy_pending_ = false;
     void* last_stream_ = nullptr;  // stream of the last launch()
-    void* copied_event_ = nullptr;  // hipEvent_t: H2D copy issued on a stream other than the kernels' 
+    void* copied_event_ = nullptr;
+    void* entropy_event_ = nullptr;  // hipEvent_t: entropy stage finished on its own stream  // hipEvent_t: H2D copy issued on a stream other than the kernels' 
     Buffer work_;  // device only: subsequence states, first-block indices, change counter
     std::vector<HuffImage> huff_images_;
     std::vector<HuffUnit> huff_units_, huff_dc_units_;

@@ -37,6 +37,7 @@ struct hipjpegHandle {
     void* submitted_stream[kPages] = {nullptr, nullptr, nullptr};
     int num_submitted = 0;
     hipStream_t copy_stream = nullptr;  // H2D copies of submitted batches: they overlap the kernels of the batch before
+    hipStream_t entropy_stream = nullptr;  // GPU entropy stage of submitted batches: beside the pixel kernels of the batch before
     std::unique_ptr<EncodeBatch> encode;
     EncodeBatch* encode_view = nullptr;  // the batch hipjpegEncodeGetBitstream / GetCoefficients / Stats talk about
     // pipelined encoding (hipjpegEncodeBatchSubmit / Wait): two pages, each driven by its own host thread on its own
@@ -171,6 +172,7 @@ hipjpegStatus_t hipjpegDestroy(hipjpegHandle_t handle)
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     (void)hipSetDevice(handle->device_id);
     if (handle->copy_stream) (void)hipStreamDestroy(handle->copy_stream);
+    if (handle->entropy_stream) (void)hipStreamDestroy(handle->entropy_stream);
     for (auto& pg : handle->encode_pages) {
         if (pg.result.valid()) (void)pg.result.get();
         pg.batch.reset();
@@ -270,11 +272,14 @@ hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* 
     if (handle->num_submitted >= hipjpegHandle::kPages) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // every page in flight: Wait first
     if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
     if (!handle->copy_stream && hipStreamCreateWithFlags(&handle->copy_stream, hipStreamNonBlocking) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    static const bool two_streams = getenv("HIPJPEG_SINGLE_STREAM") == nullptr;  // HIPJPEG_SINGLE_STREAM=1: measurement aid
+    if (two_streams && !handle->entropy_stream && hipStreamCreateWithFlags(&handle->entropy_stream, hipStreamNonBlocking) != hipSuccess)
+        return HIPJPEG_STATUS_HIP_ERROR;
     hipjpegStatus_t st = hipjpegDecodeBatchHost(handle, data, lengths, batch_size, outputs, format, flags, nullptr);
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     DecodeBatch& b = handle->cur();
     if ((st = b.transfer(handle->copy_stream, true)) != HIPJPEG_STATUS_SUCCESS) return st;
-    if ((st = b.launch(stream)) != HIPJPEG_STATUS_SUCCESS) return st;
+    if ((st = b.launch(stream, -1, handle->entropy_stream)) != HIPJPEG_STATUS_SUCCESS) return st;
     handle->submitted[handle->num_submitted] = handle->current;
     handle->submitted_stream[handle->num_submitted] = stream;
     handle->num_submitted++;
