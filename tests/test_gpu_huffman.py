@@ -146,3 +146,31 @@ def test_randomly_damaged_streams_never_disagree_with_the_host_path(dec):
     outs, _ = dec.decode(bases[:2], gpu_huffman=True)
     torch.cuda.synchronize()
     assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(bases[0]))
+
+
+def test_pipelined_submit_wait_with_three_batches_in_flight(dec):
+    """hipjpegDecodeBatchSubmit / Wait: results come back in submission order, identical to the one-shot path, also when a
+    batch carries a stream the kernels have to hand back to the host decoder and when batches mix both entropy stages."""
+    import torch
+    good = [oracle.encode(synth_image(320 + 16 * k, 200 + 8 * k, seed=70 + k), "420" if k % 2 else "422", 85) for k in range(6)]
+    prog = next(load_decode_case(e)[0] for e in _M["decode"] if e["progressive"] and e["width"] >= 64)
+    broken = good[0][: len(good[0]) // 2] + b"\xff\xd9"
+    batches = [good[:4], [good[4], prog, good[5]], [good[1], broken, good[2]], good[2:6], [prog], good[:3]]
+    refs = {j: oracle.decode(j) for b in batches for j in b if j != broken}
+    outs = [dec.allocate_outputs(b) for b in batches]
+    results = []
+    for k, b in enumerate(batches):
+        dec.submit(b, outs[k])
+        if k >= 2:
+            results.append(dec.wait(check=False))
+    results.append(dec.wait(check=False))
+    results.append(dec.wait(check=False))
+    torch.cuda.synchronize()
+    assert len(results) == len(batches)
+    for k, (b, st) in enumerate(zip(batches, results)):
+        for i, j in enumerate(b):
+            if j == broken:
+                assert st[i] in (4, 5), (k, i)
+            else:
+                assert st[i] == 0, (k, i)
+                assert np.array_equal(outs[k][i].cpu().numpy(), refs[j]), (k, i)
