@@ -170,7 +170,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     std::vector<size_t> xform_plane_off;  // per TransformImage plane, in order
     xform_desc_.clear();
     size_t huff_stream_total = 0, huff_subseq_ub = 0, huff_pool_total = 0, huff_blocks_total = 0, huff_raw_total = 0, huff_chunks_total = 0;
-    size_t huff_blockpos_total = 0;
+    size_t huff_blockpos_total = 0, huff_boundary_total = 0;
     max_huff_units_ = max_huff_wunits_ = 0;
     max_pool_words_ = 0;
     std::vector<size_t> plane_off((size_t)n * 4, (size_t)-1);
@@ -328,6 +328,9 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
                 huff_blocks_total += ((size_t)f.comp[c].blocks_w * f.comp[c].blocks_h + 31) & ~(size_t)31;
             }
             max_huff_wunits_ += ((size_t)f.mcus_x * f.mcus_y + kHuffMcusPerWg - 1) / kHuffMcusPerWg + 1;
+            im.boundary_offset = huff_boundary_total;  // relative; rebased below (restart boundaries + per-subsequence index)
+            im.num_boundaries = (uint32_t)f.scans[0].rst_after.size();
+            if (f.scans[0].restart_interval) huff_boundary_total += align_up(((size_t)im.num_boundaries + nsub + 1) * 4, 64);
             im.block_pos_offset = huff_blockpos_total * 4;
             huff_blockpos_total += (f.total_blocks() + 63) & ~(size_t)63;
         }
@@ -353,7 +356,8 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     xform_desc_offset_ = align_up(huff_chunk_units_offset_ + sizeof(HuffUnit) * huff_chunks_total, 256);
     xform_units_offset_ = align_up(xform_desc_offset_ + sizeof(TransformImage) * xform_desc_.size(), 256);
     const size_t tables_base = align_up(xform_units_offset_ + sizeof(WorkUnit) * max_xform_units, 256);
-    const size_t streams_base = align_up(tables_base + huff_pool_total, 256);
+    const size_t boundaries_base = align_up(tables_base + huff_pool_total, 256);
+    const size_t streams_base = align_up(boundaries_base + huff_boundary_total, 256);
     coef_offset_ = align_up(streams_base + huff_raw_total, 256);
     for (int pass = 0; pass < 2; pass++) {  // host-decoded images first, GPU-decoded ones behind the H2D boundary
         if (pass == 1) {
@@ -370,6 +374,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
             }
             if (im.gpu_entropy) {
                 im.raw_offset += streams_base;
+                im.boundary_offset += boundaries_base;
                 im.tables_offset += tables_base;
             }
         }
@@ -449,6 +454,19 @@ void DecodeBatch::entropy_stage(int i)
         HuffImage& h = huff_images_[im.huff_index];
         fill_huff_image(im.frame, im.stream_bytes, &h);
         build_gpu_pool(sc, &h, reinterpret_cast<uint16_t*>(pinned_.data() + im.tables_offset));
+        if (sc.restart_interval) {
+            // restart boundaries in bits, and for every subsequence the first boundary at or behind its first bit
+            uint32_t* bnd = reinterpret_cast<uint32_t*>(pinned_.data() + im.boundary_offset);
+            uint32_t* sub = bnd + im.num_boundaries;
+            for (uint32_t b = 0; b < im.num_boundaries; b++) bnd[b] = sc.rst_after[b] * 8u;
+            uint32_t idx = 0;
+            for (uint32_t j = 0; j <= h.num_subseq; j++) {
+                while (idx < im.num_boundaries && bnd[idx] < j * (uint32_t)kSubseqBits) idx++;
+                sub[j] = idx;
+            }
+            h.restart_interval = (uint32_t)sc.restart_interval;
+            h.num_boundaries = im.num_boundaries;
+        }
         // magnitude bound for the 24-bit multiplier decision without seeing the coefficients: DC values live in int16,
         // AC magnitudes are below 2^(largest size category any AC table of the scan can code)
         for (int c = 0; c < im.frame.ncomp; c++) {
@@ -562,6 +580,10 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         }
         h.stream = work_.data() + work_streams_ + im.stream_offset;
         h.raw = device_.data() + im.raw_offset;
+        if (h.restart_interval) {
+            h.boundaries = reinterpret_cast<const uint32_t*>(device_.data() + im.boundary_offset);
+            h.sub_boundary = h.boundaries + h.num_boundaries;
+        }
         h.raw_bytes = im.stream_bytes;
         h.first_chunk = im.first_chunk;
         for (uint32_t c = 0; c * (uint32_t)kDestuffChunk < im.stream_bytes; c++) huff_chunk_units_.push_back(HuffUnit{(uint32_t)g, c});

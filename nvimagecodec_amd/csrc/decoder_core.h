@@ -69,6 +69,8 @@ struct PlannedImage {
     size_t pool_words = 0;      // lookup-table entries of the scan (GPU entropy path)
     size_t raw_offset = 0;      // staged copy of the scan's entropy-coded bytes
     uint32_t first_chunk = 0;   // first destuff chunk (batch-wide numbering)
+    size_t boundary_offset = 0;   // restart boundaries + per-subsequence boundary index (staging area)
+    uint32_t num_boundaries = 0;
     size_t block_pos_offset = 0;  // bytes into the block-position scratch
     size_t dc_diff_offset = 0;
     size_t dc_plane_offset[4] = {0, 0, 0, 0};  // bytes into the same scratch: compact DC planes per component  // bytes into the DC-difference scratch

@@ -55,12 +55,21 @@ struct WgShared {
     uint32_t wave_count[4];
 };
 
+// restart boundaries live in global memory (a handful of reads per decode; the destuffed positions come from the host's
+// marker walk)
+__device__ __forceinline__ uint32_t load_boundary(const uint32_t* boundaries, uint32_t n, uint32_t i)
+{
+    return i < n ? ((const HJ_GLOBAL uint32_t*)boundaries)[i] : 0xFFFFFFFFu;
+}
 // LDS accessors for decode_subsequence.
 struct DevEnv {
     uint32_t stream_base;  // LDS byte address of the staged words
     uint32_t word0;        // image word index of the first staged word
     uint32_t pool;         // LDS byte address of the lookup tables
     const HJ_LDS uint32_t* tsel;  // per MCU position: BYTE offsets of the DC / AC first-level tables, packed lo/hi
+    const uint32_t* boundaries;
+    uint32_t num_boundaries;
+    __device__ __forceinline__ uint32_t boundary(uint32_t i) const { return load_boundary(boundaries, num_boundaries, i); }
     __device__ __forceinline__ uint32_t word(uint32_t i) const
     {
         const uint32_t local = i - word0;
@@ -76,6 +85,18 @@ struct DevEnv {
         return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0x1FFu) << 7) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
     }
 };
+
+__device__ __forceinline__ uint32_t boundary0_of(const HuffImage& im, uint32_t subseq)
+{
+    return im.restart_interval ? ((const HJ_GLOBAL uint32_t*)im.sub_boundary)[subseq] : 0u;
+}
+// decode_subsequence with or without restart handling (wave-uniform choice: one image per workgroup)
+template <class Env>
+__device__ __forceinline__ SubseqState walk_subsequence(bool rst, const HuffGeom& geom, const Env& env, uint32_t begin, uint32_t limit, int z, int k,
+                                                        uint32_t boundary0)
+{
+    return rst ? decode_subsequence<true>(geom, env, begin, limit, z, k, boundary0) : decode_subsequence<false>(geom, env, begin, limit, z, k);
+}
 
 // Cooperative staging of stream words: ROWS subsequences starting with subsequence first_row of the image (first_row may
 // be -1: that row is filled with ones) plus kStagedExtra words.  16-byte global loads, all of a lane's loads in flight
@@ -150,13 +171,15 @@ __device__ __forceinline__ void stage_constants(uint32_t* tsel, KSlot* kslot, ui
     }
 }
 
-__device__ __forceinline__ DevEnv make_env(WgShared& sh, HJ_LDS uint16_t* pool, uint32_t first)
+__device__ __forceinline__ DevEnv make_env(WgShared& sh, HJ_LDS uint16_t* pool, uint32_t first, const HuffGeom& geom)
 {
     DevEnv env;
     env.stream_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)sh.stream;
     env.word0 = (first - 1) * kSubseqWords;  // row 0 = the halo (wraps for the first workgroup of an image; so do the indices)
     env.pool = (uint32_t)(uintptr_t)pool;
     env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
+    env.boundaries = geom.boundaries;
+    env.num_boundaries = geom.num_boundaries;
     return env;
 }
 
@@ -189,12 +212,18 @@ __device__ __forceinline__ int compact_tasks(WgShared& sh, bool has, int value, 
 // markers, fill bytes) never get here (gpu_entropy_eligible()).
 
 // 0x80 in every byte of x (little-endian dword) that is 0x00 and whose predecessor byte is 0xFF; prev = the byte before x.
-__device__ __forceinline__ uint32_t stuffed_mask(uint32_t x, uint32_t prev)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }  // 0x80 per zero byte
+
+// Bytes of x to drop: a 0x00 behind an 0xFF (stuffing), and both bytes of a restart marker FF D0..D7.  prev = the byte in
+// front of x, next = the byte behind it.
+__device__ __forceinline__ uint32_t stuffed_mask(uint32_t x, uint32_t prev, uint32_t next)
 {
-    const uint32_t np = ~((x << 8) | prev);  // byte i = ~predecessor of x's byte i: zero where the predecessor is 0xFF
-    const uint32_t zero_x = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-    const uint32_t zero_np = ~(((np & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | np | 0x7F7F7F7Fu);
-    return zero_x & zero_np;
+    const uint32_t ff_before = zero_bytes(~((x << 8) | prev));        // predecessor is 0xFF
+    const uint32_t rst_x = zero_bytes((x & 0xF8F8F8F8u) ^ 0xD0D0D0D0u);  // x's byte is D0..D7
+    const uint32_t second = (zero_bytes(x) | rst_x) & ff_before;      // stuffed zero, or the marker's second byte
+    const uint32_t after = (x >> 8) | (next << 24);                   // successor of each byte
+    const uint32_t first = zero_bytes(~x) & zero_bytes((after & 0xF8F8F8F8u) ^ 0xD0D0D0D0u);  // an FF in front of D0..D7
+    return second | first;
 }
 
 // stuffed-byte masks of the 64 bytes at p (16-byte aligned); returns the count
@@ -211,9 +240,10 @@ __device__ __forceinline__ uint32_t lane_masks(const uint8_t* p, bool has_prev, 
         x[4 * i + 2] = v.z;
         x[4 * i + 3] = v.w;
     }
+    const uint32_t behind = p[64];  // the raw copy is padded with 16 neutral bytes: always readable
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        m[i] = stuffed_mask(x[i], prev);
+        m[i] = stuffed_mask(x[i], prev, i < 15 ? (x[i < 15 ? i + 1 : 15] & 0xFFu) : behind);
         prev = x[i] >> 24;
         n += __popc(m[i]);
     }
@@ -246,9 +276,10 @@ __global__ __launch_bounds__(kThreads) void destuff_count_kernel(const HuffImage
             n = lane_masks(im.raw + off, off > 0, m, x);
         } else {
             uint32_t prev = off > 0 ? im.raw[off - 1] : 0u;
+            const uint32_t* words = reinterpret_cast<const uint32_t*>(im.raw + off);  // 16 neutral bytes of padding follow the data
             for (uint32_t i = 0; i < pieces * 4; i++) {
-                const uint32_t w = reinterpret_cast<const uint32_t*>(im.raw + off)[i];
-                n += __popc(stuffed_mask(w, prev));
+                const uint32_t w = words[i];
+                n += __popc(stuffed_mask(w, prev, words[i + 1] & 0xFFu));
                 prev = w >> 24;
             }
         }
@@ -284,9 +315,10 @@ __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __
         len = min(64u, raw_bytes - off);
         const uint32_t pieces = (len + 15) / 16;
         uint32_t prev = off > 0 ? im.raw[off - 1] : 0u;
+        for (uint32_t i = 0; i < 16; i++) x[i] = i < pieces * 4 ? reinterpret_cast<const uint32_t*>(im.raw + off)[i] : 0x01010101u;
+        const uint32_t behind = pieces == 4 ? im.raw[off + 64] : 0x01u;  // 16 neutral bytes of padding follow the data
         for (uint32_t i = 0; i < 16; i++) {
-            x[i] = i < pieces * 4 ? reinterpret_cast<const uint32_t*>(im.raw + off)[i] : 0x01010101u;
-            m[i] = stuffed_mask(x[i], prev);
+            m[i] = stuffed_mask(x[i], prev, i < 15 ? (x[i < 15 ? i + 1 : 15] & 0xFFu) : behind);
             prev = x[i] >> 24;
             n += __popc(m[i]);
         }
@@ -384,14 +416,16 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
     stage_constants(sh.tsel, nullptr, nullptr, im, false);
     __syncthreads();
 
-    const DevEnv env = make_env(sh, pool, u.first);
+    const DevEnv env = make_env(sh, pool, u.first, geom);
+    const bool rst = im.restart_interval != 0;
     unsigned long long old_global = ~0ull;
     int task = -1;
     if (first_pass) {
         const unsigned long long assumed = (unsigned long long)j * kSubseqBits;
         unsigned long long mine = 0;  // first workgroup of an image, lane 0: the exact initial state (bit 0, z 0, k 0)
         if (owner || (t == 0 && u.first > 0)) {
-            mine = pack_state(decode_subsequence(geom, env, j * kSubseqBits, (j + 1) * kSubseqBits, 0, 0));
+            const uint32_t bidx0 = boundary0_of(im, j);
+            mine = pack_state(walk_subsequence(rst, geom, env, j * kSubseqBits, (j + 1) * kSubseqBits, 0, 0, bidx0));
         }
         sh.end[t] = mine;
         __syncthreads();
@@ -409,7 +443,7 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
         bool moved = false;
         if (task >= 0) {
             const SubseqState p = unpack_state(sh.end[task - 1]);
-            now = pack_state(decode_subsequence(geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8));
+            now = pack_state(walk_subsequence(rst, geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8, boundary0_of(im, u.first - 1 + task)));
             moved = ((now ^ sh.end[task]) & kSyncMask) != 0;
         }
         __syncthreads();  // every start state has been read before any end state is replaced
@@ -463,6 +497,9 @@ struct TailEnv {
     uint32_t word0;     // image word index of its first word
     uint32_t pool;
     const HJ_LDS uint32_t* tsel;
+    const uint32_t* boundaries;
+    uint32_t num_boundaries;
+    __device__ __forceinline__ uint32_t boundary(uint32_t i) const { return load_boundary(boundaries, num_boundaries, i); }
     __device__ __forceinline__ uint32_t word(uint32_t i) const { return *(const HJ_LDS uint32_t*)(uintptr_t)(row_base + ((i - word0) << 2)); }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
     __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
@@ -504,6 +541,9 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
     env.row_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&sh.rows[t * kTailRowWords];
     env.pool = (uint32_t)(uintptr_t)pool;
     env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
+    env.boundaries = geom.boundaries;
+    env.num_boundaries = geom.num_boundaries;
+    const bool rst = im.restart_interval != 0;
     const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
     const uint32_t gwords = im.stream_words;
     int rounds = 0, cur = 0;
@@ -533,7 +573,7 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
                     row[4 * i + 3] = ok ? __builtin_bswap32(x.w) : ~0u;
                 }
                 const SubseqState p = unpack_state(sh.end[task - 1]);
-                now = pack_state(decode_subsequence(geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8));
+                now = pack_state(walk_subsequence(rst, geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8, boundary0_of(im, u.first - 1 + task)));
                 moved = ((now ^ sh.end[task]) & kSyncMask) != 0;
             }
             __syncthreads();  // one wave: orders the LDS traffic, costs next to nothing
@@ -616,7 +656,8 @@ __global__ __launch_bounds__(kThreads) void huff_pos_kernel(const HuffImage* __r
     const int t = threadIdx.x;
     const uint32_t j = u.first - 1 + t;
     if (t == 0 || j >= nsub) return;
-    const DevEnv env = make_env(sh, pool, u.first);
+    const DevEnv env = make_env(sh, pool, u.first, geom);
+    const bool rst = im.restart_interval != 0;
     const unsigned long long* st = states + im.first_subseq;
     uint32_t begin = 0;
     int z = 0, k = 0;
@@ -628,9 +669,13 @@ __global__ __launch_bounds__(kThreads) void huff_pos_kernel(const HuffImage* __r
     }
     HJ_GLOBAL uint32_t* out = (HJ_GLOBAL uint32_t*)im.block_pos;
     const uint32_t total_blocks = im.total_blocks;
-    position_subsequence(geom, env, begin, (j + 1) * kSubseqBits, z, k, first_block[im.first_subseq + j], [&](uint32_t block, uint32_t pos) {
+    auto rec = [&](uint32_t block, uint32_t pos) {
         if (block < total_blocks) out[block] = pos;
-    });
+    };
+    if (rst)
+        position_subsequence<true>(geom, env, begin, (j + 1) * kSubseqBits, z, k, first_block[im.first_subseq + j], rec, boundary0_of(im, j));
+    else
+        position_subsequence<false>(geom, env, begin, (j + 1) * kSubseqBits, z, k, first_block[im.first_subseq + j], rec);
 }
 
 // ---- write pass, step 2: one lane per block -----------------------------------------------------------------------------------
@@ -777,6 +822,7 @@ __global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __res
 __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units)
 {
     __shared__ int s_sum[kThreads];
+    __shared__ int s_flag[kThreads];
     const HuffUnit u = units[blockIdx.x];  // first = component
     const HuffImage& im = images[u.image];
     const int c = (int)u.first;
@@ -787,6 +833,8 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
     HJ_GLOBAL int16_t* plane = (HJ_GLOBAL int16_t*)im.dc_plane[c];
     const HJ_GLOBAL int16_t* diff = (const HJ_GLOBAL int16_t*)im.dc_diff;
     const uint32_t bw = im.blocks_w[c], mcus_x = im.mcus_x;
+    // restart intervals: the predictor starts over every `seg` entries of the component (0xFFFFFFFF: never)
+    const uint32_t seg = im.restart_interval ? im.restart_interval * bpc : 0xFFFFFFFFu;
     // entry s of the component (MCU order) sits at diff[(s / bpc) * bpm + k0 + s % bpc]; every lane takes a contiguous run
     const uint32_t per = (n + kThreads - 1) / kThreads;
     const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
@@ -795,31 +843,58 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
         return mcu * bpm + k0 + (s - mcu * bpc);
     };
     constexpr int kBatch = 8;  // independent loads in flight per lane
-    int sum = 0;
-    for (uint32_t s = lo; s < hi; s += kBatch) {
-        int d[kBatch];
-#pragma unroll
-        for (int i = 0; i < kBatch; i++) d[i] = s + i < hi ? (int)diff[index_of(s + i)] : 0;
-#pragma unroll
-        for (int i = 0; i < kBatch; i++) sum += d[i];
-    }
-    s_sum[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-        int t = threadIdx.x >= (unsigned)off ? s_sum[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_sum[threadIdx.x] += t;
-        __syncthreads();
-    }
-    int run = threadIdx.x ? s_sum[threadIdx.x - 1] : 0;
+    // per lane: the running sum at the end of its run (since the last restart inside the run, if any)
+    int sum = 0, flag = 0;
+    uint32_t until = lo < hi ? (seg == 0xFFFFFFFFu ? 0xFFFFFFFFu : (seg - lo % seg) % seg) : 0xFFFFFFFFu;  // entries until the next restart
     for (uint32_t s = lo; s < hi; s += kBatch) {
         int d[kBatch];
 #pragma unroll
         for (int i = 0; i < kBatch; i++) d[i] = s + i < hi ? (int)diff[index_of(s + i)] : 0;
 #pragma unroll
         for (int i = 0; i < kBatch; i++) {
-            run += d[i];
             if (s + i < hi) {
+                if (until == 0) {
+                    sum = 0;
+                    flag = 1;
+                    until = seg;
+                }
+                until--;
+            }
+            sum += d[i];
+        }
+    }
+    s_sum[threadIdx.x] = sum;
+    s_flag[threadIdx.x] = flag;
+    __syncthreads();
+    // segmented inclusive scan over the lanes: (a, fa) . (b, fb) = fb ? (b, 1) : (a + b, fa)
+    for (int off = 1; off < kThreads; off <<= 1) {
+        int a = 0, fa = 0;
+        if (threadIdx.x >= (unsigned)off) {
+            a = s_sum[threadIdx.x - off];
+            fa = s_flag[threadIdx.x - off];
+        }
+        __syncthreads();
+        if (threadIdx.x >= (unsigned)off && !s_flag[threadIdx.x]) {
+            s_sum[threadIdx.x] += a;
+            s_flag[threadIdx.x] = fa;
+        }
+        __syncthreads();
+    }
+    int run = threadIdx.x ? s_sum[threadIdx.x - 1] : 0;
+    until = lo < hi ? (seg == 0xFFFFFFFFu ? 0xFFFFFFFFu : (seg - lo % seg) % seg) : 0xFFFFFFFFu;
+    for (uint32_t s = lo; s < hi; s += kBatch) {
+        int d[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) d[i] = s + i < hi ? (int)diff[index_of(s + i)] : 0;
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) {
+            if (s + i < hi) {
+                if (until == 0) {
+                    run = 0;
+                    until = seg;
+                }
+                until--;
+                run += d[i];
                 const uint32_t mcu = (s + i) / bpc, jj = (s + i) - mcu * bpc;
                 const uint32_t my = mcu / mcus_x, mx = mcu - my * mcus_x;
                 const uint32_t dy = jj / h, dx = jj - dy * h;

@@ -9,7 +9,13 @@ bool gpu_entropy_eligible(const FrameInfo& f)
 {
     if (f.progressive() || f.scans.size() != 1) return false;
     const ScanHeader& sc = f.scans[0];
-    if (sc.ncomp != f.ncomp || sc.restart_interval != 0 || !sc.plain_stuffing) return false;
+    if (sc.ncomp != f.ncomp || !sc.plain_stuffing) return false;
+    {
+        // restart intervals: every interval but the last must be closed by its marker (RST0..7 in order: plain_stuffing)
+        const size_t mcus = (size_t)(f.ncomp == 1 ? ((f.comp[0].samp_w + 7) / 8) * ((f.comp[0].samp_h + 7) / 8) : f.mcus_x * f.mcus_y);
+        const size_t expect = sc.restart_interval ? (mcus + sc.restart_interval - 1) / sc.restart_interval - 1 : 0;
+        if (sc.rst_after.size() != expect) return false;
+    }
     int bpm = 0;
     for (int i = 0; i < sc.ncomp; i++) {
         if (sc.comp_index[i] != i) return false;  // keep the MCU layout simple: components in frame order
@@ -41,8 +47,10 @@ size_t destuff_scan(const uint8_t* data, const ScanHeader& sc, uint8_t* out)
         if (p < end && *p == 0x00) {
             *o++ = 0xFF;
             p++;
+        } else if (p < end && *p >= 0xD0 && *p <= 0xD7) {
+            p++;  // restart marker: dropped; the interval behind it starts at this (byte-aligned) position
         } else {
-            break;  // a marker (cannot happen before data_end for restart-free scans) or the end
+            break;  // another marker (cannot happen before data_end) or the end
         }
     }
     const size_t n = (size_t)(o - out);
@@ -206,6 +214,7 @@ struct HostEnv {
         const uint8_t* p = im->stream + (size_t)i * 4;  // the slack behind the stream covers the reader's look-ahead
         return i < im->stream_words ? ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3] : ~0u;
     }
+    uint32_t boundary(uint32_t i) const { return i < im->num_boundaries ? im->boundaries[i] : 0xFFFFFFFFu; }
     uint32_t lookup1(uint32_t t, uint32_t w) const { return im->pool[t + (w >> (32 - kHuffFastBits))]; }
     uint32_t lookup2(uint32_t e, uint32_t w) const { return im->pool[(e & 0x1FFu) * 64u + ((w >> 16) & ((1u << kHuffSubBits) - 1))]; }
     uint32_t tables(int k) const { return (uint32_t)im->k[k].tdc | ((uint32_t)im->k[k].tac << 16); }
@@ -231,9 +240,15 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
     fill_huff_image(f, (uint32_t)n, &im);
     build_gpu_pool(sc, &im, pool.data());
     std::vector<int16_t> dc_diff(im.total_blocks);
+    std::vector<uint32_t> boundaries;
+    for (uint32_t b : sc.rst_after) boundaries.push_back(b * 8u);
     im.stream = stream.data();
     im.pool = pool.data();
     im.dc_diff = dc_diff.data();
+    im.boundaries = boundaries.data();
+    im.num_boundaries = (uint32_t)boundaries.size();
+    im.restart_interval = (uint32_t)sc.restart_interval;
+    const bool rst = sc.restart_interval != 0;
     for (int c = 0; c < f.ncomp; c++) {
         im.coef[c] = coef[c];
         memset(coef[c], 0x5A, (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 128);  // every block must be written by the write pass
@@ -245,14 +260,17 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
     std::vector<SubseqState> cur(ns), nxt(ns);
     uint32_t err = 0;
     // pass 0
-    for (uint32_t i = 0; i < ns; i++) cur[i] = decode_subsequence(geom, env, i * kSubseqBits, (i + 1) * kSubseqBits, 0, 0);
+    auto walk = [&](uint32_t begin, uint32_t limit, int z, int k) {
+        return rst ? decode_subsequence<true>(geom, env, begin, limit, z, k, 0) : decode_subsequence<false>(geom, env, begin, limit, z, k);
+    };
+    for (uint32_t i = 0; i < ns; i++) cur[i] = walk(i * kSubseqBits, (i + 1) * kSubseqBits, 0, 0);
     int passes = 0;
     for (;;) {
         bool changed = false;
         if (ns) nxt[0] = cur[0];
         for (uint32_t i = 1; i < ns; i++) {
             const SubseqState& prev = cur[i - 1];
-            nxt[i] = decode_subsequence(geom, env, prev.end_bit, (i + 1) * kSubseqBits, prev.zk & 255, prev.zk >> 8);
+            nxt[i] = walk(prev.end_bit, (i + 1) * kSubseqBits, prev.zk & 255, prev.zk >> 8);
             if (pack_state(nxt[i]) != pack_state(cur[i])) changed = true;
         }
         cur.swap(nxt);
@@ -274,9 +292,13 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
     for (uint32_t i = 0; i < ns; i++) {
         const uint32_t begin = i == 0 ? 0 : cur[i - 1].end_bit;
         const int z = i == 0 ? 0 : (cur[i - 1].zk & 255), k = i == 0 ? 0 : (cur[i - 1].zk >> 8);
-        position_subsequence(geom, env, begin, (i + 1) * kSubseqBits, z, k, first_block[i], [&](uint32_t block, uint32_t pos) {
+        auto rec = [&](uint32_t block, uint32_t pos) {
             if (block < im.total_blocks) block_pos[block] = pos;
-        });
+        };
+        if (rst)
+            position_subsequence<true>(geom, env, begin, (i + 1) * kSubseqBits, z, k, first_block[i], rec, 0);
+        else
+            position_subsequence<false>(geom, env, begin, (i + 1) * kSubseqBits, z, k, first_block[i], rec);
     }
     // step 2: every block on its own
     for (uint32_t b = 0; b < im.total_blocks; b++) {
@@ -290,14 +312,16 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
     if (err) return 1;
     // DC integration, per component in MCU (scan) order
     int pred[4] = {0, 0, 0, 0};
-    uint32_t block = 0;
+    uint32_t block = 0, mcu = 0;
     for (uint32_t my = 0; my < im.mcus_y; my++)
-        for (uint32_t mx = 0; mx < im.mcus_x; mx++)
+        for (uint32_t mx = 0; mx < im.mcus_x; mx++, mcu++) {
+            if (rst && mcu % im.restart_interval == 0) pred[0] = pred[1] = pred[2] = pred[3] = 0;  // DC predictors start over
             for (uint32_t k = 0; k < im.blocks_per_mcu; k++, block++) {
                 const int c = im.k[k].comp;
                 pred[c] += dc_diff[block];
                 env.block_ptr((int)k, mx, my)[0] = (int16_t)pred[c];
             }
+        }
     return 0;
 }
 

@@ -86,7 +86,11 @@ struct alignas(16) HuffImage {
     uint32_t raw_bytes;
     uint32_t decoded_blocks; // blocks the converged decoders completed (scan kernel); < total_blocks = truncated stream
     uint32_t* block_pos;     // total_blocks bit positions: where every block starts (position pass -> block pass)
-    uint64_t pad0;
+    // restart intervals (0 = none): the bit positions where intervals 1, 2, ... begin in the destuffed stream, and for every
+    // subsequence the index of the first of them at or behind its first bit
+    const uint32_t* boundaries;
+    const uint32_t* sub_boundary;
+    uint32_t restart_interval, num_boundaries;
     HuffK k[10];
     uint32_t blocks_w[4];
     uint8_t comp_h[4], comp_v[4], comp_k0[4], pad1[4];  // comp_k0 = first position k of the component inside the MCU
@@ -120,6 +124,8 @@ static const uint8_t kZigzagDeviceGpuHost[64] = HJ_ZIGZAG_DEVICE_TABLE;
 struct HuffGeom {
     uint32_t total_bits, blocks_per_mcu, mcus_x, mcus_y;
     int16_t* dc_diff;
+    const uint32_t* boundaries;
+    uint32_t num_boundaries;
 };
 HJ_HD HuffGeom make_geom(const HuffImage& im)
 {
@@ -129,6 +135,8 @@ HJ_HD HuffGeom make_geom(const HuffImage& im)
     g.mcus_x = im.mcus_x;
     g.mcus_y = im.mcus_y;
     g.dc_diff = im.dc_diff;
+    g.boundaries = im.boundaries;
+    g.num_boundaries = im.num_boundaries;
     return g;
 }
 
@@ -163,6 +171,46 @@ struct BitReader {
     }
 };
 
+// Restart markers (DRI): the scan is a chain of independent intervals.  The markers themselves are removed together with the
+// byte stuffing; what is left of them is a list of BOUNDARIES, the bit positions (multiples of 8) where intervals begin.  In
+// front of a boundary the encoder has filled the last byte with one-bits.  A decoder looks at them before every symbol:
+//   * it is at or past the next boundary: whatever it believed, a fresh interval starts exactly there -- position, zigzag index
+//     and MCU position are forced (for the true trajectory this changes nothing; a desynchronised one is exact from here on,
+//     so no correction chain outlives an interval);
+//   * it stands at the end of an MCU less than a byte in front of the boundary and only one-bits remain: padding, skip it
+//     (no complete symbol consists of one-bits only, so real data is never skipped).
+// Env::boundary(i) = bit position of boundary i, 0xFFFFFFFF behind the last one.
+struct RestartCursor {
+    uint32_t index, bound;
+    template <class Env>
+    HJ_HD void start(const Env& env, uint32_t first_candidate, uint32_t pos)
+    {
+        index = first_candidate;
+        bound = env.boundary(index);
+        while (bound < pos) bound = env.boundary(++index);
+    }
+    // returns true when pos/z/k were changed (the caller restarts its bit reader and reloads its table selection)
+    template <class Env>
+    HJ_HD bool normalise(const Env& env, uint32_t hi_bits, uint32_t* pos, int* z, int* k)
+    {
+        if (*pos >= bound) {
+            const bool changed = *pos != bound || *z != 0 || *k != 0;
+            *pos = bound;
+            *z = 0;
+            *k = 0;
+            bound = env.boundary(++index);
+            return changed;
+        }
+        const uint32_t gap = bound - *pos;
+        if (*z == 0 && *k == 0 && gap < 8 && (hi_bits >> (32 - gap)) == (1u << gap) - 1) {
+            *pos = bound;
+            bound = env.boundary(++index);
+            return true;
+        }
+        return false;
+    }
+};
+
 // Synchronisation decode: the symbols that START in [begin, limit) (and before total_bits), beginning in state (z, k).
 // Tracks the decoder state and counts the blocks completed; nothing is stored.
 // Env supplies the memory accessors:
@@ -171,8 +219,9 @@ struct BitReader {
 //                                        unit lookup1 wants
 //   uint32_t lookup1(uint32_t t, w)      first-level entry of table t for window w (index = top kHuffFastBits bits)
 //   uint32_t lookup2(uint32_t e, w)      second-level entry behind first-level entry e (index = next kHuffSubBits bits)
-template <class Env>
-HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k)
+// RST: the scan has restart intervals; boundary0 = index of the first boundary at or behind the subsequence's first bit.
+template <bool RST, class Env>
+HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, uint32_t boundary0 = 0)
 {
     uint32_t pos = begin, nblocks = 0;
     const uint32_t end = limit < im.total_bits ? limit : im.total_bits;
@@ -181,7 +230,15 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
     uint32_t tcur = z == 0 ? (tsel & 0xFFFFu) : (tsel >> 16);  // table of the next symbol: DC at the start of a block, AC after it
     BitReader br;
     br.start(env, pos);
+    RestartCursor rc;
+    if (RST) rc.start(env, boundary0, pos);
     while (pos < end) {
+        if (RST && rc.normalise(env, br.hi, &pos, &z, &k)) {
+            tsel = env.tables(k);
+            tcur = tsel & 0xFFFFu;
+            br.start(env, pos);
+            if (pos >= end) break;
+        }
         const uint32_t fetched = env.word(br.next);
         uint32_t e = env.lookup1(tcur, br.hi);
         tcur = tsel >> 16;
@@ -211,19 +268,34 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
 
 // Write pass, step 1 -- where the blocks start.  Same walk as decode_subsequence from the converged start state; calls
 // rec(block, pos) for every block whose first (DC) symbol starts in [begin, limit): `block` = scan-order index, `pos` = bit
-// position.  `block0` is the index of the block in progress at `begin` (the scan's prefix sum of completed blocks).
-template <class Env, class Rec>
-HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, uint32_t block0, const Rec& rec)
+// position (behind the padding of a restart boundary, if one lies in front of it).  `block0` is the index of the block in
+// progress at `begin` (the scan's prefix sum of completed blocks).
+template <bool RST, class Env, class Rec>
+HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, uint32_t block0, const Rec& rec,
+                                uint32_t boundary0 = 0)
 {
     uint32_t pos = begin, block = block0;
     const uint32_t end = limit < im.total_bits ? limit : im.total_bits;
     const int bpm = (int)im.blocks_per_mcu;
     uint32_t tsel = env.tables(k);
     uint32_t tcur = z == 0 ? (tsel & 0xFFFFu) : (tsel >> 16);
-    if (z == 0 && pos < end) rec(block, pos);
+    bool fresh = z == 0;  // the next symbol opens a block
     BitReader br;
     br.start(env, pos);
+    RestartCursor rc;
+    if (RST) rc.start(env, boundary0, pos);
     while (pos < end) {
+        if (RST && rc.normalise(env, br.hi, &pos, &z, &k)) {
+            tsel = env.tables(k);
+            tcur = tsel & 0xFFFFu;
+            br.start(env, pos);
+            fresh = true;
+            if (pos >= end) break;
+        }
+        if (fresh) {
+            rec(block, pos);
+            fresh = false;
+        }
         const uint32_t fetched = env.word(br.next);
         uint32_t e = env.lookup1(tcur, br.hi);
         if ((e >> 9) == kZadvLong) e = env.lookup2(e, br.hi);
@@ -237,7 +309,7 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
             if (++k == bpm) k = 0;
             tsel = env.tables(k);
             tcur = tsel & 0xFFFFu;
-            if (pos < end) rec(block, pos);
+            fresh = true;
         }
     }
 }

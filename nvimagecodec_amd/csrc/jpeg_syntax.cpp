@@ -14,11 +14,14 @@ namespace {
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
 // Finds the end of an entropy-coded segment: first 0xFF followed by something other than 0x00, 0xFF or RSTn.
-// *plain = false when the segment holds anything but data bytes and FF 00 pairs (RSTn markers, fill bytes, a lone FF at the
-// end of the input).
-size_t find_scan_end(const uint8_t* data, size_t pos, size_t size, bool* plain)
+// *plain = false when the segment holds fill bytes (FF FF), a lone FF at the end of the input, or restart markers that do not
+// count RST0, RST1, ... RST7, RST0 ...; rst_after (optional) receives, for every RSTn marker, the offset of the byte behind it in
+// the DESTUFFED segment (stuffed zeros and the markers themselves removed).
+size_t find_scan_end(const uint8_t* data, size_t pos, size_t size, bool* plain, std::vector<uint32_t>* rst_after)
 {
     *plain = true;
+    const size_t begin = pos;
+    size_t stuffed = 0, markers = 0;
     while (pos < size) {
         const uint8_t* ff = static_cast<const uint8_t*>(memchr(data + pos, 0xFF, size - pos));
         if (!ff) return size;
@@ -29,9 +32,12 @@ size_t find_scan_end(const uint8_t* data, size_t pos, size_t size, bool* plain)
         }
         uint8_t m = data[i + 1];
         if (m == 0x00) {
+            stuffed++;
             pos = i + 2;
         } else if (m >= 0xD0 && m <= 0xD7) {
-            *plain = false;
+            if ((unsigned)(m - 0xD0) != (markers & 7)) *plain = false;
+            markers++;
+            if (rst_after) rst_after->push_back((uint32_t)(i + 2 - begin - stuffed - 2 * markers));
             pos = i + 2;
         } else if (m == 0xFF) {
             *plain = false;
@@ -246,7 +252,7 @@ ParseStatus parse_jpeg(const uint8_t* data, size_t size, FrameInfo* f, bool head
             }
             sc.restart_interval = restart_interval;
             sc.data_begin = pos + L;
-            sc.data_end = find_scan_end(data, sc.data_begin, size, &sc.plain_stuffing);
+            sc.data_end = find_scan_end(data, sc.data_begin, size, &sc.plain_stuffing, headers_only ? nullptr : &sc.rst_after);
             f->scans.push_back(sc);
             pos = sc.data_end;
             continue;

@@ -41,7 +41,9 @@ struct ScanHeader {
     // Tables in force when this scan starts (DHT/DQT/DRI may be redefined between scans)
     HuffSpec dc[4], ac[4];
     int restart_interval = 0;
-    bool plain_stuffing = true;  // the segment consists of data bytes and FF 00 pairs only (no RSTn, no fill bytes)
+    bool plain_stuffing = true;  // the segment consists of data bytes, FF 00 pairs and RSTn markers in their proper order
+                                 // (no fill bytes, no lone FF at the end of the input)
+    std::vector<uint32_t> rst_after;  // per RSTn marker: offset of the byte behind it in the destuffed segment
 };
 
 struct FrameInfo {

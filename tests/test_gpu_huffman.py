@@ -33,13 +33,13 @@ def _sync():
 
 
 def test_all_goldens_mixed_eligibility_one_batch(dec):
-    """Eligible streams (baseline, one interleaved scan) go through the GPU entropy kernels, the others (progressive,
-    restart markers) through the host entropy stage -- in the same batch."""
+    """Eligible streams (baseline, one interleaved scan, with or without restart intervals) go through the GPU entropy
+    kernels, the others (progressive) through the host entropy stage -- in the same batch."""
     cases = [load_decode_case(e) for e in _M["decode"]]
     outs, statuses = dec.decode([c[0] for c in cases], gpu_huffman=True)
     _sync()
     st = dec.stats()
-    assert st["gpu_entropy_images"] == sum(1 for e in _M["decode"] if not e["progressive"] and e["restart"] == 0)
+    assert st["gpu_entropy_images"] == sum(1 for e in _M["decode"] if not e["progressive"])  # incl. restart intervals
     assert all(s == 0 for s in statuses)
     import hashlib
     for e, (jpeg, rgb), o in zip(_M["decode"], cases, outs):
@@ -174,3 +174,15 @@ def test_pipelined_submit_wait_with_three_batches_in_flight(dec):
             else:
                 assert st[i] == 0, (k, i)
                 assert np.array_equal(outs[k][i].cpu().numpy(), refs[j]), (k, i)
+
+
+def test_restart_interval_streams_on_the_gpu(dec):
+    import torch
+    spec = [(1920, 1080, "420", 90, 120), (1920, 1080, "420", 90, 1), (1283, 721, "422", 80, 7), (640, 480, "444", 95, 40), (500, 333, "gray", 70, 3),
+            (3840, 2160, "420", 85, 240)]
+    jpegs = [oracle.encode(synth_image(w, h, seed=11 * k + 1), sub, q, restart_interval=r) for k, (w, h, sub, q, r) in enumerate(spec)]
+    outs, _ = dec.decode(jpegs, gpu_huffman=True)
+    torch.cuda.synchronize()
+    assert dec.stats()["gpu_entropy_images"] == len(jpegs)
+    for j, o in zip(jpegs, outs):
+        assert np.array_equal(o.cpu().numpy(), oracle.decode(j))

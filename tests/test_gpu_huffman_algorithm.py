@@ -20,11 +20,11 @@ with open(os.path.join(GOLDEN, "manifest.json")) as _f:
 @pytest.mark.parametrize("entry", _M["decode"], ids=lambda e: e["name"])
 def test_algorithm_matches_oracle_or_declines(entry):
     jpeg, _ = load_decode_case(entry)
-    eligible = not entry["progressive"] and entry["restart"] == 0
+    eligible = not entry["progressive"]  # restart intervals are walked on the GPU too
     try:
         coefs, passes = lowlevel.entropy_decode_gpu_algorithm_host(jpeg)
     except N.HipJpegError as e:
-        assert e.status == 3 and not eligible  # UNSUPPORTED: progressive / restart markers keep the host entropy stage
+        assert e.status == 3 and not eligible  # UNSUPPORTED: progressive scans keep the host entropy stage
         return
     assert eligible and passes >= 1
     ref, _ = oracle.decode_coefficients(jpeg)
@@ -69,3 +69,14 @@ def test_streams_with_fill_bytes_stay_on_the_host_stage():
     a, _ = oracle.decode_coefficients(jpeg)
     b = lowlevel.entropy_decode_host(odd)[0]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("interval", [1, 2, 5, 17, 60, 1000])
+def test_restart_intervals(interval):
+    """DRI streams: markers are dropped with the byte stuffing, decoders re-synchronise exactly at every interval boundary
+    and the DC predictors start over."""
+    for (w, h, sub, q) in ((320, 240, "420", 90), (257, 129, "444", 75), (200, 120, "gray", 95), (640, 96, "422", 50)):
+        jpeg = oracle.encode(synth_image(w, h, seed=w + interval), sub, q, restart_interval=interval)
+        coefs, passes = lowlevel.entropy_decode_gpu_algorithm_host(jpeg)
+        ref, _ = oracle.decode_coefficients(jpeg)
+        assert all(np.array_equal(a, b) for a, b in zip(coefs, ref)), (w, h, sub, interval)
