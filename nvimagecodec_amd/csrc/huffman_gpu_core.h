@@ -174,6 +174,7 @@ struct BitReader {
 // Restart markers (DRI): the scan is a chain of independent intervals.  The markers themselves are removed together with the
 // byte stuffing; what is left of them is a list of BOUNDARIES, the bit positions (multiples of 8) where intervals begin.  In
 // front of a boundary the encoder has filled the last byte with one-bits.  A decoder looks at them before every symbol:
+// (at the start of a walk and whenever it has completed an MCU -- the only places where the true trajectory can meet a boundary)
 //   * it is at or past the next boundary: whatever it believed, a fresh interval starts exactly there -- position, zigzag index
 //     and MCU position are forced (for the true trajectory this changes nothing; a desynchronised one is exact from here on,
 //     so no correction chain outlives an interval);
@@ -231,18 +232,21 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
     BitReader br;
     br.start(env, pos);
     RestartCursor rc;
-    if (RST) rc.start(env, boundary0, pos);
-    while (pos < end) {
-        if (RST && rc.normalise(env, br.hi, &pos, &z, &k)) {
+    if (RST) {
+        // boundaries are looked at where the true trajectory meets them: at the start and whenever an MCU has been completed
+        rc.start(env, boundary0, pos);
+        if (rc.normalise(env, br.hi, &pos, &z, &k)) {
             tsel = env.tables(k);
             tcur = tsel & 0xFFFFu;
             br.start(env, pos);
-            if (pos >= end) break;
         }
+    }
+    while (pos < end) {
         const uint32_t fetched = env.word(br.next);
         uint32_t e = env.lookup1(tcur, br.hi);
         tcur = tsel >> 16;
         z += (int)(e >> 9);
+        bool mcu_done = false;
         if (z >= 64) {  // end of a block, or a code that continues in a second-level table
             if ((e >> 9) == kZadvLong) {
                 e = env.lookup2(e, br.hi);
@@ -254,10 +258,16 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
                 if (++k == bpm) k = 0;
                 tsel = env.tables(k);
                 tcur = tsel & 0xFFFFu;
+                mcu_done = k == 0;
             }
         }
         pos += e & 31u;
         br.consume(e & 31u, fetched);
+        if (RST && mcu_done && rc.normalise(env, br.hi, &pos, &z, &k)) {
+            tsel = env.tables(k);
+            tcur = tsel & 0xFFFFu;
+            br.start(env, pos);
+        }
     }
     SubseqState st;
     st.end_bit = pos;
@@ -283,15 +293,16 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
     BitReader br;
     br.start(env, pos);
     RestartCursor rc;
-    if (RST) rc.start(env, boundary0, pos);
-    while (pos < end) {
-        if (RST && rc.normalise(env, br.hi, &pos, &z, &k)) {
+    if (RST) {
+        rc.start(env, boundary0, pos);
+        if (rc.normalise(env, br.hi, &pos, &z, &k)) {
             tsel = env.tables(k);
             tcur = tsel & 0xFFFFu;
             br.start(env, pos);
             fresh = true;
-            if (pos >= end) break;
         }
+    }
+    while (pos < end) {
         if (fresh) {
             rec(block, pos);
             fresh = false;
@@ -310,6 +321,11 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
             tsel = env.tables(k);
             tcur = tsel & 0xFFFFu;
             fresh = true;
+            if (RST && k == 0 && rc.normalise(env, br.hi, &pos, &z, &k)) {
+                tsel = env.tables(k);
+                tcur = tsel & 0xFFFFu;
+                br.start(env, pos);
+            }
         }
     }
 }
