@@ -10,7 +10,9 @@ namespace hipjpeg {
 // K1: IDCT of component blocks into u8 planes.  One WorkUnit = 256 blocks.
 int launch_idct_plane(bool exact, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K2: fused luma IDCT + chroma upsample (factors hs x vs, 0 = no chroma) + colour conversion + store.
-int launch_luma_color(bool exact, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+// flavour: which instantiation of the fused luma kernel (decode_kernels.hip luma_color_body)
+enum LumaFlavour { kLumaMul24 = 0, kLumaExact = 1, kLumaCommon = 2, kNumLumaFlavours = 3 };
+int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K3: per-pixel colour stage from planes (replication upsampling) for uncommon sampling layouts.
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // Geometry pass (region of interest + EXIF orientation): WorkUnit{image = TransformImage index, block_base = first output row}.

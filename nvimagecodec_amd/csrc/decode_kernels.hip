@@ -33,6 +33,9 @@ constexpr int kThreads = 256;
 #ifndef HJ_MIN_WAVES
 #define HJ_MIN_WAVES 4
 #endif
+#ifndef HJ_MIN_WAVES_LUMA
+#define HJ_MIN_WAVES_LUMA 5  // measured: 4 -> 1.017 ms, 5 -> 0.966 ms, 6 -> 1.18 ms (spills) per 256 x 1080p, generic flavour
+#endif
 constexpr int kBlocksPerWave = 32;     // two lanes per block
 constexpr int kLdsBlockStride = 144;   // 128 B of coefficients + 16 B pad -> conflict-free ds_read_b128 at this lane stride
 
@@ -112,6 +115,29 @@ __device__ __forceinline__ int range_limit(int v)
 {
     int s = __builtin_amdgcn_sbfe(v, 0, 10);
     return clamp255(s + 128);
+}
+
+
+// ---- two int16 per register (colour stage)
+using i16x2 = __attribute__((ext_vector_type(2))) short;
+__device__ __forceinline__ unsigned lo_pair(int a, int b) { return __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x05040100u); }  // a[15:0] | b[15:0] << 16
+__device__ __forceinline__ unsigned hi_pair(int a, int b) { return __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x07060302u); }  // a[31:16] | b[31:16] << 16
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) + __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned clamp_s8_pair(unsigned a)
+{
+    const i16x2 lo = {-128, -128}, hi = {127, 127};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, a), lo), hi));
+}
+// four int16 (two registers) -> four bytes, each saturated to 0..255: a.lo a.hi b.lo b.hi
+__device__ __forceinline__ unsigned sat_pk4(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(a));
+    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r) : "v"(b));
+    return r;
 }
 
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) { return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24); }
@@ -304,23 +330,23 @@ __device__ __forceinline__ void upsample_row(uint2 near, uint2 far, bool odd_row
     if constexpr (HS == 2) {
         // window byte j <-> chroma column (4*bx - 1 + j); output pixel 2i+e sits over window column i+1
         if (fancy) {
-            int cs[6];
-            if constexpr (VS == 2) {
+            // jdsample.c h2v2_fancy_upsample / h2v1_fancy_upsample: vertical (3,1) then horizontal (3,1) triangle filters.
+            // Both passes of one output pixel are ONE v_dot4_u32_u8 over the bytes [n_j, n_j+1, f_j, f_j+1] (n = near row,
+            // f = far row, j = window column) with weights (3,9,1,3) for the left pixel of column j+1 and (9,3,3,1) for the
+            // right pixel of column j; libjpeg's rounding terms (8 / 7, h2v1: 1 / 2) ride in the accumulator operand.
+            const unsigned q0 = __builtin_amdgcn_perm(far.x, near.x, 0x05040100u);  // n0 n1 f0 f1
+            const unsigned q2 = __builtin_amdgcn_perm(far.x, near.x, 0x07060302u);  // n2 n3 f2 f3
+            const unsigned q4 = __builtin_amdgcn_perm(far.y, near.y, 0x05040100u);  // n4 n5 f4 f5
+            const unsigned q1 = __builtin_amdgcn_perm(q2, q0, 0x06030401u);         // n1 n2 f1 f2
+            const unsigned q3 = __builtin_amdgcn_perm(q4, q2, 0x06030401u);         // n3 n4 f3 f4
+            const unsigned qq[5] = {q0, q1, q2, q3, q4};
+            constexpr unsigned w_left = VS == 2 ? 0x03010903u : 0x00000301u, w_right = VS == 2 ? 0x01030309u : 0x00000103u;
+            constexpr unsigned r_left = VS == 2 ? 8 : 1, r_right = VS == 2 ? 7 : 2;
+            constexpr int sh = VS == 2 ? 4 : 2;
 #pragma unroll
-                for (int j = 0; j < 6; j++) cs[j] = 3 * byte_of(near, j) + byte_of(far, j);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    o[2 * i] = (3 * cs[i + 1] + cs[i] + 8) >> 4;
-                    o[2 * i + 1] = (3 * cs[i + 1] + cs[i + 2] + 7) >> 4;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 6; j++) cs[j] = byte_of(near, j);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    o[2 * i] = (3 * cs[i + 1] + cs[i] + 1) >> 2;
-                    o[2 * i + 1] = (3 * cs[i + 1] + cs[i + 2] + 2) >> 2;
-                }
+            for (int i = 0; i < 4; i++) {
+                o[2 * i] = (int)(__builtin_amdgcn_udot4(qq[i], w_left, r_left, false) >> sh);
+                o[2 * i + 1] = (int)(__builtin_amdgcn_udot4(qq[i + 1], w_right, r_right, false) >> sh);
             }
         } else {
 #pragma unroll
@@ -343,7 +369,11 @@ __device__ __forceinline__ void upsample_row(uint2 near, uint2 far, bool odd_row
 constexpr int kOutRowBytes = kBlocksPerWave * 24 + 16;  // one pixel row of a wave's 32 blocks (interleaved RGB) + bank-skew pad
 constexpr int kLdsLumaWaveBytes = 8 * kOutRowBytes;     // 6,272 B: first the coefficient staging (4,608 B), then the RGB tile
 
-template <bool EXACT, int HS, int VS>
+//   COMMON = the configuration nearly every caller uses, fixed at compile time: YCbCr source, interleaved RGB output whose
+//   rows are 16-byte aligned, libjpeg's default fancy upsampling.  Same arithmetic, but no wave-uniform format branches and
+//   ~20 fewer live registers (85 instead of 104 VGPRs: five waves per SIMD without spills).  The host picks the kernel per
+//   image (DecodeBatch::finalize).
+template <bool EXACT, int HS, int VS, bool COMMON>
 __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,13 +391,13 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     const bool valid = bx < bw && by < bh && x0 < W && y0 < H;  // false: pair idles (block is MCU padding or outside the tile)
 
     const int fmt = im.out_format;
-    const bool planar = fmt == kOutPlanarRGB || fmt == kOutPlanarBGR;
-    const bool bgr = fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR;
-    const bool ycc = im.color_model == 1;
+    const bool planar = !COMMON && (fmt == kOutPlanarRGB || fmt == kOutPlanarBGR);
+    const bool bgr = !COMMON && (fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR);
+    const bool ycc = COMMON || im.color_model == 1;
     const bool full = x0 + 8 <= W;
     // Interleaved output whose rows are 16-byte aligned goes through an LDS tile so that the wave emits 16 B per lane,
     // fully coalesced, instead of 24-byte-strided 8-byte stores.
-    const bool staged = !planar && ((((uintptr_t)im.out[0]) | im.out_pitch[0]) & 15) == 0;
+    const bool staged = COMMON || (!planar && ((((uintptr_t)im.out[0]) | im.out_pitch[0]) & 15) == 0);
 
     if (valid) {
         // chroma window rows for this lane's four image rows (issued before the IDCT so the loads fly while we compute)
@@ -377,7 +407,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
         if constexpr (HS != 0) {
             const int dw = im.comp[1].samp_w, dh = im.comp[1].samp_h;
             // libjpeg picks the triangle filters only when do_fancy_upsampling and (for h2v1/h2v2) downsampled_width > 2
-            fancy = (im.flags & kFlagFancyUpsampling) && (HS == 1 || dw > 2);
+            fancy = COMMON || ((im.flags & kFlagFancyUpsampling) && (HS == 1 || dw > 2));
             const int wx = HS == 2 ? 4 * bx - 1 : 8 * bx;
             // VS == 2: image rows 0..3 need chroma rows 4by-1 .. 4by+2, rows 4..7 need 4by+1 .. 4by+4;  VS == 1: rows map 1:1
             const int first = VS == 2 ? 4 * by - 1 + (p ? 2 : 0) : 8 * by + (p ? 4 : 0);
@@ -388,54 +418,103 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
         int rows[4][8];
         column_pass_and_exchange<EXACT>(cols, EXACT ? im.comp[0].qpair_exact[p] : im.comp[0].qpair[p], p, rows);
         // additive constants of the colour conversion (kept in VGPRs: a VOP3 instruction reads one scalar operand at most)
-        const int kr = 32768 - 128 * 91881, kb = 32768 - 128 * 116130, kg = 32768 + 128 * 22554 + 128 * 46802;
+        // (+ 128 << 16: the luma offset, see the packed colour stage below)
+        const int kr = 32768 - 128 * 91881 + (128 << 16), kb = 32768 - 128 * 116130 + (128 << 16), kg = 32768 + 128 * 22554 + 128 * 46802 + (128 << 16);
 
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             idct8<false, 18>(rows[i]);
             const int r = p ? 7 - i : i;  // image row inside the block
             if (y0 + r >= H) continue;
-            int R[8], G[8], B[8];
-            if constexpr (HS == 0) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) R[c] = G[c] = B[c] = range_limit(rows[i][c]);
-            } else {
-                int cb[8], cr[8];
-                // local window-row indices are the same for both lanes (lane 1's window is loaded upside down):
-                //   VS == 2:  i = 0: near 1 far 0 | 1: near 1 far 2 | 2: near 2 far 1 | 3: near 2 far 3      VS == 1: row i
-                constexpr int kNear[4] = {1, 1, 2, 2}, kFar[4] = {0, 2, 1, 3};
-                const int near = VS == 2 ? kNear[i] : i, far = VS == 2 ? kFar[i] : i;
-                const bool odd_row = (i & 1) != (int)p;  // r = i or 7 - i
-                upsample_row<HS, VS>(cbw[near], cbw[far], odd_row, fancy, cb);
-                upsample_row<HS, VS>(crw[near], crw[far], odd_row, fancy, cr);
+            // q: the row's 24 output bytes (interleaved), or q[2k], q[2k+1] = the eight bytes of output plane k (planar)
+            unsigned q[6];
+            bool packed_done = false;
+            if constexpr (HS != 0) {
                 if (ycc) {
-                    // jdcolor.c ycc_rgb_convert with SCALEBITS = 16; (x - 128) folded into the additive constants
+                    packed_done = true;
+                    int cb[8], cr[8];
+                    // local window-row indices are the same for both lanes (lane 1's window is loaded upside down):
+                    //   VS == 2:  i = 0: near 1 far 0 | 1: near 1 far 2 | 2: near 2 far 1 | 3: near 2 far 3      VS == 1: row i
+                    constexpr int kNear[4] = {1, 1, 2, 2}, kFar[4] = {0, 2, 1, 3};
+                    const int near = VS == 2 ? kNear[i] : i, far = VS == 2 ? kFar[i] : i;
+                    const bool odd_row = (i & 1) != (int)p;  // r = i or 7 - i
+                    upsample_row<HS, VS>(cbw[near], cbw[far], odd_row, fancy, cb);
+                    upsample_row<HS, VS>(crw[near], crw[far], odd_row, fancy, cr);
+                    // jdcolor.c ycc_rgb_convert with SCALEBITS = 16, two pixels per register from here on:
+                    //   y = clamp(s + 128, 0, 255) = clamp(s, -128, 127) + 128 with s the 10-bit range-limit index, and the
+                    //   +128 as well as the (x - 128) of the chroma terms live in the additive constants, so
+                    //   bits 31..16 of one 24-bit mad ARE "chroma term + 128" as an int16 (|.| < 2^9);
+                    //   v_sat_pk_u8_i16 is the final clamp to 0..255 and the byte packing in one instruction.
+                    unsigned s0[4], s1[4], s2[4];
 #pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        const int y = range_limit(rows[i][c]);
-                        const int rr = mad24(cr[c], 91881, kr) >> 16;
-                        const int bb = mad24(cb[c], 116130, kb) >> 16;
-                        const int gg = mad24(cr[c], -46802, mad24(cb[c], -22554, kg)) >> 16;
-                        R[c] = clamp255(y + rr);
-                        G[c] = clamp255(y + gg);
-                        B[c] = clamp255(y + bb);
+                    for (int c = 0; c < 8; c += 2) {
+                        const unsigned yp = clamp_s8_pair(lo_pair(__builtin_amdgcn_sbfe(rows[i][c], 0, 10), __builtin_amdgcn_sbfe(rows[i][c + 1], 0, 10)));
+                        const unsigned tr = hi_pair(mad24(cr[c], 91881, kr), mad24(cr[c + 1], 91881, kr));
+                        const unsigned tb = hi_pair(mad24(cb[c], 116130, kb), mad24(cb[c + 1], 116130, kb));
+                        const unsigned tg = hi_pair(mad24(cr[c], -46802, mad24(cb[c], -22554, kg)), mad24(cr[c + 1], -46802, mad24(cb[c + 1], -22554, kg)));
+                        const unsigned sr = pk_add16(yp, tr), sb = pk_add16(yp, tb);
+                        s0[c >> 1] = bgr ? sb : sr;
+                        s1[c >> 1] = pk_add16(yp, tg);
+                        s2[c >> 1] = bgr ? sr : sb;
                     }
-                } else {
-                    // Adobe RGB JPEG: the three components already are R, G, B
+                    if (planar) {
+                        q[0] = sat_pk4(s0[0], s0[1]);
+                        q[1] = sat_pk4(s0[2], s0[3]);
+                        q[2] = sat_pk4(s1[0], s1[1]);
+                        q[3] = sat_pk4(s1[2], s1[3]);
+                        q[4] = sat_pk4(s2[0], s2[1]);
+                        q[5] = sat_pk4(s2[2], s2[3]);
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        R[c] = range_limit(rows[i][c]);
-                        G[c] = cb[c];
-                        B[c] = cr[c];
+                        for (int h = 0; h < 2; h++) {  // pixels 4h .. 4h+3 -> three dwords
+                            const unsigned rg01 = sat_pk4(s0[2 * h], s1[2 * h]);          // R0 R1 G0 G1
+                            const unsigned rg23 = sat_pk4(s0[2 * h + 1], s1[2 * h + 1]);  // R2 R3 G2 G3
+                            const unsigned b03 = sat_pk4(s2[2 * h], s2[2 * h + 1]);       // B0 B1 B2 B3
+                            q[3 * h] = __builtin_amdgcn_perm(b03, rg01, 0x01040200u);      // R0 G0 B0 R1
+                            const unsigned m = __builtin_amdgcn_perm(b03, rg01, 0x00000503u);  // G1 B1 . .
+                            q[3 * h + 1] = __builtin_amdgcn_perm(rg23, m, 0x06040100u);    // G1 B1 R2 G2
+                            q[3 * h + 2] = __builtin_amdgcn_perm(b03, rg23, 0x07030106u);  // B2 R3 G3 B3
+                        }
                     }
                 }
             }
-            if (bgr) {
+            if (!packed_done) {
+                int R[8], G[8], B[8];
+                if constexpr (HS == 0) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const int t = R[c];
-                    R[c] = B[c];
-                    B[c] = t;
+                    for (int c = 0; c < 8; c++) R[c] = G[c] = B[c] = range_limit(rows[i][c]);
+                } else {
+                    // Adobe RGB JPEG: the three components already are R, G, B (same window rows as above)
+                    constexpr int kNear[4] = {1, 1, 2, 2}, kFar[4] = {0, 2, 1, 3};
+                    const int near = VS == 2 ? kNear[i] : i, far = VS == 2 ? kFar[i] : i;
+                    const bool odd_row = (i & 1) != (int)p;
+                    upsample_row<HS, VS>(cbw[near], cbw[far], odd_row, fancy, G);
+                    upsample_row<HS, VS>(crw[near], crw[far], odd_row, fancy, B);
+#pragma unroll
+                    for (int c = 0; c < 8; c++) R[c] = range_limit(rows[i][c]);
+                }
+                if (bgr) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const int t = R[c];
+                        R[c] = B[c];
+                        B[c] = t;
+                    }
+                }
+                if (planar) {
+                    q[0] = pack4(R[0], R[1], R[2], R[3]);
+                    q[1] = pack4(R[4], R[5], R[6], R[7]);
+                    q[2] = pack4(G[0], G[1], G[2], G[3]);
+                    q[3] = pack4(G[4], G[5], G[6], G[7]);
+                    q[4] = pack4(B[0], B[1], B[2], B[3]);
+                    q[5] = pack4(B[4], B[5], B[6], B[7]);
+                } else {
+                    q[0] = pack4(R[0], G[0], B[0], R[1]);
+                    q[1] = pack4(G[1], B[1], R[2], G[2]);
+                    q[2] = pack4(B[2], R[3], G[3], B[3]);
+                    q[3] = pack4(R[4], G[4], B[4], R[5]);
+                    q[4] = pack4(G[5], B[5], R[6], G[6]);
+                    q[5] = pack4(B[6], R[7], G[7], B[7]);
                 }
             }
             // row offsets: (wave-uniform 64-bit part) + (per-lane 32-bit part) keeps 64-bit multiplies off the vector ALU
@@ -444,41 +523,37 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
                 uint8_t* p1 = im.out[1] + (size_t)y0 * im.out_pitch[1] + (__umul24((unsigned)r, im.out_pitch[1]) + (unsigned)x0);
                 uint8_t* p2 = im.out[2] + (size_t)y0 * im.out_pitch[2] + (__umul24((unsigned)r, im.out_pitch[2]) + (unsigned)x0);
                 if (full && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 7) == 0) {
-                    *reinterpret_cast<uint2*>(p0) = make_uint2(pack4(R[0], R[1], R[2], R[3]), pack4(R[4], R[5], R[6], R[7]));
-                    *reinterpret_cast<uint2*>(p1) = make_uint2(pack4(G[0], G[1], G[2], G[3]), pack4(G[4], G[5], G[6], G[7]));
-                    *reinterpret_cast<uint2*>(p2) = make_uint2(pack4(B[0], B[1], B[2], B[3]), pack4(B[4], B[5], B[6], B[7]));
+                    *reinterpret_cast<uint2*>(p0) = make_uint2(q[0], q[1]);
+                    *reinterpret_cast<uint2*>(p1) = make_uint2(q[2], q[3]);
+                    *reinterpret_cast<uint2*>(p2) = make_uint2(q[4], q[5]);
                 } else {
 #pragma unroll
                     for (int c = 0; c < 8; c++)
                         if (x0 + c < W) {
-                            p0[c] = (uint8_t)R[c];
-                            p1[c] = (uint8_t)G[c];
-                            p2[c] = (uint8_t)B[c];
+                            p0[c] = (uint8_t)(q[c >> 2] >> (8 * (c & 3)));
+                            p1[c] = (uint8_t)(q[2 + (c >> 2)] >> (8 * (c & 3)));
+                            p2[c] = (uint8_t)(q[4 + (c >> 2)] >> (8 * (c & 3)));
                         }
                 }
             } else {
-                const uint2 q0 = make_uint2(pack4(R[0], G[0], B[0], R[1]), pack4(G[1], B[1], R[2], G[2]));
-                const uint2 q1 = make_uint2(pack4(B[2], R[3], G[3], B[3]), pack4(R[4], G[4], B[4], R[5]));
-                const uint2 q2 = make_uint2(pack4(G[5], B[5], R[6], G[6]), pack4(B[6], R[7], G[7], B[7]));
                 if (staged) {
                     uint2* t = reinterpret_cast<uint2*>(lds_wave + r * kOutRowBytes + blk * 24);
-                    t[0] = q0;
-                    t[1] = q1;
-                    t[2] = q2;
+                    t[0] = make_uint2(q[0], q[1]);
+                    t[1] = make_uint2(q[2], q[3]);
+                    t[2] = make_uint2(q[4], q[5]);
                 } else {
                     uint8_t* o = im.out[0] + (size_t)y0 * im.out_pitch[0] + (__umul24((unsigned)r, im.out_pitch[0]) + (unsigned)x0 * 3u);
                     if (full && ((uintptr_t)o & 7) == 0) {
-                        uint2* q = reinterpret_cast<uint2*>(o);
-                        q[0] = q0;
-                        q[1] = q1;
-                        q[2] = q2;
+                        uint2* t = reinterpret_cast<uint2*>(o);
+                        t[0] = make_uint2(q[0], q[1]);
+                        t[1] = make_uint2(q[2], q[3]);
+                        t[2] = make_uint2(q[4], q[5]);
                     } else {
 #pragma unroll
                         for (int c = 0; c < 8; c++)
                             if (x0 + c < W) {
-                                o[3 * c] = (uint8_t)R[c];
-                                o[3 * c + 1] = (uint8_t)G[c];
-                                o[3 * c + 2] = (uint8_t)B[c];
+#pragma unroll
+                                for (int k = 0; k < 3; k++) o[3 * c + k] = (uint8_t)(q[(3 * c + k) >> 2] >> (8 * ((3 * c + k) & 3)));
                             }
                     }
                 }
@@ -512,12 +587,12 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     }
 }
 
-template <bool EXACT, int HS, int VS>
-__global__ __launch_bounds__(kThreads, HJ_MIN_WAVES) void luma_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
+template <bool EXACT, int HS, int VS, bool COMMON>
+__global__ __launch_bounds__(kThreads, HJ_MIN_WAVES_LUMA) void luma_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
     __shared__ __attribute__((aligned(16))) char lds[4 * kLdsLumaWaveBytes];
     const WorkUnit u = units[blockIdx.x];
-    luma_color_body<EXACT, HS, VS>(images[u.image], u, lds);
+    luma_color_body<EXACT, HS, VS, COMMON>(images[u.image], u, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -633,29 +708,33 @@ int launch_idct_plane(bool exact, const DecodeImage* images, const WorkUnit* uni
     return (int)hipGetLastError();
 }
 
-template <bool EXACT>
+template <bool EXACT, bool COMMON>
 static int launch_luma_color_t(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, hipStream_t s)
 {
-    if (hs == 0)
-        hipLaunchKernelGGL((luma_color_kernel<EXACT, 0, 0>), dim3(nunits), dim3(kThreads), 0, s, images, units);
-    else if (hs == 1 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<EXACT, 1, 1>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+    if (hs == 0) {
+        if constexpr (COMMON) return (int)hipErrorInvalidValue;  // gray sources have no colour conversion to specialise
+        else hipLaunchKernelGGL((luma_color_kernel<EXACT, 0, 0, false>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+    } else if (hs == 1 && vs == 1)
+        hipLaunchKernelGGL((luma_color_kernel<EXACT, 1, 1, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<EXACT, 2, 1>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<EXACT, 2, 1, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<EXACT, 2, 2>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<EXACT, 2, 2, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 1 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<EXACT, 1, 2>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<EXACT, 1, 2, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else
         return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
 
-int launch_luma_color(bool exact, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
 {
     if (nunits <= 0) return 0;
-    return exact ? launch_luma_color_t<true>(hs, vs, images, units, nunits, (hipStream_t)stream)
-                 : launch_luma_color_t<false>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    switch (flavour) {
+    case kLumaExact: return launch_luma_color_t<true, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case kLumaCommon: return launch_luma_color_t<false, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    default: return launch_luma_color_t<false, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    }
 }
 
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)

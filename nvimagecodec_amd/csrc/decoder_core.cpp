@@ -493,10 +493,9 @@ void DecodeBatch::entropy_stage(int i)
 void DecodeBatch::finalize(hipjpegStatus_t* statuses)
 {
     generic_units_.clear();
-    for (int e = 0; e < 2; e++) {
-        plane_units_[e].clear();
+    for (int e = 0; e < 2; e++) plane_units_[e].clear();
+    for (int e = 0; e < kNumLumaFlavours; e++)
         for (auto& v : luma_units_[e]) v.clear();
-    }
     const int n = (int)images_.size();
     for (int i = 0; i < n; i++) {
         PlannedImage& im = images_[i];
@@ -531,9 +530,14 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
                 first_col = (uint32_t)im.transform.x0 / 8 / kLumaTileW * kLumaTileW;
                 end_col = std::min(end_col, (uint32_t)(im.transform.x1 + 7) / 8);
             }
+            // the everyday configuration has a kernel of its own (decode_kernels.hip, COMMON)
+            const bool common = !exact32 && im.variant != kVarGray && d.color_model == 1 && fmt == kOutInterleavedRGB &&
+                                ((((uintptr_t)d.out[0]) | d.out_pitch[0]) & 15) == 0 && (d.flags & kFlagFancyUpsampling) &&
+                                (im.variant == kVar11 || im.variant == kVar12 || d.comp[1].samp_w > 2);
+            const int flavour = exact32 ? kLumaExact : common ? kLumaCommon : kLumaMul24;
             for (uint32_t by = first_row; by < real_rows; by += kLumaTileH)
                 for (uint32_t bx = first_col; bx < end_col; bx += kLumaTileW)
-                    luma_units_[exact32][im.variant].push_back(WorkUnit{(uint32_t)i, bx, by, 0u});
+                    luma_units_[flavour][im.variant].push_back(WorkUnit{(uint32_t)i, bx, by, 0u});
         } else if (im.variant == -1) {
             for (int y = 0; y < f.height; y++) generic_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});
         }
@@ -547,10 +551,9 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         if (!v.empty()) memcpy(base + off, v.data(), v.size() * sizeof(WorkUnit));
         off += v.size() * sizeof(WorkUnit);
     };
-    for (int e = 0; e < 2; e++) {
-        put(plane_units_[e], &unit_off_plane_[e]);
+    for (int e = 0; e < 2; e++) put(plane_units_[e], &unit_off_plane_[e]);
+    for (int e = 0; e < kNumLumaFlavours; e++)
         for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[e][k], &unit_off_luma_[e][k]);
-    }
     put(generic_units_, &unit_off_generic_);
     // geometry pass
     xform_units_.clear();
@@ -801,9 +804,9 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
         rc = launch_idct_plane(e == 1, dimg, units_at(unit_off_plane_[e]), (int)plane_units_[e].size(), stream);
         check("idct_plane", (int)plane_units_[e].size());
     }
-    for (int e = 0; e < 2; e++)
+    for (int e = 0; e < kNumLumaFlavours; e++)
         for (int k = 0; k < kNumLumaVariants && rc == 0 && (which < 0 || which == 1); k++) {
-            rc = launch_luma_color(e == 1, hs[k], vs[k], dimg, units_at(unit_off_luma_[e][k]), (int)luma_units_[e][k].size(), stream);
+            rc = launch_luma_color(e, hs[k], vs[k], dimg, units_at(unit_off_luma_[e][k]), (int)luma_units_[e][k].size(), stream);
             check("luma_color", (int)luma_units_[e][k].size());
         }
     if (rc == 0 && (which < 0 || which == 2)) {
@@ -821,9 +824,6 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
 hipjpegStatus_t DecodeBatch::launch(void* stream, int which, void* entropy_stream)
 {
     if (!finalized_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    const DecodeImage* dimg = reinterpret_cast<const DecodeImage*>(device_.data() + desc_offset_);
-    auto units_at = [&](size_t off) { return reinterpret_cast<const WorkUnit*>(device_.data() + off); };
-    static const int hs[kNumLumaVariants] = {0, 1, 2, 2, 1}, vs[kNumLumaVariants] = {0, 1, 1, 2, 2};
     // HIPJPEG_DEBUG_SYNC=1: synchronise after every launch and report which kernel failed (debug aid only)
     static const bool debug_sync = getenv("HIPJPEG_DEBUG_SYNC") != nullptr;
     auto check = [&](const char* what, int n) {
@@ -886,7 +886,7 @@ void DecodeBatch::stats(int32_t num_units[3], uint64_t* coef_bytes, uint64_t* ou
     if (num_units) {
         num_units[0] = (int32_t)(plane_units_[0].size() + plane_units_[1].size());
         num_units[1] = 0;
-        for (int e = 0; e < 2; e++)
+        for (int e = 0; e < kNumLumaFlavours; e++)
             for (const auto& v : luma_units_[e]) num_units[1] += (int32_t)v.size();
         num_units[2] = (int32_t)generic_units_.size();
     }

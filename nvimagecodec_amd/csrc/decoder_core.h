@@ -120,9 +120,9 @@ private:
     std::vector<PlannedImage> images_;
     std::vector<DecodeImage> desc_;  // host copy (device pointers inside)
     // index [0] = 24-bit multiplier kernels, [1] = exact 32-bit multiplier kernels
-    std::vector<WorkUnit> plane_units_[2], luma_units_[2][kNumLumaVariants], generic_units_;
+    std::vector<WorkUnit> plane_units_[2], luma_units_[3][kNumLumaVariants], generic_units_;  // luma: [LumaFlavour]
     size_t desc_offset_ = 0, units_offset_ = 0, coef_offset_ = 0, staging_bytes_ = 0, plane_bytes_ = 0;
-    size_t unit_off_plane_[2] = {0, 0}, unit_off_luma_[2][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0;
+    size_t unit_off_plane_[2] = {0, 0}, unit_off_luma_[3][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0;
     uint64_t coef_bytes_ = 0, output_bytes_ = 0;
     bool finalized_ = false;
     // ---- GPU entropy stage

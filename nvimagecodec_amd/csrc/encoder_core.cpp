@@ -234,11 +234,9 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
     if ((st = henc_dev_.reserve(dev1 + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     // pinned staging: phase-1 upload | totals | phase-2 upload (descriptors again, chunk units, headers) | lengths, offsets
     std::vector<std::vector<uint8_t>> headers(ng);
-    size_t header_total = 0;
     for (int g = 0; g < ng; g++) {
         const PlannedEncode& im = images_[idx[g]];
         write_standard_headers(im.geom, im.qlum, im.qchr, &headers[g]);
-        header_total += align_up(headers[g].size(), 16);
     }
     const size_t p_totals = up1;
     const size_t p_up2 = align_up(p_totals + (size_t)ng * 4, 256);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev tool: rebuild the decode kernels with different occupancy targets and time the device stage
 cd $GRAFT_REPO_ROOT
-for w in 2 3 4; do
+for w in 5 6; do
   rm -f nvimagecodec_amd/csrc/build/decode_kernels.o
   make -C nvimagecodec_amd/csrc -j8 EXTRA_FLAGS="-DHJ_MIN_WAVES=$w" > /dev/null 2>&1
   echo "== min waves/SIMD $w"
