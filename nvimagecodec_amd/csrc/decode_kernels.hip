@@ -255,16 +255,20 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
         idct8<false, 18>(rows[i]);
         const int r = p ? 7 - i : i;
         if (y0 + r < lim_h) {
-            int px[8];
+            // range limit (jdmaster.c table as arithmetic, see range_limit) on int16 pairs: + 128, then v_sat_pk_u8_i16 clamps
+            // to 0..255 and packs the bytes
+            unsigned pr[4];
 #pragma unroll
-            for (int c = 0; c < 8; c++) px[c] = range_limit(rows[i][c]);
+            for (int c = 0; c < 8; c += 2)
+                pr[c >> 1] = pk_add16(lo_pair(__builtin_amdgcn_sbfe(rows[i][c], 0, 10), __builtin_amdgcn_sbfe(rows[i][c + 1], 0, 10)), 0x00800080u);
+            const uint2 px = make_uint2(sat_pk4(pr[0], pr[1]), sat_pk4(pr[2], pr[3]));
             uint8_t* qd = base + __umul24((unsigned)r, pitch);
             if (fast) {
-                *reinterpret_cast<uint2*>(qd) = make_uint2(pack4(px[0], px[1], px[2], px[3]), pack4(px[4], px[5], px[6], px[7]));
+                *reinterpret_cast<uint2*>(qd) = px;
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; c++)
-                    if (x0 + c < lim_w) qd[c] = (uint8_t)px[c];
+                    if (x0 + c < lim_w) qd[c] = (uint8_t)((c < 4 ? px.x : px.y) >> (8 * (c & 3)));
             }
         }
     }
