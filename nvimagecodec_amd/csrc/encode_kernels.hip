@@ -26,6 +26,7 @@ constexpr int kTileBX = 32, kTileBY = 8;  // luma blocks per workgroup tile
 constexpr int kLdsBlockStride = 144;      // 128 B block + 16 B pad (same conflict-free stride as the decoder)
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 
 constexpr int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633;
 constexpr int F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
@@ -291,12 +292,351 @@ __global__ __launch_bounds__(kThreads) void forward_kernel(const EncodeImage* __
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// forward_pair_kernel: the same arithmetic with TWO LANES per 8x8 block (the decoder's mapping, decode_kernels.hip) for the
+// inputs nearly every caller has: interleaved RGB/BGR, three components, 4:2:0 / 4:2:2 / 4:4:4.  The one-lane-per-block
+// kernel above holds a whole block in registers (240 VGPRs, two waves per SIMD) and stays for every other layout.
+//   lane p of a pair loads and colour-converts four pixel rows of the block -- lane 0 rows 0,1,2,3, lane 1 rows 7,6,5,4 --
+//   downsamples its chroma patch into the LDS chroma tile, runs the FDCT row pass on its four rows and leaves them in the
+//   block's LDS slot as int16; after the hand-off it reads columns 4p..4p+3 of all eight rows back, lane 1 from the bottom
+//   row up: reversing the input of the 1-D FDCT leaves the even outputs alone and negates the odd part's inputs, so lane 1
+//   runs the very same butterfly with the nine odd-part multipliers negated (registers, set up once) -- no lane-dependent
+//   selects anywhere.  Quantized coefficients go back into the slot in natural order; the wave's copy-out gathers them in
+//   zigzag order (each lane always fetches the same eight positions) and stores 16 bytes per lane, fully coalesced.
+// ------------------------------------------------------------------------------------------------
+struct OddPart {
+    int f0298, f2053, f3072, f1501, n0899, n2562, n1961, n0390, f1175;
+};
+
+__device__ __forceinline__ int mul24v(int a, int b)
+{
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// jfdctint.c column pass (final descale) with the odd part's multipliers in registers
+__device__ __forceinline__ void fdct8_columns(int (&d)[8], const OddPart& k)
+{
+    int t0 = d[0] + d[7], t7 = d[0] - d[7];
+    int t1 = d[1] + d[6], t6 = d[1] - d[6];
+    int t2 = d[2] + d[5], t5 = d[2] - d[5];
+    int t3 = d[3] + d[4], t4 = d[3] - d[4];
+    int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    d[0] = descale(t10 + t11, 2);
+    d[4] = descale(t10 - t11, 2);
+    int z1 = __mul24(t12 + t13, F_0_541);
+    d[2] = descale(z1 + __mul24(t13, F_0_765), 15);
+    d[6] = descale(z1 + __mul24(t12, -F_1_847), 15);
+    z1 = t4 + t7;
+    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+    int z5 = mul24v(z3 + z4, k.f1175);
+    t4 = mul24v(t4, k.f0298);
+    t5 = mul24v(t5, k.f2053);
+    t6 = mul24v(t6, k.f3072);
+    t7 = mul24v(t7, k.f1501);
+    z1 = mul24v(z1, k.n0899);
+    z2 = mul24v(z2, k.n2562);
+    z3 = mul24v(z3, k.n1961) + z5;
+    z4 = mul24v(z4, k.n0390) + z5;
+    d[7] = descale(t4 + z1 + z3, 15);
+    d[5] = descale(t5 + z2 + z4, 15);
+    d[3] = descale(t6 + z2 + z3, 15);
+    d[1] = descale(t7 + z1 + z4, 15);
+}
+
+__device__ __forceinline__ void pair_lds_fence()
+{
+    // LDS operations of one wave execute in order; only the compiler has to be kept from reordering across the hand-off
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ unsigned pack16(int a, int b) { return __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x05040100u); }  // a[15:0] | b[15:0] << 16
+
+using lds_char = __attribute__((address_space(3))) char;
+
+// FDCT row pass of one block row (level-shifted samples) and hand-off: the row goes into the block's LDS slot as int16.
+__device__ __forceinline__ void row_pass_store(int (&s)[8], lds_char* slot, int row)
+{
+    fdct8<true>(s);
+    const u32x4 v = {pack16(s[0], s[1]), pack16(s[2], s[3]), pack16(s[4], s[5]), pack16(s[6], s[7])};
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(slot + row * 16) = v;
+}
+
+// After every row of the block is in the slot: column pass of columns 4p..4p+3 (lane 1 bottom row first, see above),
+// quantization, and the quantized coefficients back into the slot in natural order (int16).  The caller fences afterwards.
+// qmagic / qhalf16: natural-order tables in LDS (half16 = half << 4).
+__device__ __forceinline__ void column_pass_quantize(lds_char* slot, bool p, const OddPart& odd, const __attribute__((address_space(3))) unsigned* qmagic,
+                                                     const __attribute__((address_space(3))) unsigned* qhalf16)
+{
+    using lds_u32x2 = __attribute__((address_space(3))) u32x2;
+    using lds_u32x4 = __attribute__((address_space(3))) u32x4;
+    pair_lds_fence();
+    u32x2 rd[8];
+    lds_char* mine = slot + (p ? 7 * 16 + 8 : 0);
+    const int step = p ? -16 : 16;
+#pragma unroll
+    for (int n = 0; n < 8; n++) rd[n] = *reinterpret_cast<const lds_u32x2*>(mine + n * step);
+    pair_lds_fence();  // the partner has read too before anything below overwrites the slot (same wave: program order)
+    int col[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            const unsigned w = (j < 2) ? rd[n].x : rd[n].y;
+            col[j][n] = (j & 1) ? ((int)w >> 16) : (int)(short)(w & 0xFFFF);
+        }
+        fdct8_columns(col[j], odd);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // jcdctmgr.c quantize: divisor 8*q, round half away from zero (see fdct_quantize above)
+        const u32x4 qm = *reinterpret_cast<const lds_u32x4*>(qmagic + k * 8 + (p ? 4 : 0));
+        const u32x4 qh = *reinterpret_cast<const lds_u32x4*>(qhalf16 + k * 8 + (p ? 4 : 0));
+        const unsigned m4[4] = {qm.x, qm.y, qm.z, qm.w}, h4[4] = {qh.x, qh.y, qh.z, qh.w};
+        int r[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int v = col[j][k];
+            const int sgn = v >> 31;
+            const unsigned a16 = (((unsigned)((v ^ sgn) - sgn)) << 4) + h4[j];
+            const int m = (int)__umulhi(a16, m4[j]);
+            r[j] = (m ^ sgn) - sgn;
+        }
+        *reinterpret_cast<lds_u32x2*>(slot + k * 16 + (p ? 8 : 0)) = u32x2{pack16(r[0], r[1]), pack16(r[2], r[3])};
+    }
+}
+
+// byte offsets (inside a natural-order int16 block) of the eight coefficients that make up 16-byte piece `piece` of the
+// zigzag-ordered block
+__device__ const unsigned short kZigzagPieceOffsets[8][8] = {
+    {0, 2, 16, 32, 18, 4, 6, 20},       {34, 48, 64, 50, 36, 22, 8, 10},    {24, 38, 52, 66, 80, 96, 82, 68},
+    {54, 40, 26, 12, 14, 28, 42, 56},   {70, 84, 98, 112, 114, 100, 86, 72}, {58, 44, 30, 46, 60, 74, 88, 102},
+    {116, 118, 104, 90, 76, 62, 78, 92}, {106, 120, 122, 108, 94, 110, 124, 126}};
+
+// gathers piece (lane & 7) of block slot `slot` in zigzag order; off = the piece's eight byte offsets, two per register
+__device__ __forceinline__ u32x4 gather_zigzag_piece(const lds_char* slot, const uint4& off)
+{
+    using lds_u16 = __attribute__((address_space(3))) unsigned short;
+    const unsigned o[4] = {off.x, off.y, off.z, off.w};
+    unsigned h[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) h[t] = *reinterpret_cast<const lds_u16*>(slot + ((t & 1) ? (o[t >> 1] >> 16) : (o[t >> 1] & 0xFFFF)));
+    return u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+}
+
+constexpr int kPairSlotStride = 144;  // 128 B block + 16 B pad
+
+template <int HS, int VS>
+__global__ __launch_bounds__(kThreads, 4) void forward_pair_kernel(const EncodeImage* __restrict__ images, const EncodeUnit* __restrict__ units)
+{
+    constexpr int kChromaW = kTileBX * 8 / HS, kChromaH = kTileBY * 8 / VS;  // downsampled chroma tile
+    __shared__ __attribute__((aligned(16))) char lds_slots[4 * 32 * kPairSlotStride];             // 18,432 B
+    __shared__ __attribute__((aligned(16))) unsigned lds_quant[4][64];                             // luma magic, half16, chroma magic, half16
+    __shared__ __attribute__((aligned(16))) unsigned char lds_chroma[2][kChromaH][kChromaW + 16];  // 4:2:0: 9,216 B ... 4:4:4: 34,816 B
+
+    const EncodeUnit u = units[blockIdx.x];
+    const EncodeImage& im = images[u.image];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool p = lane & 1;
+    const int blk = lane >> 1;
+    const int W = im.width, H = im.height;
+    {
+        const int t = tid >> 6, k = tid & 63;
+        lds_quant[t][k] = (t & 1) ? im.qnat[t >> 1].half16[k] : im.qnat[t >> 1].magic[k];
+    }
+    OddPart odd;
+    {
+        const int sg = p ? -1 : 1;
+        odd.f0298 = sg * F_0_298;
+        odd.f2053 = sg * F_2_053;
+        odd.f3072 = sg * F_3_072;
+        odd.f1501 = sg * F_1_501;
+        odd.n0899 = sg * -F_0_899;
+        odd.n2562 = sg * -F_2_562;
+        odd.n1961 = sg * -F_1_961;
+        odd.n0390 = sg * -F_0_390;
+        odd.f1175 = sg * F_1_175;
+    }
+    const uint4 zoff = *reinterpret_cast<const uint4*>(&kZigzagPieceOffsets[lane & 7][0]);
+    // colour weights: for BGR input the first and third byte swap roles -- wave-uniform scalars, no per-pixel work
+    const bool bgr = im.in_format == kInInterleavedBGR;
+    const int y0w = bgr ? 7471 : 19595, y2w = bgr ? 19595 : 7471;
+    const int cb0w = bgr ? 32768 : -11059, cb2w = bgr ? -11059 : 32768;
+    const int cr0w = bgr ? -5329 : 32768, cr2w = bgr ? 32768 : -5329;
+    const int kyc = 32768 - (128 << 16);  // + ONE_HALF, level shift folded in
+    const int kcc = (128 << 16) + 32767;  // CBCR_OFFSET + ONE_HALF - 1
+    __syncthreads();  // quant tables
+
+    lds_char* wave_slots = (lds_char*)lds_slots + wave * 32 * kPairSlotStride;
+    lds_char* slot = wave_slots + blk * kPairSlotStride;
+    const auto* qtab = (const __attribute__((address_space(3))) unsigned*)&lds_quant[0][0];
+    const unsigned char* in0 = im.in[0];
+    const unsigned pitch = im.in_pitch[0];
+
+    // ---- phase A: wave w takes block rows 2w and 2w+1 of the tile, 32 blocks each
+#pragma unroll 1
+    for (int it = 0; it < 2; it++) {
+        const int lby = wave * 2 + it;
+        const int bx = u.tile_bx * kTileBX + blk, by = u.tile_by * kTileBY + lby;
+        const int x0 = bx * 8, y0 = by * 8;
+        const bool interior = x0 + 8 <= W;
+        // the lane's four pixel rows (24 bytes each), loads first
+        unsigned w[4][6];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = p ? 7 - i : i;
+            const int y = min(y0 + r, H - 1);  // rows past the image replicate the last row (jcprepct.c expand_bottom_edge)
+            const unsigned char* rowp = in0 + (size_t)y * pitch;
+            if (interior) {
+                const u32x2* v = reinterpret_cast<const u32x2*>(rowp + (size_t)x0 * 3);
+                const u32x2 a = __builtin_nontemporal_load(v), b = __builtin_nontemporal_load(v + 1), c = __builtin_nontemporal_load(v + 2);
+                w[i][0] = a.x; w[i][1] = a.y; w[i][2] = b.x; w[i][3] = b.y; w[i][4] = c.x; w[i][5] = c.y;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; k++) w[i][k] = 0;
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int x = min(x0 + c, W - 1);  // columns past the image replicate the last pixel (expand_right_edge)
+#pragma unroll
+                    for (int t = 0; t < 3; t++) w[i][(3 * c + t) >> 2] |= (unsigned)rowp[3 * x + t] << (8 * ((3 * c + t) & 3));
+                }
+            }
+        }
+        int cbs[4], crs[4];  // 4:2:0: horizontal pair sums of the previous row
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = p ? 7 - i : i;
+            int yrow[8], cb[8], cr[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int c0 = (int)((w[i][(3 * c) >> 2] >> (8 * ((3 * c) & 3))) & 0xFF);
+                const int c1 = (int)((w[i][(3 * c + 1) >> 2] >> (8 * ((3 * c + 1) & 3))) & 0xFF);
+                const int c2 = (int)((w[i][(3 * c + 2) >> 2] >> (8 * ((3 * c + 2) & 3))) & 0xFF);
+                // jccolor.c rgb_ycc_convert, SCALEBITS 16
+                yrow[c] = (__mul24(c0, y0w) + __mul24(c1, 38470) + __mul24(c2, y2w) + kyc) >> 16;
+                cb[c] = (__mul24(c0, cb0w) + __mul24(c1, -21709) + __mul24(c2, cb2w) + kcc) >> 16;
+                cr[c] = (__mul24(c0, cr0w) + __mul24(c1, -27439) + __mul24(c2, cr2w) + kcc) >> 16;
+            }
+            row_pass_store(yrow, slot, r);
+            // chroma into the (downsampled) LDS tile: jcsample.c h2v2_downsample (bias 1,2,1,2), h2v1_downsample (bias 0,1,0,1),
+            // fullsize_downsample
+            using lds_u32 = __attribute__((address_space(3))) unsigned;
+            using lds_u32x2 = __attribute__((address_space(3))) u32x2;
+            if constexpr (HS == 2 && VS == 2) {
+                if (i & 1) {
+                    unsigned o0 = 0, o1 = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        o0 |= (unsigned)((cbs[c] + cb[2 * c] + cb[2 * c + 1] + 1 + (c & 1)) >> 2) << (8 * c);
+                        o1 |= (unsigned)((crs[c] + cr[2 * c] + cr[2 * c + 1] + 1 + (c & 1)) >> 2) << (8 * c);
+                    }
+                    const int crow = lby * 4 + (p ? 3 - (i >> 1) : (i >> 1));
+                    *(lds_u32*)&lds_chroma[0][crow][blk * 4] = o0;
+                    *(lds_u32*)&lds_chroma[1][crow][blk * 4] = o1;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        cbs[c] = cb[2 * c] + cb[2 * c + 1];
+                        crs[c] = cr[2 * c] + cr[2 * c + 1];
+                    }
+                }
+            } else if constexpr (HS == 2 && VS == 1) {
+                unsigned o0 = 0, o1 = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    o0 |= (unsigned)((cb[2 * c] + cb[2 * c + 1] + (c & 1)) >> 1) << (8 * c);
+                    o1 |= (unsigned)((cr[2 * c] + cr[2 * c + 1] + (c & 1)) >> 1) << (8 * c);
+                }
+                *(lds_u32*)&lds_chroma[0][lby * 8 + r][blk * 4] = o0;
+                *(lds_u32*)&lds_chroma[1][lby * 8 + r][blk * 4] = o1;
+            } else {
+                *(lds_u32x2*)&lds_chroma[0][lby * 8 + r][blk * 8] =
+                    u32x2{(unsigned)cb[0] | (cb[1] << 8) | (cb[2] << 16) | ((unsigned)cb[3] << 24), (unsigned)cb[4] | (cb[5] << 8) | (cb[6] << 16) | ((unsigned)cb[7] << 24)};
+                *(lds_u32x2*)&lds_chroma[1][lby * 8 + r][blk * 8] =
+                    u32x2{(unsigned)cr[0] | (cr[1] << 8) | (cr[2] << 16) | ((unsigned)cr[3] << 24), (unsigned)cr[4] | (cr[5] << 8) | (cr[6] << 16) | ((unsigned)cr[7] << 24)};
+            }
+        }
+        column_pass_quantize(slot, p, odd, qtab, qtab + 64);
+        pair_lds_fence();
+        // copy-out: the wave's 32 blocks are 4 KB contiguous in the luma grid
+        if (by < (int)im.real_h[0]) {
+            int16_t* rowbase = im.coef[0] + ((size_t)by * im.blocks_w[0] + (size_t)u.tile_bx * kTileBX) * 64;
+            const int nvalid = min((int)im.real_w[0] - (int)u.tile_bx * kTileBX, kTileBX);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int g = k * 64 + lane, b = g >> 3;
+                if (b < nvalid) {
+                    const u32x4 v = gather_zigzag_piece(wave_slots + b * kPairSlotStride, zoff);
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(rowbase) + g);
+                }
+            }
+        }
+        pair_lds_fence();  // slots are reused by the next block row
+    }
+    __syncthreads();  // chroma tile complete
+
+    // ---- phase B: the tile's chroma blocks, two lanes each: (32/HS) x (8/VS) blocks per component
+    constexpr int cbw = kTileBX / HS, cbh = kTileBY / VS, per_comp = cbw * cbh, nchroma = 2 * per_comp;
+    const int last_row = (H + VS - 1) / VS - 1;  // last real downsampled row (rows below replicate it: jcprepct.c)
+#pragma unroll 1
+    for (int base = 0; base < nchroma; base += kThreads / 2) {
+        const int idx = base + (tid >> 1);  // < nchroma: every count is a multiple of 128
+        const int comp = idx / per_comp, rem = idx - comp * per_comp;
+        const int cby = rem / cbw, cbx = rem - cby * cbw;
+        const int gcy = u.tile_by * cbh + cby;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = p ? 7 - i : i;
+            const int lrow = min(gcy * 8 + r, last_row) - (int)u.tile_by * kChromaH;
+            const u32x2 v = *(const __attribute__((address_space(3))) u32x2*)&lds_chroma[comp][lrow][cbx * 8];
+            int srow[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) srow[c] = (int)(((c < 4 ? v.x : v.y) >> (8 * (c & 3))) & 0xFF) - 128;
+            row_pass_store(srow, slot, r);
+        }
+        column_pass_quantize(slot, p, odd, qtab + 128, qtab + 192);
+        pair_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int g = k * 64 + lane, b = g >> 3;  // block b of this wave's 32
+            const int bidx = base + wave * 32 + b;
+            const int bcomp = bidx / per_comp, brem = bidx - bcomp * per_comp;
+            const int bcy = brem / cbw, bcx = brem - bcy * cbw;
+            const int ggx = u.tile_bx * cbw + bcx, ggy = u.tile_by * cbh + bcy;
+            if (ggx < (int)im.real_w[1 + bcomp] && ggy < (int)im.real_h[1 + bcomp]) {
+                const u32x4 v = gather_zigzag_piece(wave_slots + b * kPairSlotStride, zoff);
+                u32x4* dst = reinterpret_cast<u32x4*>(im.coef[1 + bcomp] + ((size_t)ggy * im.blocks_w[1 + bcomp] + ggx) * 64) + (lane & 7);
+                __builtin_nontemporal_store(v, dst);
+            }
+        }
+        pair_lds_fence();
+    }
+}
+
 }  // namespace
 
 int launch_forward(const EncodeImage* images, const EncodeUnit* units, int nunits, void* stream)
 {
     if (nunits <= 0) return 0;
     hipLaunchKernelGGL(forward_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    return (int)hipGetLastError();
+}
+
+int launch_forward_pair(int hs, int vs, const EncodeImage* images, const EncodeUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    if (hs == 2 && vs == 2)
+        hipLaunchKernelGGL((forward_pair_kernel<2, 2>), dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    else if (hs == 2 && vs == 1)
+        hipLaunchKernelGGL((forward_pair_kernel<2, 1>), dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    else if (hs == 1 && vs == 1)
+        hipLaunchKernelGGL((forward_pair_kernel<1, 1>), dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    else
+        return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
 

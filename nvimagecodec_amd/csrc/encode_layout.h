@@ -24,6 +24,12 @@ struct alignas(16) EncodeQuant {
     uint32_t half[64];
 };
 
+// The same quantizer indexed by NATURAL (row-major) position, half pre-shifted by 4 (forward_pair_kernel)
+struct alignas(16) EncodeQuantNatural {
+    uint32_t magic[64];
+    uint32_t half16[64];
+};
+
 struct alignas(16) EncodeImage {
     const uint8_t* in[4];
     int16_t* coef[4];
@@ -33,6 +39,7 @@ struct alignas(16) EncodeImage {
     uint32_t width, height, ncomp, in_format;
     uint32_t hs, vs, pad0, pad1;        // luma sampling factors (chroma is 1x1)
     EncodeQuant quant[2];               // [0] luma table, [1] chroma table
+    EncodeQuantNatural qnat[2];
 };
 
 // One workgroup = one tile of 32 x 8 luma blocks.

@@ -60,6 +60,7 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
     images_.assign(n, PlannedEncode());
     desc_.assign(n, EncodeImage());
     units_.clear();
+    for (auto& v : unit_lists_) v.clear();
     coef_total_ = 0;
     pixel_bytes_ = coef_bytes_ = 0;
     for (int i = 0; i < n; i++) {
@@ -111,14 +112,24 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
                 const uint32_t div = 8u * q[kZigzagNatural[k]];
                 d.quant[t].magic[k] = (1u << 28) / div + 1;
                 d.quant[t].half[k] = div >> 1;
+                d.qnat[t].magic[kZigzagNatural[k]] = d.quant[t].magic[k];
+                d.qnat[t].half16[kZigzagNatural[k]] = (div >> 1) << 4;
             }
         }
         // tiles cover the real luma blocks only
         const int tiles_x = (g.real_w[0] + kTileBX - 1) / kTileBX, tiles_y = (g.real_h[0] + kTileBY - 1) / kTileBY;
+        // interleaved 8-byte-aligned RGB/BGR into 4:2:0 / 4:2:2 / 4:4:4 has a kernel of its own (encode_kernels.hip forward_pair_kernel)
+        int flavour = 0;
+        if (g.ncomp == 3 && (fmt == HIPJPEG_OUTPUT_RGBI || fmt == HIPJPEG_OUTPUT_BGRI) && ((((uintptr_t)in.plane[0]) | in.pitch[0]) & 7) == 0)
+            flavour = (g.hs == 2 && g.vs == 2) ? 1 : (g.hs == 2 && g.vs == 1) ? 2 : (g.hs == 1 && g.vs == 1) ? 3 : 0;
         for (int ty = 0; ty < tiles_y; ty++)
-            for (int tx = 0; tx < tiles_x; tx++) units_.push_back(EncodeUnit{(uint32_t)i, (uint32_t)tx, (uint32_t)ty, 0u});
+            for (int tx = 0; tx < tiles_x; tx++) unit_lists_[flavour].push_back(EncodeUnit{(uint32_t)i, (uint32_t)tx, (uint32_t)ty, 0u});
         pixel_bytes_ += (uint64_t)g.width * g.height * (g.ncomp == 1 ? 1 : 3);
         for (int c = 0; c < g.ncomp; c++) coef_bytes_ += (uint64_t)g.real_w[c] * g.real_h[c] * 128;
+    }
+    for (int f = 0; f < 4; f++) {  // one table, the flavours back to back
+        unit_first_[f] = units_.size();
+        units_.insert(units_.end(), unit_lists_[f].begin(), unit_lists_[f].end());
     }
     units_offset_ = align_up(sizeof(EncodeImage) * (size_t)n, 256);
     desc_bytes_ = align_up(units_offset_ + sizeof(EncodeUnit) * units_.size(), 256);
@@ -144,8 +155,11 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
 
 hipjpegStatus_t EncodeBatch::relaunch(void* stream)
 {
-    int rc = launch_forward(reinterpret_cast<const EncodeImage*>(device_.data()), reinterpret_cast<const EncodeUnit*>(device_.data() + units_offset_),
-                            (int)units_.size(), stream);
+    const EncodeImage* dimg = reinterpret_cast<const EncodeImage*>(device_.data());
+    const EncodeUnit* dunits = reinterpret_cast<const EncodeUnit*>(device_.data() + units_offset_);
+    static const int pair_hs[4] = {0, 2, 2, 1}, pair_vs[4] = {0, 2, 1, 1};
+    int rc = launch_forward(dimg, dunits + unit_first_[0], (int)unit_lists_[0].size(), stream);
+    for (int f = 1; f < 4 && rc == 0; f++) rc = launch_forward_pair(pair_hs[f], pair_vs[f], dimg, dunits + unit_first_[f], (int)unit_lists_[f].size(), stream);
     if (rc != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (!event_) {
         hipEvent_t ev;

@@ -104,6 +104,15 @@ OP_LOOP(k_dot4, EACH(G_DOT4))
 OP_LOOP(k_pkmul, EACH(G_PKMUL))
 OP_LOOP(k_madi16, EACH(G_MADI16))
 OP_LOOP(k_pkashr, EACH(G_PKASHR))
+__device__ __forceinline__ int f_mulhi(int x, int a) { int r; asm volatile("v_mul_hi_u32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(a)); return r; }
+__device__ __forceinline__ int f_mulhi24(int x, int a) { int r; asm volatile("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(x), "v"(a)); return r; }
+__device__ __forceinline__ int f_xor(int x, int a) { int r; asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(a)); return r; }
+#define G_MULHI(x) f_mulhi(x, a)
+#define G_MULHI24(x) f_mulhi24(x, a)
+#define G_XOR(x) f_xor(x, a)
+OP_LOOP(k_mulhi, EACH(G_MULHI))
+OP_LOOP(k_mulhi24, EACH(G_MULHI24))
+OP_LOOP(k_xor, EACH(G_XOR))
 typedef void (*kern_t)(int*, int, int, int);
 int main()
 {
@@ -113,7 +122,7 @@ int main()
         {"v_med3_i32", k_med3}, {"v_lshl_or_b32", k_lshlor}, {"v_add3_u32", k_add3}, {"v_cndmask_b32", k_cnd}, {"v_ashrrev_i32", k_ashr},
         {"v_pk_add_u16", k_pkadd}, {"v_pk_mad_u16", k_pkmad}, {"v_mov_dpp", k_dpp}, {"v_mul_i32_i24_e32", k_mul24v2}, {"v_and_b32", k_and},
         {"v_max_i32", k_max}, {"v_perm_b32", k_perm}, {"v_sat_pk_u8_i16", k_satpk}, {"v_add_u32_sdwa", k_addsdwa}, {"v_mul_u32_u24_sdwa", k_mulsdwa},
-        {"v_cndmask_b32_e32", k_cnd2}, {"v_lshl_add_u32", k_lshladd}, {"v_cndmask_b32_e64 sgpr", k_cnd64}, {"v_dot2_i32_i16", k_dot2}, {"v_dot4_i32_i8", k_dot4}, {"v_pk_mul_lo_u16", k_pkmul}, {"v_mad_i32_i16", k_madi16}, {"v_pk_ashrrev_i16", k_pkashr}};
+        {"v_cndmask_b32_e32", k_cnd2}, {"v_lshl_add_u32", k_lshladd}, {"v_cndmask_b32_e64 sgpr", k_cnd64}, {"v_dot2_i32_i16", k_dot2}, {"v_dot4_i32_i8", k_dot4}, {"v_pk_mul_lo_u16", k_pkmul}, {"v_mad_i32_i16", k_madi16}, {"v_pk_ashrrev_i16", k_pkashr}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_hi_u32_u24", k_mulhi24}, {"v_xor_b32", k_xor}};
     const int iters = 2000;
     for (int wg_per_cu : {4}) {
         printf("== %d workgroups of 256 per CU (%d waves/SIMD)\n", wg_per_cu, wg_per_cu);
