@@ -300,24 +300,15 @@ __global__ __launch_bounds__(kThreads) void forward_kernel(const EncodeImage* __
 //   lane p of a pair loads and colour-converts four pixel rows of the block -- lane 0 rows 0,1,2,3, lane 1 rows 7,6,5,4 --
 //   downsamples its chroma patch into the LDS chroma tile, runs the FDCT row pass on its four rows and leaves them in the
 //   block's LDS slot as int16; after the hand-off it reads columns 4p..4p+3 of all eight rows back, lane 1 from the bottom
-//   row up: reversing the input of the 1-D FDCT leaves the even outputs alone and negates the odd part's inputs, so lane 1
-//   runs the very same butterfly with the nine odd-part multipliers negated (registers, set up once) -- no lane-dependent
-//   selects anywhere.  Quantized coefficients go back into the slot in natural order; the wave's copy-out gathers them in
+//   row up: reversing the input of the 1-D FDCT leaves the even outputs alone and negates the odd ones, which lane 1 undoes
+//   with a rounding term one smaller and a sign flip after the quantizer (fdct8_columns) -- no lane-dependent selects anywhere.  Quantized coefficients go back into the slot in natural order; the wave's copy-out gathers them in
 //   zigzag order (each lane always fetches the same eight positions) and stores 16 bytes per lane, fully coalesced.
 // ------------------------------------------------------------------------------------------------
-struct OddPart {
-    int f0298, f2053, f3072, f1501, n0899, n2562, n1961, n0390, f1175;
-};
-
-__device__ __forceinline__ int mul24v(int a, int b)
-{
-    int r;
-    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// jfdctint.c column pass (final descale) with the odd part's multipliers in registers
-__device__ __forceinline__ void fdct8_columns(int (&d)[8], const OddPart& k)
+// jfdctint.c column pass (final descale).  `rnd` is the rounding term of the four odd outputs: 1 << 14 for a lane that feeds
+// the rows top-down.  A lane that feeds them bottom-up (input reversed) gets the even outputs unchanged and the odd part
+// negated BEFORE the rounding shift; with rnd = (1 << 14) - 1 its odd outputs are then exactly the negated true values
+// ((-x + h) >> n == -((x + h - 1) >> n)), and the caller flips their sign after the (sign-symmetric) quantizer.
+__device__ __forceinline__ void fdct8_columns(int (&d)[8], int rnd)
 {
     int t0 = d[0] + d[7], t7 = d[0] - d[7];
     int t1 = d[1] + d[6], t6 = d[1] - d[6];
@@ -331,19 +322,19 @@ __device__ __forceinline__ void fdct8_columns(int (&d)[8], const OddPart& k)
     d[6] = descale(z1 + __mul24(t12, -F_1_847), 15);
     z1 = t4 + t7;
     int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
-    int z5 = mul24v(z3 + z4, k.f1175);
-    t4 = mul24v(t4, k.f0298);
-    t5 = mul24v(t5, k.f2053);
-    t6 = mul24v(t6, k.f3072);
-    t7 = mul24v(t7, k.f1501);
-    z1 = mul24v(z1, k.n0899);
-    z2 = mul24v(z2, k.n2562);
-    z3 = mul24v(z3, k.n1961) + z5;
-    z4 = mul24v(z4, k.n0390) + z5;
-    d[7] = descale(t4 + z1 + z3, 15);
-    d[5] = descale(t5 + z2 + z4, 15);
-    d[3] = descale(t6 + z2 + z3, 15);
-    d[1] = descale(t7 + z1 + z4, 15);
+    int z5 = __mul24(z3 + z4, F_1_175);
+    t4 = __mul24(t4, F_0_298);
+    t5 = __mul24(t5, F_2_053);
+    t6 = __mul24(t6, F_3_072);
+    t7 = __mul24(t7, F_1_501);
+    z1 = __mul24(z1, -F_0_899);
+    z2 = __mul24(z2, -F_2_562);
+    z3 = __mul24(z3, -F_1_961) + z5;
+    z4 = __mul24(z4, -F_0_390) + z5;
+    d[7] = (t4 + z1 + z3 + rnd) >> 15;
+    d[5] = (t5 + z2 + z4 + rnd) >> 15;
+    d[3] = (t6 + z2 + z3 + rnd) >> 15;
+    d[1] = (t7 + z1 + z4 + rnd) >> 15;
 }
 
 __device__ __forceinline__ void pair_lds_fence()
@@ -368,8 +359,8 @@ __device__ __forceinline__ void row_pass_store(int (&s)[8], lds_char* slot, int 
 
 // After every row of the block is in the slot: column pass of columns 4p..4p+3 (lane 1 bottom row first, see above),
 // quantization, and the quantized coefficients back into the slot in natural order (int16).  The caller fences afterwards.
-// qmagic / qhalf16: natural-order tables in LDS (half16 = half << 4).
-__device__ __forceinline__ void column_pass_quantize(lds_char* slot, bool p, const OddPart& odd, const __attribute__((address_space(3))) unsigned* qmagic,
+// qmagic / qhalf16: tables in LDS, COLUMN-major over the natural block (index column * 8 + row), half16 = half << 4.
+__device__ __forceinline__ void column_pass_quantize(lds_char* slot, bool p, const __attribute__((address_space(3))) unsigned* qmagic,
                                                      const __attribute__((address_space(3))) unsigned* qhalf16)
 {
     using lds_u32x2 = __attribute__((address_space(3))) u32x2;
@@ -381,32 +372,39 @@ __device__ __forceinline__ void column_pass_quantize(lds_char* slot, bool p, con
 #pragma unroll
     for (int n = 0; n < 8; n++) rd[n] = *reinterpret_cast<const lds_u32x2*>(mine + n * step);
     pair_lds_fence();  // the partner has read too before anything below overwrites the slot (same wave: program order)
-    int col[4][8];
+    const int flip = p ? -1 : 0;
+    const int rnd = p ? (1 << 14) - 1 : (1 << 14);
+    // two columns at a time; the tables are stored column-major so the eight quantizers of a column are two 16-byte reads
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int half = 0; half < 2; half++) {
+        int r[2][8];
 #pragma unroll
-        for (int n = 0; n < 8; n++) {
-            const unsigned w = (j < 2) ? rd[n].x : rd[n].y;
-            col[j][n] = (j & 1) ? ((int)w >> 16) : (int)(short)(w & 0xFFFF);
+        for (int jj = 0; jj < 2; jj++) {
+            int d[8];
+#pragma unroll
+            for (int n = 0; n < 8; n++) {
+                const unsigned w = half ? rd[n].y : rd[n].x;
+                d[n] = jj ? ((int)w >> 16) : (int)(short)(w & 0xFFFF);
+            }
+            fdct8_columns(d, rnd);
+            const int tcol = ((p ? 4 : 0) + 2 * half + jj) * 8;
+            const u32x4 ma = *reinterpret_cast<const lds_u32x4*>(qmagic + tcol), mb = *reinterpret_cast<const lds_u32x4*>(qmagic + tcol + 4);
+            const u32x4 ha = *reinterpret_cast<const lds_u32x4*>(qhalf16 + tcol), hb = *reinterpret_cast<const lds_u32x4*>(qhalf16 + tcol + 4);
+            const unsigned m8[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w}, h8[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                // jcdctmgr.c quantize: divisor 8*q, round half away from zero (see fdct_quantize above)
+                const int v = d[k];
+                const int sgn = v >> 31;
+                const unsigned a16 = (((unsigned)((v ^ sgn) - sgn)) << 4) + h8[k];
+                const int m = (int)__umulhi(a16, m8[k]);
+                const int sg2 = (k & 1) ? (sgn ^ flip) : sgn;  // odd rows of the bottom-up lane are negated (fdct8_columns)
+                r[jj][k] = (m ^ sg2) - sg2;
+            }
         }
-        fdct8_columns(col[j], odd);
-    }
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        // jcdctmgr.c quantize: divisor 8*q, round half away from zero (see fdct_quantize above)
-        const u32x4 qm = *reinterpret_cast<const lds_u32x4*>(qmagic + k * 8 + (p ? 4 : 0));
-        const u32x4 qh = *reinterpret_cast<const lds_u32x4*>(qhalf16 + k * 8 + (p ? 4 : 0));
-        const unsigned m4[4] = {qm.x, qm.y, qm.z, qm.w}, h4[4] = {qh.x, qh.y, qh.z, qh.w};
-        int r[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int v = col[j][k];
-            const int sgn = v >> 31;
-            const unsigned a16 = (((unsigned)((v ^ sgn) - sgn)) << 4) + h4[j];
-            const int m = (int)__umulhi(a16, m4[j]);
-            r[j] = (m ^ sgn) - sgn;
-        }
-        *reinterpret_cast<lds_u32x2*>(slot + k * 16 + (p ? 8 : 0)) = u32x2{pack16(r[0], r[1]), pack16(r[2], r[3])};
+        for (int k = 0; k < 8; k++)
+            *reinterpret_cast<__attribute__((address_space(3))) unsigned*>(slot + k * 16 + (p ? 8 : 0) + half * 4) = pack16(r[0][k], r[1][k]);
     }
 }
 
@@ -428,10 +426,13 @@ __device__ __forceinline__ u32x4 gather_zigzag_piece(const lds_char* slot, const
     return u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
 }
 
+#ifndef HJ_PAIR_WAVES
+#define HJ_PAIR_WAVES 4
+#endif
 constexpr int kPairSlotStride = 144;  // 128 B block + 16 B pad
 
 template <int HS, int VS>
-__global__ __launch_bounds__(kThreads, 4) void forward_pair_kernel(const EncodeImage* __restrict__ images, const EncodeUnit* __restrict__ units)
+__global__ __launch_bounds__(kThreads, HJ_PAIR_WAVES) void forward_pair_kernel(const EncodeImage* __restrict__ images, const EncodeUnit* __restrict__ units)
 {
     constexpr int kChromaW = kTileBX * 8 / HS, kChromaH = kTileBY * 8 / VS;  // downsampled chroma tile
     __shared__ __attribute__((aligned(16))) char lds_slots[4 * 32 * kPairSlotStride];             // 18,432 B
@@ -447,19 +448,6 @@ __global__ __launch_bounds__(kThreads, 4) void forward_pair_kernel(const EncodeI
     {
         const int t = tid >> 6, k = tid & 63;
         lds_quant[t][k] = (t & 1) ? im.qnat[t >> 1].half16[k] : im.qnat[t >> 1].magic[k];
-    }
-    OddPart odd;
-    {
-        const int sg = p ? -1 : 1;
-        odd.f0298 = sg * F_0_298;
-        odd.f2053 = sg * F_2_053;
-        odd.f3072 = sg * F_3_072;
-        odd.f1501 = sg * F_1_501;
-        odd.n0899 = sg * -F_0_899;
-        odd.n2562 = sg * -F_2_562;
-        odd.n1961 = sg * -F_1_961;
-        odd.n0390 = sg * -F_0_390;
-        odd.f1175 = sg * F_1_175;
     }
     const uint4 zoff = *reinterpret_cast<const uint4*>(&kZigzagPieceOffsets[lane & 7][0]);
     // colour weights: for BGR input the first and third byte swap roles -- wave-uniform scalars, no per-pixel work
@@ -560,7 +548,7 @@ __global__ __launch_bounds__(kThreads, 4) void forward_pair_kernel(const EncodeI
                     u32x2{(unsigned)cr[0] | (cr[1] << 8) | (cr[2] << 16) | ((unsigned)cr[3] << 24), (unsigned)cr[4] | (cr[5] << 8) | (cr[6] << 16) | ((unsigned)cr[7] << 24)};
             }
         }
-        column_pass_quantize(slot, p, odd, qtab, qtab + 64);
+        column_pass_quantize(slot, p, qtab, qtab + 64);
         pair_lds_fence();
         // copy-out: the wave's 32 blocks are 4 KB contiguous in the luma grid
         if (by < (int)im.real_h[0]) {
@@ -598,7 +586,7 @@ __global__ __launch_bounds__(kThreads, 4) void forward_pair_kernel(const EncodeI
             for (int c = 0; c < 8; c++) srow[c] = (int)(((c < 4 ? v.x : v.y) >> (8 * (c & 3))) & 0xFF) - 128;
             row_pass_store(srow, slot, r);
         }
-        column_pass_quantize(slot, p, odd, qtab + 128, qtab + 192);
+        column_pass_quantize(slot, p, qtab + 128, qtab + 192);
         pair_lds_fence();
 #pragma unroll
         for (int k = 0; k < 4; k++) {

@@ -24,7 +24,7 @@ struct alignas(16) EncodeQuant {
     uint32_t half[64];
 };
 
-// The same quantizer indexed by NATURAL (row-major) position, half pre-shifted by 4 (forward_pair_kernel)
+// The same quantizer indexed column-major over the natural block (column * 8 + row), half pre-shifted by 4 (forward_pair_kernel)
 struct alignas(16) EncodeQuantNatural {
     uint32_t magic[64];
     uint32_t half16[64];

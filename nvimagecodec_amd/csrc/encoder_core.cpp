@@ -112,8 +112,9 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
                 const uint32_t div = 8u * q[kZigzagNatural[k]];
                 d.quant[t].magic[k] = (1u << 28) / div + 1;
                 d.quant[t].half[k] = div >> 1;
-                d.qnat[t].magic[kZigzagNatural[k]] = d.quant[t].magic[k];
-                d.qnat[t].half16[kZigzagNatural[k]] = (div >> 1) << 4;
+                const int nat = kZigzagNatural[k], tr = (nat & 7) * 8 + (nat >> 3);
+                d.qnat[t].magic[tr] = d.quant[t].magic[k];
+                d.qnat[t].half16[tr] = (div >> 1) << 4;
             }
         }
         // tiles cover the real luma blocks only
