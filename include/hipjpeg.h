@@ -197,9 +197,10 @@ HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatch(hipjpegHandle_t handle, const hip
 /* Pipelined encoding: Submit queues a whole batch (forward kernel + entropy stage per `flags` as in
  * hipjpegEncodeBatchEntropy + copy of the files to host memory) and returns at once; it runs on an internal stream, ordered
  * behind the work already queued on `stream` (the producer of the pixels).  Wait blocks until the OLDEST submitted batch is
- * complete, returns its statuses and makes it the batch hipjpegEncodeGetBitstream talks about.  At most two batches in
- * flight; the bitstreams of a waited batch stay valid until the second Submit after it.  The copy of one batch's files
- * overlaps the kernels of the next. */
+ * complete, returns its statuses and makes it the batch hipjpegEncodeGetBitstream talks about.  At most three batches in
+ * flight (three pages, used round robin); the bitstreams of a waited batch stay valid until a Submit takes its page again:
+ * the third Submit after the one that queued it.  The PCIe-bound file output of one batch overlaps the kernels of the
+ * others. */
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchSubmit(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
                                                      int batch_size, unsigned flags, void* stream);
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size);

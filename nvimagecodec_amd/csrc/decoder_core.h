@@ -39,6 +39,7 @@ public:
     void release();
     uint8_t* data() const { return ptr_; }
     size_t capacity() const { return cap_; }
+    bool custom() const { return custom_; }  // allocated through the caller's hooks
 
 private:
     Kind kind_;

@@ -305,7 +305,7 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
     const size_t q_foff = align_up(q_len + (size_t)ng * 4, 256);
     const size_t q_raw = align_up(q_foff + (size_t)ng * 8, 256);
     const size_t q_arena = align_up(q_raw + raw_total, 256);
-    if ((st = henc_dev2_.reserve(q_arena + arena_cap + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    if ((st = henc_dev2_.reserve(q_arena + arena_cap + 256)) != HIPJPEG_STATUS_SUCCESS) return st;  // (arena unused when the files go to the host directly)
     // the pinned buffer is about to grow: keep what is still needed
     const size_t p_len = align_up(p_up2 + up2, 256);
     const size_t p_foff = align_up(p_len + (size_t)ng * 4, 256);
@@ -325,7 +325,12 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
     uint32_t* chunk_out = reinterpret_cast<uint32_t*>(dev2 + q_out);
     uint32_t* final_len = reinterpret_cast<uint32_t*>(dev2 + q_len);
     unsigned long long* final_off = reinterpret_cast<unsigned long long*>(dev2 + q_foff);
-    uint8_t* arena = dev2 + q_arena;
+    // The finished files go straight into pinned host memory when it is ours (hipHostMalloc: mapped into the device's address
+    // space): the expand kernel's stores cross PCIe themselves and no copy follows.  With a caller-supplied pinned allocator
+    // the mapping is unknown, so the files are assembled in HBM and copied.
+    static const bool no_direct = getenv("HIPJPEG_ENCODE_STAGED_OUTPUT") != nullptr;
+    bool direct = !no_direct && henc_out_.reserve(arena_cap + 256) == HIPJPEG_STATUS_SUCCESS && !henc_out_.custom();
+    uint8_t* arena = direct ? henc_out_.data() : dev2 + q_arena;
     if (hipMemcpyAsync(dev2, pin + p_up2, up2, hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_henc_zero(dev2 + q_raw, raw_total, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_henc_write(dimg2, dunits, (int)units.size(), dtables, block_off, block_bits, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
@@ -340,9 +345,11 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
     if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     const size_t used = (size_t)h_foff[ng - 1] + align_up((size_t)h_len[ng - 1], 16);
     if (used > arena_cap) return HIPJPEG_STATUS_HIP_ERROR;  // cannot happen: the capacity assumes every byte is stuffed
-    if ((st = henc_out_.reserve(used + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
-    if (hipMemcpyAsync(henc_out_.data(), arena, used, hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-    if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (!direct) {
+        if ((st = henc_out_.reserve(used + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+        if (hipMemcpyAsync(henc_out_.data(), arena, used, hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    }
     for (int g = 0; g < ng; g++) {
         PlannedEncode& im = images_[idx[g]];
         im.gpu_bitstream = henc_out_.data() + h_foff[g];

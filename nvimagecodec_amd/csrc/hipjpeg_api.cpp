@@ -40,8 +40,9 @@ struct hipjpegHandle {
     hipStream_t entropy_stream = nullptr;  // GPU entropy stage of submitted batches: beside the pixel kernels of the batch before
     std::unique_ptr<EncodeBatch> encode;
     EncodeBatch* encode_view = nullptr;  // the batch hipjpegEncodeGetBitstream / GetCoefficients / Stats talk about
-    // pipelined encoding (hipjpegEncodeBatchSubmit / Wait): two pages, each driven by its own host thread on its own
-    // stream, so that the D2H copy and the two short host round trips of one batch overlap the kernels of the other
+    // pipelined encoding (hipjpegEncodeBatchSubmit / Wait): three pages, each driven by its own host thread on its own
+    // stream, so that the PCIe-bound file output and the two short host round trips of one batch overlap the kernels of the
+    // others (two pages fall into lock-step: both batches compute, then both wait for PCIe)
     struct EncodePage {
         std::unique_ptr<EncodeBatch> batch;
         hipStream_t stream = nullptr;
@@ -50,7 +51,8 @@ struct hipjpegHandle {
         std::vector<hipjpegEncodeInput_t> inputs;
         std::vector<hipjpegEncodeParams_t> params;
     };
-    EncodePage encode_pages[2];
+    static constexpr int kEncodePages = 3;
+    EncodePage encode_pages[kEncodePages];
     int encode_next = 0, encode_oldest = 0, encode_in_flight = 0;
 };
 
@@ -375,7 +377,7 @@ hipjpegStatus_t hipjpegEncodeBatchSubmit(hipjpegHandle_t handle, const hipjpegEn
                                          unsigned flags, void* stream)
 {
     if (!handle || batch_size < 0 || (batch_size > 0 && (!inputs || !params))) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    if (handle->encode_in_flight >= 2) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // both pages busy: Wait first
+    if (handle->encode_in_flight >= hipjpegHandle::kEncodePages) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // every page busy: Wait first
     if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
     hipjpegHandle::EncodePage& pg = handle->encode_pages[handle->encode_next];
     if (!pg.batch) {
@@ -407,7 +409,7 @@ hipjpegStatus_t hipjpegEncodeBatchSubmit(hipjpegHandle_t handle, const hipjpegEn
         }
         return HIPJPEG_STATUS_SUCCESS;
     });
-    handle->encode_next ^= 1;
+    handle->encode_next = (handle->encode_next + 1) % hipjpegHandle::kEncodePages;
     handle->encode_in_flight++;
     return HIPJPEG_STATUS_SUCCESS;
 }
@@ -416,7 +418,7 @@ hipjpegStatus_t hipjpegEncodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* 
 {
     if (!handle || handle->encode_in_flight == 0) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     hipjpegHandle::EncodePage& pg = handle->encode_pages[handle->encode_oldest];
-    handle->encode_oldest ^= 1;
+    handle->encode_oldest = (handle->encode_oldest + 1) % hipjpegHandle::kEncodePages;
     handle->encode_in_flight--;
     const hipjpegStatus_t st = pg.result.get();
     handle->encode_view = pg.batch.get();

@@ -346,7 +346,7 @@ class BatchEncoder:
         return list(st_arr)
 
     # -- pipelined: submit() queues forward kernel + entropy stage + copy of the files and returns; wait() completes the
-    #    oldest submitted batch and returns (statuses, bitstreams).  At most two batches in flight.
+    #    oldest submitted batch and returns (statuses, bitstreams).  At most three batches in flight.
     def submit(self, images, subsampling="420", quality=90, input_format="rgb", restart_interval=0, optimized_huffman=False, stream=None,
                gpu_huffman=None):
         if gpu_huffman is None:

@@ -21,8 +21,9 @@ for rep in range(2):
     K = 16
     for i in range(K):
         enc.submit(imgs, "420", 90, "rgb", gpu_huffman=True)
-        if i > 0:
+        if i > 1:
             enc.wait(fetch=False)
+    enc.wait(fetch=False)
     enc.wait(fetch=False)
     t1 = time.time()
     print("pipelined submit/wait: %.2f ms/batch %.0f img/s" % ((t1 - t0) / K * 1e3, K * B / (t1 - t0)), flush=True)
