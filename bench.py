@@ -347,7 +347,7 @@ def main():
         kernel_ms = k1_ms + k2_ms
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_f_hbm_traffic.json")
         if os.path.exists(tp):
             try:
                 with open(tp) as f:
@@ -366,7 +366,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_step": alg_bytes,
                          "kernels": [{"name": "idct_plane_kernel<false>", "avg_ms": round(k1_ms, 4), "workgroups": stats["units"][0]},
-                                     {"name": "luma_color_kernel<false,2,2>", "avg_ms": round(k2_ms, 4), "workgroups": stats["units"][1]}]},
+                                     {"name": "luma_color_kernel<false,2,2,true>", "avg_ms": round(k2_ms, 4), "workgroups": stats["units"][1]}]},
             "host_stage": {"images_per_s": round(BATCH / t_host, 1), "threads": host_threads, "h2d_GBps": round(stats["coef_bytes"] / t_h2d / 1e9, 1)},
             "end_to_end": {"images_per_s": round(BATCH * world / t_e2e_gpu, 1), "mp_per_s": round(BATCH * world / t_e2e_gpu * WIDTH * HEIGHT / 1e6, 1),
                            "includes": "host JPEG bytes -> RGB in HBM: header parse + H2D of the bitstreams + GPU entropy stage + device stage, "

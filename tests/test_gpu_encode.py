@@ -110,6 +110,30 @@ def test_pitched_input(enc, torch_mod):
         assert s[0] == oracle.encode(im, "420", 90)
 
 
+def test_pair_kernel_ragged_edges(enc, torch_mod):
+    """forward_pair_kernel (two lanes per block) takes interleaved RGB/BGR whose base and pitch are multiples of 8 bytes.  Odd
+    widths only get there through a padded pitch: ragged right / bottom edges (libjpeg's edge replication), images smaller
+    than one MCU, widths that end inside / exactly on / one block past a 32-block tile, 4:2:0 / 4:2:2 / 4:4:4, both byte orders."""
+    torch = torch_mod
+    sizes = [(1, 1), (7, 9), (17, 13), (33, 65), (250, 63), (257, 66), (264, 70), (300, 200), (519, 131)]
+    for fmt in ("rgb", "bgr"):
+        for sub in ("420", "422", "444"):
+            views, refs = [], []
+            for (w, h) in sizes:
+                im = synth_image(w, h, seed=5 * w + h)
+                pitch = (3 * w + 7) // 8 * 8 + 8
+                buf = torch.zeros(h * pitch + 64, dtype=torch.uint8, device="cuda")
+                assert buf.data_ptr() % 8 == 0
+                view = torch.as_strided(buf, (h, w, 3), (pitch, 3, 1))
+                src = im[:, :, ::-1] if fmt == "bgr" else im
+                view.copy_(torch.from_numpy(np.ascontiguousarray(src)).cuda())
+                views.append(view)
+                refs.append(im)
+            streams = enc.encode(views, subsampling=sub, quality=85, input_format=fmt)
+            for (w, h), s, im in zip(sizes, streams, refs):
+                assert s == oracle.encode(im, sub, 85), f"{w}x{h} {sub} {fmt}"
+
+
 def test_config2_1080p_420_q90_batch_and_roundtrip(enc, torch_mod):
     """BASELINE.json configs[2] shape (reduced batch): 1920x1080 RGB -> q90 4:2:0; then decode our own streams on the GPU:
     encode->decode must equal the oracle's encode->decode (size-independent round-trip property at full size)."""
