@@ -184,6 +184,33 @@ __device__ __forceinline__ void fetch_half_block(const DecodeComponent& cd, int 
     if (dc_apart && !(lane & 1)) cols[0].x = (cols[0].x & 0xFFFF0000u) | dc;
 }
 
+// The same for a tile of the luma kernel: slot j of the wave is block (row0 + (j >> row_shift), col0 + (j & col_mask)) --
+// one run of 32 blocks (row_shift 5, col_mask 31) or two runs of 16 (row_shift 4, col_mask 15; narrow tiles).
+__device__ __forceinline__ void fetch_tile_half_block(const DecodeComponent& cd, int row0, int col0, int row_shift, int col_mask, int bw, int bh,
+                                                      char* lds_wave, int lane, u32x4 (&cols)[4])
+{
+    const u32x4* src = reinterpret_cast<const u32x4*>(cd.coef);
+    const bool dc_apart = cd.dc_stride != 64;  // wave-uniform: host-decoded images carry the DC inside the block already
+    unsigned dc = 0;
+    {
+        const int j = lane >> 1, row = row0 + (j >> row_shift), col = col0 + (j & col_mask);
+        if (dc_apart && row < bh && col < bw) dc = (unsigned short)cd.dc[row * bw + col];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int g = k * 64 + lane, j = g >> 3;
+        const int row = row0 + (j >> row_shift), col = col0 + (j & col_mask);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < bh && col < bw) v = __builtin_nontemporal_load(src + ((size_t)(row * bw + col) * 8 + (g & 7)));
+        *reinterpret_cast<u32x4*>(lds_wave + j * kLdsBlockStride + (g & 7) * 16) = v;
+    }
+    wave_lds_fence();
+    const char* mine = lds_wave + (lane >> 1) * kLdsBlockStride + (lane & 1) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; j++) cols[j] = *reinterpret_cast<const u32x4*>(mine + j * 16);
+    if (dc_apart && !(lane & 1)) cols[0].x = (cols[0].x & 0xFFFF0000u) | dc;
+}
+
 // Dequantize + column pass of this lane's four columns, exchange with the partner lane, and assemble the row-pass inputs.
 //   q: this lane's 32 quantizers, q[j*8 + r] for column 4p+j, with odd rows negated when p == 1 (DecodeComponent::qpair).
 //   rows[i][c]: pass-1 workspace of image row (p ? 7-i : i), column c -- ready for idct8<false,18>.
@@ -372,6 +399,7 @@ __device__ __forceinline__ void upsample_row(uint2 near, uint2 far, bool odd_row
 // wave w of the workgroup owns the 32 consecutive blocks of block row (comp + w).
 constexpr int kOutRowBytes = kBlocksPerWave * 24 + 16;  // one pixel row of a wave's 32 blocks (interleaved RGB) + bank-skew pad
 constexpr int kLdsLumaWaveBytes = 8 * kOutRowBytes;     // 6,272 B: first the coefficient staging (4,608 B), then the RGB tile
+constexpr int kNarrowRowBytes = 16 * 24;                // narrow tiles: 16 pixel rows of 16 blocks (6,144 B)
 
 //   COMMON = the configuration nearly every caller uses, fixed at compile time: YCbCr source, interleaved RGB output whose
 //   rows are 16-byte aligned, libjpeg's default fancy upsampling.  Same arithmetic, but no wave-uniform format branches and
@@ -384,12 +412,16 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     const bool p = lane & 1;
     const int blk = lane >> 1;
     const int bw = im.comp[0].blocks_w, bh = im.comp[0].blocks_h;
-    const int bx0 = u.block_base, by = (int)u.comp + wave;
-    const int bx = bx0 + blk;
+    // tile shapes (WorkUnit::mode, wave-uniform): 0 = 32 x 4 blocks, a wave owns 32 blocks of one block row;
+    //                                             1 = 16 x 8 blocks ("narrow": the ragged right edge of widths like 1920 = 7.5 x 256
+    //                                                 pixels), a wave owns 16 blocks of two block rows -- no half-idle waves
+    const bool narrow = u.mode != 0;
+    const int row_shift = narrow ? 4 : 5, col_mask = narrow ? 15 : 31;
+    const int bx0 = u.block_base, by_wave = (int)u.comp + (narrow ? 2 * wave : wave);
+    const int bx = bx0 + (blk & col_mask), by = by_wave + (blk >> row_shift);
     char* lds_wave = lds + wave * kLdsLumaWaveBytes;
     u32x4 cols[4];
-    // the wave's blocks are contiguous in memory up to the end of the block row
-    fetch_half_block(im.comp[0], by * bw + bx0, by < bh ? (by + 1) * bw : 0, lds_wave, lane, cols);
+    fetch_tile_half_block(im.comp[0], by_wave, bx0, row_shift, col_mask, bw, bh, lds_wave, lane, cols);
     const int x0 = bx * 8, y0 = by * 8;
     const int W = im.width, H = im.height;
     const bool valid = bx < bw && by < bh && x0 < W && y0 < H;  // false: pair idles (block is MCU padding or outside the tile)
@@ -541,7 +573,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
                 }
             } else {
                 if (staged) {
-                    uint2* t = reinterpret_cast<uint2*>(lds_wave + r * kOutRowBytes + blk * 24);
+                    uint2* t = reinterpret_cast<uint2*>(lds_wave + (narrow ? ((blk >> 4) * 8 + r) * kNarrowRowBytes + (blk & 15) * 24 : r * kOutRowBytes + blk * 24));
                     t[0] = make_uint2(q[0], q[1]);
                     t[1] = make_uint2(q[2], q[3]);
                     t[2] = make_uint2(q[4], q[5]);
@@ -565,18 +597,22 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
         }
     }
 
-    if (!staged || by >= bh || y0 >= H) return;  // wave-uniform
+    const int y0w = by_wave * 8;
+    if (!staged || by_wave >= bh || y0w >= H) return;  // wave-uniform
     wave_lds_fence();
-    // the wave's tile: rows y0..y0+7, bytes [bx0*24, bx0*24 + row_bytes) of each row
-    const int row_bytes = min(W - bx0 * 8, kBlocksPerWave * 8) * 3;
-    const int nrows = min(8, H - y0);
-    uint8_t* out_base = im.out[0] + (size_t)y0 * im.out_pitch[0] + (size_t)bx0 * 24;
+    // the wave's tile: pixel rows y0w .. y0w + 7 (narrow: + 15), bytes [bx0*24, bx0*24 + row_bytes) of each row
+    const int tile_row_bytes = narrow ? kNarrowRowBytes : kBlocksPerWave * 24, lds_row_bytes = narrow ? kNarrowRowBytes : kOutRowBytes;
+    const int row_bytes = min((W - bx0 * 8) * 3, tile_row_bytes);
+    const int nrows = min(min(narrow ? 16 : 8, H - y0w), (bh - by_wave) * 8);
+    const int chunks_per_row = tile_row_bytes >> 4;  // 48 or 24
+    const int recip = narrow ? 2731 : 1366;          // g / chunks_per_row == (g * recip) >> 16 for g < 384
+    uint8_t* out_base = im.out[0] + (size_t)y0w * im.out_pitch[0] + (size_t)bx0 * 24;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        const int g = k * 64 + lane;  // 16-byte chunk of the 8 x 768 B tile
-        const int r = (g * 1366) >> 16, off = (g - r * 48) * 16;  // g / 48 for g < 384
+        const int g = k * 64 + lane;  // 16-byte chunk of the 6,144-byte tile
+        const int r = (g * recip) >> 16, off = (g - r * chunks_per_row) * 16;
         if (r < nrows && off < row_bytes) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(lds_wave + r * kOutRowBytes + off);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds_wave + r * lds_row_bytes + off);
             uint8_t* dst = out_base + (__umul24((unsigned)r, im.out_pitch[0]) + (unsigned)off);
             if (off + 16 <= row_bytes) {
 #ifdef HJ_ABLATE_STORE

@@ -535,9 +535,16 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
                                 ((((uintptr_t)d.out[0]) | d.out_pitch[0]) & 15) == 0 && (d.flags & kFlagFancyUpsampling) &&
                                 (im.variant == kVar11 || im.variant == kVar12 || d.comp[1].samp_w > 2);
             const int flavour = exact32 ? kLumaExact : common ? kLumaCommon : kLumaMul24;
+            // a ragged right edge of at most half a tile (1920 pixels = 7.5 tiles) is covered by narrow tiles, 16 x 8 blocks,
+            // so that no wave runs half empty
+            const uint32_t span = end_col - first_col, ragged = span % kLumaTileW;
+            const uint32_t wide_end = (ragged != 0 && ragged <= kLumaTileW / 2) ? end_col - ragged : end_col;
             for (uint32_t by = first_row; by < real_rows; by += kLumaTileH)
-                for (uint32_t bx = first_col; bx < end_col; bx += kLumaTileW)
+                for (uint32_t bx = first_col; bx < wide_end; bx += kLumaTileW)
                     luma_units_[flavour][im.variant].push_back(WorkUnit{(uint32_t)i, bx, by, 0u});
+            if (wide_end < end_col)
+                for (uint32_t by = first_row; by < real_rows; by += 2 * kLumaTileH)
+                    luma_units_[flavour][im.variant].push_back(WorkUnit{(uint32_t)i, wide_end, by, 1u});
         } else if (im.variant == -1) {
             for (int y = 0; y < f.height; y++) generic_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});
         }
