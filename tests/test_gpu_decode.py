@@ -76,6 +76,28 @@ def test_output_formats(dec, fmt):
         assert np.array_equal(o.cpu().numpy(), ref), (e["name"], fmt)
 
 
+@pytest.mark.parametrize("fmt", ["rgb", "bgr", "rgb_planar"])
+def test_tile_shapes_at_the_right_edge(dec, fmt):
+    """The fused luma kernel covers a block row with 32-block tiles and, where the ragged rest is at most 16 blocks, with
+    narrow 16 x 8-block tiles (two block rows per wave).  Widths around every boundary (rest of 1, 8, 15, 16, 17, 31 blocks,
+    ragged pixels inside the last block), heights that end inside the first / second block row of a narrow tile, every
+    sampling the kernel fuses, interleaved and planar outputs (the common-case and the generic kernel flavour)."""
+    cases = []
+    for blocks_w in (1, 16, 17, 32, 33, 40, 47, 48, 49, 63, 80):
+        w = blocks_w * 8 - (3 if blocks_w % 2 else 0)
+        for h, sub in ((8 * 9 + 5, "420"), (8 * 5 + 1, "422"), (8 * 8, "444"), (8 * 17 - 2, "gray")):
+            img = synth_image(w, h, seed=w + 7 * h)
+            cases.append(oracle.encode(img if sub != "gray" else img[:, :, 1].copy(), sub, 88))
+    outs, statuses = dec.decode(cases, fmt=fmt, fancy=True)
+    _sync()
+    assert all(st == 0 for st in statuses)
+    for j, o in zip(cases, outs):
+        ref = oracle.decode(j, oracle.FMT_BGR if fmt == "bgr" else oracle.FMT_RGB)
+        if fmt.endswith("planar"):
+            ref = ref.transpose(2, 0, 1)
+        assert np.array_equal(o.cpu().numpy(), ref)
+
+
 def test_fancy_upsampling_off(dec):
     """fancy_upsampling=0 (python/decoder.cpp:283 default): replication.  The oracle's replicate path is not pinned by a
     libjpeg-turbo vector (Pillow cannot switch do_fancy_upsampling off) -- 'parity unpinned' for this option."""
