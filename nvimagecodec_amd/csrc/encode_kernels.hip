@@ -480,7 +480,8 @@ __global__ __launch_bounds__(kThreads, HJ_PAIR_WAVES) void forward_pair_kernel(c
             const int y = min(y0 + r, H - 1);  // rows past the image replicate the last row (jcprepct.c expand_bottom_edge)
             const unsigned char* rowp = in0 + (size_t)y * pitch;
             if (interior) {
-                const u32x2* v = reinterpret_cast<const u32x2*>(rowp + (size_t)x0 * 3);
+                // (explicitly global: through a generic pointer these become FLAT loads, which also count against the LDS counter)
+                const auto* v = (const __attribute__((address_space(1))) u32x2*)(rowp + (size_t)x0 * 3);
                 const u32x2 a = __builtin_nontemporal_load(v), b = __builtin_nontemporal_load(v + 1), c = __builtin_nontemporal_load(v + 2);
                 w[i][0] = a.x; w[i][1] = a.y; w[i][2] = b.x; w[i][3] = b.y; w[i][4] = c.x; w[i][5] = c.y;
             } else {
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(kThreads, HJ_PAIR_WAVES) void forward_pair_kernel(c
                 const int g = k * 64 + lane, b = g >> 3;
                 if (b < nvalid) {
                     const u32x4 v = gather_zigzag_piece(wave_slots + b * kPairSlotStride, zoff);
-                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(rowbase) + g);
+                    __builtin_nontemporal_store(v, (__attribute__((address_space(1))) u32x4*)rowbase + g);
                 }
             }
         }
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(kThreads, HJ_PAIR_WAVES) void forward_pair_kernel(c
             const int ggx = u.tile_bx * cbw + bcx, ggy = u.tile_by * cbh + bcy;
             if (ggx < (int)im.real_w[1 + bcomp] && ggy < (int)im.real_h[1 + bcomp]) {
                 const u32x4 v = gather_zigzag_piece(wave_slots + b * kPairSlotStride, zoff);
-                u32x4* dst = reinterpret_cast<u32x4*>(im.coef[1 + bcomp] + ((size_t)ggy * im.blocks_w[1 + bcomp] + ggx) * 64) + (lane & 7);
+                auto* dst = (__attribute__((address_space(1))) u32x4*)(im.coef[1 + bcomp] + ((size_t)ggy * im.blocks_w[1 + bcomp] + ggx) * 64) + (lane & 7);
                 __builtin_nontemporal_store(v, dst);
             }
         }
