@@ -10,7 +10,9 @@
 //     work with an event before imageReady(SUCCESS) (cuda_decoder.cpp:552-558)
 // What is different by design: the reference issues one nvJPEG device call per image from per-thread streams; here the
 // executor threads only run the Huffman host stage, and the last one to finish issues ONE H2D copy and ONE launch per
-// kernel for the whole batch (two batch pages alternate so the next batch's host stage overlaps the GPU).
+// kernel for the whole batch (three job pages rotate so the next batch's -- or the next piece's -- host stage and H2D copy
+// overlap the GPU work in flight).
+#include <algorithm>
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
@@ -76,6 +78,8 @@ public:
                               const nvimgcodecDecodeParams_t* params);
 
 private:
+    nvimgcodecStatus_t decode_chunk(nvimgcodecCodeStreamDesc_t** code_streams, nvimgcodecImageDesc_t** images, int batch_size,
+                                    const nvimgcodecDecodeParams_t* params);
     struct Sample {
         nvimgcodecCodeStreamDesc_t* code_stream = nullptr;
         nvimgcodecImageDesc_t* image = nullptr;
@@ -97,6 +101,7 @@ private:
         bool busy = false;
         HipJpegDecoder* owner = nullptr;
         hipEvent_t event = nullptr;
+        hipStream_t stream = nullptr;  // H2D copy and kernels of this job: jobs overlap each other on the device
     };
 
     void single_can_decode(nvimgcodecProcessingStatus_t* status, nvimgcodecCodeStreamDesc_t* cs, nvimgcodecImageDesc_t* image,
@@ -112,9 +117,10 @@ private:
     bool gpu_huffman_ = true;  // entropy-decode eligible streams on the GPU (the reference's GPU_HYBRID backend analogue)
     bool ok_ = false;
     int device_ = 0;
-    hipStream_t stream_ = nullptr;
-    std::unique_ptr<Job> jobs_[2];
+    static constexpr int kJobPages = 3;
+    std::unique_ptr<Job> jobs_[kJobPages];
     int next_job_ = 0;
+    int pipeline_chunks_ = 0;  // option: pieces a large batch is cut into (0 = choose by size, 1 = never cut)
     // Header parsing of a batch (a marker walk through every file) runs on these threads inside decode(): the framework's
     // executor only takes per-sample tasks that report through imageReady, and the batch layout needs every header first.
     std::unique_ptr<hipjpeg::ForkJoinPool> parse_pool_;
@@ -128,6 +134,7 @@ HipJpegDecoder::HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgc
         std::istringstream v(value);
         if (key == "fancy_upsampling") v >> fancy_;
         if (key == "gpu_huffman") v >> gpu_huffman_;
+        if (key == "pipeline_chunks") v >> pipeline_chunks_;
     });
     {
         int threads = 0;
@@ -149,14 +156,18 @@ HipJpegDecoder::HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgc
         HJ_LOG_ERROR(fw_, kDecoderId, "no usable HIP device " << device_ << " (found " << count << ")");
         return;
     }
-    if (hipSetDevice(device_) != hipSuccess || hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) {
-        HJ_LOG_ERROR(fw_, kDecoderId, "could not create a HIP stream on device " << device_);
+    if (hipSetDevice(device_) != hipSuccess) {
+        HJ_LOG_ERROR(fw_, kDecoderId, "could not select HIP device " << device_);
         return;
     }
     for (auto& j : jobs_) {
         j.reset(new Job(device_, &hooks_));
         j->owner = this;
-        if (hipEventCreateWithFlags(&j->event, hipEventDisableTiming) != hipSuccess) return;
+        if (hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&j->event, hipEventDisableTiming) != hipSuccess) {
+            HJ_LOG_ERROR(fw_, kDecoderId, "could not create a HIP stream on device " << device_);
+            return;
+        }
     }
     ok_ = true;
 }
@@ -168,15 +179,13 @@ HipJpegDecoder::~HipJpegDecoder()
         std::unique_lock<std::mutex> lk(j->m);
         j->cv.wait(lk, [&] { return !j->busy; });
     }
-    if (stream_) {
-        (void)hipSetDevice(device_);
-        (void)hipStreamSynchronize(stream_);
-    }
+    (void)hipSetDevice(device_);
     for (auto& j : jobs_) {
+        if (j && j->stream) (void)hipStreamSynchronize(j->stream);
         if (j && j->event) (void)hipEventDestroy(j->event);
+        if (j && j->stream) (void)hipStreamDestroy(j->stream);
         j.reset();
     }
-    if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 // What the geometry pass has to do for one sample.  Returns bit 0: the region cannot be used, bit 1: the orientation is not
@@ -340,6 +349,7 @@ void HipJpegDecoder::finish(Job* job)
     const int n = (int)job->samples.size();
     bool gpu_ok = hipSetDevice(device_) == hipSuccess;
     job->batch.finalize(job->statuses.data());
+    hipStream_t stream_ = job->stream;
     if (gpu_ok) gpu_ok = job->batch.transfer(stream_) == HIPJPEG_STATUS_SUCCESS;
     if (gpu_ok) gpu_ok = job->batch.launch(stream_) == HIPJPEG_STATUS_SUCCESS;
     // GPU-decoded streams: their verdicts come back from the device (blocks; the other job page keeps the host stage of
@@ -369,16 +379,33 @@ void HipJpegDecoder::finish(Job* job)
     job->cv.notify_all();
 }
 
+// A large batch is cut into up to three pieces, each a job of its own (own page, own stream): the host stage and the H2D copy of
+// one piece run beside the kernels of the piece before it, exactly as they do between consecutive decode() calls.  Samples
+// report through imageReady piece by piece.
 nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_streams, nvimgcodecImageDesc_t** images, int batch_size,
                                           const nvimgcodecDecodeParams_t* params)
 {
     if (!code_streams || !images || !params) return NVIMGCODEC_STATUS_EXTENSION_INVALID_PARAMETER;
     if (batch_size < 1) return NVIMGCODEC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> serial(decode_mutex_);
+    int chunks = pipeline_chunks_ > 0 ? pipeline_chunks_ : (batch_size >= 192 ? 3 : batch_size >= 96 ? 2 : 1);
+    chunks = std::max(1, std::min(chunks, std::min(batch_size, kJobPages)));
+    nvimgcodecStatus_t result = NVIMGCODEC_STATUS_SUCCESS;
+    for (int c = 0; c < chunks; c++) {
+        const int lo = (int)((long long)batch_size * c / chunks), hi = (int)((long long)batch_size * (c + 1) / chunks);
+        const nvimgcodecStatus_t st = decode_chunk(code_streams + lo, images + lo, hi - lo, params);
+        if (st != NVIMGCODEC_STATUS_SUCCESS) result = st;  // that piece's samples have been reported failed; the others go on
+    }
+    return result;
+}
+
+nvimgcodecStatus_t HipJpegDecoder::decode_chunk(nvimgcodecCodeStreamDesc_t** code_streams, nvimgcodecImageDesc_t** images, int batch_size,
+                                                const nvimgcodecDecodeParams_t* params)
+{
     static const bool timing = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;  // debug aid: phase times of decode() on stderr
     const auto t_enter = std::chrono::steady_clock::now();
-    std::lock_guard<std::mutex> serial(decode_mutex_);
     Job* job = jobs_[next_job_].get();
-    next_job_ ^= 1;
+    next_job_ = (next_job_ + 1) % kJobPages;
     {
         std::unique_lock<std::mutex> lk(job->m);
         job->cv.wait(lk, [&] { return !job->busy; });

@@ -7,7 +7,7 @@ from nvimagecodec_amd import api
 src, _ = bench.make_inputs()
 B = 256
 jpegs = [src[i % len(src)] for i in range(B)]
-for opts in ("", ":hipjpeg_decoder:gpu_huffman=0"):
+for opts in ("", "hipjpeg_decoder:pipeline_chunks=1", "hipjpeg_decoder:pipeline_chunks=2", "hipjpeg_decoder:gpu_huffman=0"):
     with api.Decoder(max_num_cpu_threads=bench.usable_cpus(), options=opts) as dec:
         imgs = dec.decode(jpegs)
         torch.cuda.synchronize()
