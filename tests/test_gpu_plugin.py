@@ -269,6 +269,30 @@ def test_many_batches_back_to_back_reuse_pages(torch_mod):
                 assert np.array_equal(im.cpu()._array, c[1]), (rep, e["name"])
 
 
+@pytest.mark.parametrize("options,count", [("hipjpeg_decoder:pipeline_chunks=3", 7), ("", 200), ("hipjpeg_decoder:pipeline_chunks=1", 100)])
+def test_large_batches_are_cut_into_pipelined_pieces(torch_mod, options, count):
+    """The plugin cuts a large batch into up to three jobs (own page, own stream) -- by size, or as the option says.  Whatever
+    the cut: every sample reports once, results keep their order, a corrupt file in the middle fails alone."""
+    from nvimagecodec_amd import api
+    entries = [e for e in _M["decode"] if e["pixels"]][:20]
+    cases = [load_decode_case(e) for e in entries]
+    jpegs = [cases[i % len(cases)][0] for i in range(count)]
+    bad = count // 2
+    broken = bytearray(jpegs[bad])
+    broken[len(broken) // 2:] = b""   # truncated: not even an EOI
+    jpegs[bad] = bytes(broken[:200])
+    with api.Decoder(max_num_cpu_threads=6, options=options) as dec:
+        for rep in range(2):
+            imgs = dec.decode(jpegs)
+            torch_mod.cuda.synchronize()
+            assert len(imgs) == count
+            for i, im in enumerate(imgs):
+                if i == bad:
+                    assert im is None
+                else:
+                    assert im is not None and np.array_equal(im.cpu()._array, cases[i % len(cases)][1]), (rep, i)
+
+
 def test_python_encoder_mirror_through_plugin(torch_mod):
     """Encoder.encode -> nvimgcodecEncoderEncode -> hipjpeg_encoder plugin -> HIP kernel + host Huffman -> host-memory code stream.
     Bitstream must equal the oracle's (== libjpeg-turbo's scan for these settings)."""
