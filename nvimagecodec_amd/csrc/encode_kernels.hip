@@ -432,7 +432,8 @@ __device__ __forceinline__ u32x4 gather_zigzag_piece(const lds_char* slot, const
 constexpr int kPairSlotStride = 144;  // 128 B block + 16 B pad
 
 template <int HS, int VS>
-__global__ __launch_bounds__(kThreads, HJ_PAIR_WAVES) void forward_pair_kernel(const EncodeImage* __restrict__ images, const EncodeUnit* __restrict__ units)
+// (4:4:4: the full-resolution chroma tile limits it to three waves per SIMD)
+__global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forward_pair_kernel(const EncodeImage* __restrict__ images, const EncodeUnit* __restrict__ units)
 {
     constexpr int kChromaW = kTileBX * 8 / HS, kChromaH = kTileBY * 8 / VS;  // downsampled chroma tile
     __shared__ __attribute__((aligned(16))) char lds_slots[4 * 32 * kPairSlotStride];             // 18,432 B

@@ -638,14 +638,14 @@ __global__ __launch_bounds__(kThreads) void huff_scan_kernel(HuffImage* __restri
 // ---- write pass, step 1: where the blocks start -----------------------------------------------------------------------------
 // Same workgroup shape as the sync kernel (lane 0 idles): every lane walks its subsequence from the converged start state
 // and records the bit position of each block that starts inside it.
-__global__ __launch_bounds__(kThreads) void huff_pos_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+__global__ __launch_bounds__(kThreads) void huff_pos_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
                                                             const unsigned long long* __restrict__ states, const uint32_t* __restrict__ first_block)
 {
     __shared__ WgShared sh;
     extern __shared__ uint16_t dyn_pool[];
     HJ_LDS uint16_t* pool = (HJ_LDS uint16_t*)dyn_pool;
     const HuffUnit u = units[blockIdx.x];
-    const HuffImage& im = images[u.image];
+    HuffImage& im = images[u.image];
     const HuffGeom geom = make_geom(im);
     const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
     if (u.first >= nsub) return;
@@ -672,9 +672,11 @@ __global__ __launch_bounds__(kThreads) void huff_pos_kernel(const HuffImage* __r
     auto rec = [&](uint32_t block, uint32_t pos) {
         if (block < total_blocks) out[block] = pos;
     };
-    if (rst)
-        position_subsequence<true>(geom, env, begin, (j + 1) * kSubseqBits, z, k, first_block[im.first_subseq + j], rec, boundary0_of(im, j));
-    else
+    if (rst) {
+        uint32_t fault = 0;
+        position_subsequence<true>(geom, env, begin, (j + 1) * kSubseqBits, z, k, first_block[im.first_subseq + j], rec, boundary0_of(im, j), &fault);
+        if (fault) im.status = 1;  // damaged restart interval: the host decoder takes the image (benign race: same value)
+    } else
         position_subsequence<false>(geom, env, begin, (j + 1) * kSubseqBits, z, k, first_block[im.first_subseq + j], rec);
 }
 
@@ -792,7 +794,13 @@ __global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __res
             if (b < nblocks) {
                 const uint32_t my = mcu / geom.mcus_x, mx = mcu - my * geom.mcus_x;
                 dst = env.block_ptr((int)k, mx, my);
-                const int dc = decode_block(geom, env, im.block_pos[b], (int)k, &err);
+                const uint32_t bpos = im.block_pos[b];
+                // restart intervals: the first block of interval j+1 starts exactly at boundary j -- anything else means
+                // the trajectory went through a damaged interval (the host decoder takes the image and names the error)
+                if (geom.interval_blocks != 0 && k == 0 && b != 0 && b % geom.interval_blocks == 0 &&
+                    bpos != load_boundary(geom.boundaries, geom.num_boundaries, b / geom.interval_blocks - 1))
+                    err = 1;
+                const int dc = decode_block(geom, env, bpos, (int)k, &err);
                 ((HJ_GLOBAL int16_t*)geom.dc_diff)[b] = (int16_t)dc;
             }
         }

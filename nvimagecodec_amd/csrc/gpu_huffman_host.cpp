@@ -295,11 +295,17 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
         auto rec = [&](uint32_t block, uint32_t pos) {
             if (block < im.total_blocks) block_pos[block] = pos;
         };
-        if (rst)
-            position_subsequence<true>(geom, env, begin, (i + 1) * kSubseqBits, z, k, first_block[i], rec, 0);
-        else
+        if (rst) {
+            uint32_t fault = 0;
+            position_subsequence<true>(geom, env, begin, (i + 1) * kSubseqBits, z, k, first_block[i], rec, 0, &fault);
+            if (fault) return 1;
+        } else
             position_subsequence<false>(geom, env, begin, (i + 1) * kSubseqBits, z, k, first_block[i], rec);
     }
+    // restart intervals: the first block of interval j+1 starts exactly at boundary j (see huff_blocks_kernel)
+    if (geom.interval_blocks)
+        for (uint32_t j = 0; j < im.num_boundaries && (uint64_t)(j + 1) * geom.interval_blocks < im.total_blocks; j++)
+            if (block_pos[(j + 1) * geom.interval_blocks] != im.boundaries[j]) return 1;
     // step 2: every block on its own
     for (uint32_t b = 0; b < im.total_blocks; b++) {
         if (block_pos[b] == 0xFFFFFFFFu) return 2;

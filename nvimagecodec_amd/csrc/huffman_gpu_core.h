@@ -126,6 +126,7 @@ struct HuffGeom {
     int16_t* dc_diff;
     const uint32_t* boundaries;
     uint32_t num_boundaries;
+    uint32_t interval_blocks;  // blocks per restart interval (0: the scan has none)
 };
 HJ_HD HuffGeom make_geom(const HuffImage& im)
 {
@@ -137,6 +138,7 @@ HJ_HD HuffGeom make_geom(const HuffImage& im)
     g.dc_diff = im.dc_diff;
     g.boundaries = im.boundaries;
     g.num_boundaries = im.num_boundaries;
+    g.interval_blocks = im.restart_interval * im.blocks_per_mcu;
     return g;
 }
 
@@ -190,12 +192,15 @@ struct RestartCursor {
         bound = env.boundary(index);
         while (bound < pos) bound = env.boundary(++index);
     }
-    // returns true when pos/z/k were changed (the caller restarts its bit reader and reloads its table selection)
+    // returns true when pos/z/k were changed (the caller restarts its bit reader and reloads its table selection).
+    // *overrun (optional) is set when the decoder had already read past the boundary: on the true trajectory of an intact
+    // stream an interval ends exactly at its boundary, so this only happens to damaged data.
     template <class Env>
-    HJ_HD bool normalise(const Env& env, uint32_t hi_bits, uint32_t* pos, int* z, int* k)
+    HJ_HD bool normalise(const Env& env, uint32_t hi_bits, uint32_t* pos, int* z, int* k, uint32_t* overrun = nullptr)
     {
         if (*pos >= bound) {
             const bool changed = *pos != bound || *z != 0 || *k != 0;
+            if (overrun && *pos != bound) *overrun = 1;
             *pos = bound;
             *z = 0;
             *k = 0;
@@ -282,8 +287,11 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
 // progress at `begin` (the scan's prefix sum of completed blocks).
 template <bool RST, class Env, class Rec>
 HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, uint32_t block0, const Rec& rec,
-                                uint32_t boundary0 = 0)
+                                uint32_t boundary0 = 0, uint32_t* fault = nullptr)
 {
+    // Restart intervals are also where damage shows (the host decoder demands the marker exactly where an interval's last
+    // MCU ends): *fault is set when a boundary is met with a block count other than (boundary number + 1) x blocks per interval,
+    // or after the decoder has read past it.
     uint32_t pos = begin, block = block0;
     const uint32_t end = limit < im.total_bits ? limit : im.total_bits;
     const int bpm = (int)im.blocks_per_mcu;
@@ -295,12 +303,14 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
     RestartCursor rc;
     if (RST) {
         rc.start(env, boundary0, pos);
-        if (rc.normalise(env, br.hi, &pos, &z, &k)) {
+        const uint32_t met = rc.index;
+        if (rc.normalise(env, br.hi, &pos, &z, &k, fault)) {
             tsel = env.tables(k);
             tcur = tsel & 0xFFFFu;
             br.start(env, pos);
             fresh = true;
         }
+        if (fault && rc.index != met && block != (met + 1) * im.interval_blocks) *fault = 1;
     }
     while (pos < end) {
         if (fresh) {
@@ -321,10 +331,14 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
             tsel = env.tables(k);
             tcur = tsel & 0xFFFFu;
             fresh = true;
-            if (RST && k == 0 && rc.normalise(env, br.hi, &pos, &z, &k)) {
-                tsel = env.tables(k);
-                tcur = tsel & 0xFFFFu;
-                br.start(env, pos);
+            if (RST && k == 0) {
+                const uint32_t met = rc.index;
+                if (rc.normalise(env, br.hi, &pos, &z, &k, fault)) {
+                    tsel = env.tables(k);
+                    tcur = tsel & 0xFFFFu;
+                    br.start(env, pos);
+                }
+                if (fault && rc.index != met && block != (met + 1) * im.interval_blocks) *fault = 1;
             }
         }
     }

@@ -148,6 +148,30 @@ def test_randomly_damaged_streams_never_disagree_with_the_host_path(dec):
     assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(bases[0]))
 
 
+def test_damaged_restart_intervals_are_handed_to_the_host_decoder(dec):
+    """Found by tools/fuzz_damage.py: inside a damaged restart interval the walk of the GPU stage can cross the next boundary
+    in the middle of an MCU and look healthy again one interval later (the block count happens to add up).  The invariant it
+    now checks: the first block of every interval starts exactly at its boundary, and no walk reads past a boundary.  The
+    three streams below used to decode "successfully" on the GPU while the host entropy decoder rejects them."""
+    import torch
+    b7 = oracle.encode(synth_image(400, 300, seed=5), "420", 85, restart_interval=7)
+    b1 = oracle.encode(synth_image(333, 222, seed=7), "420", 30, restart_interval=1)
+    patched = bytearray(b7)
+    patched[10574:10574 + 19] = bytes.fromhex("15995f381651ef13b8d8206e808f6cc4a8f1cb")
+    flipped = bytearray(b1)
+    flipped[1992], flipped[2394] = 196, 112
+    cut = b1[:3601] + b1[3607:]
+    jpegs = [bytes(patched), bytes(flipped), bytes(cut), b7, b1]
+    outs = dec.allocate_outputs(jpegs)
+    _, st_gpu = dec.decode(jpegs, outs=outs, gpu_huffman=True, check=False)
+    torch.cuda.synchronize()
+    good = [o.cpu().numpy().copy() for o in outs[3:]]
+    _, st_cpu = dec.decode(jpegs, outs=outs, gpu_huffman=False, check=False)
+    torch.cuda.synchronize()
+    assert list(st_gpu) == list(st_cpu) and all(s != 0 for s in st_gpu[:3]) and st_gpu[3] == 0 and st_gpu[4] == 0
+    assert np.array_equal(good[0], oracle.decode(b7)) and np.array_equal(good[1], oracle.decode(b1))
+
+
 def test_pipelined_submit_wait_with_three_batches_in_flight(dec):
     """hipjpegDecodeBatchSubmit / Wait: results come back in submission order, identical to the one-shot path, also when a
     batch carries a stream the kernels have to hand back to the host decoder and when batches mix both entropy stages."""

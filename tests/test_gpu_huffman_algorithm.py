@@ -80,3 +80,21 @@ def test_restart_intervals(interval):
         coefs, passes = lowlevel.entropy_decode_gpu_algorithm_host(jpeg)
         ref, _ = oracle.decode_coefficients(jpeg)
         assert all(np.array_equal(a, b) for a, b in zip(coefs, ref)), (w, h, sub, interval)
+
+
+def test_damaged_restart_intervals_are_reported():
+    """CPU twin of tests/test_gpu_huffman.py::test_damaged_restart_intervals_are_handed_to_the_host_decoder: the kernels' own
+    walk routines must notice a trajectory that crossed a restart boundary inside an MCU."""
+    b7 = oracle.encode(synth_image(400, 300, seed=5), "420", 85, restart_interval=7)
+    b1 = oracle.encode(synth_image(333, 222, seed=7), "420", 30, restart_interval=1)
+    patched = bytearray(b7)
+    patched[10574:10574 + 19] = bytes.fromhex("15995f381651ef13b8d8206e808f6cc4a8f1cb")
+    flipped = bytearray(b1)
+    flipped[1992], flipped[2394] = 196, 112
+    for bad in (bytes(patched), bytes(flipped), b1[:3601] + b1[3607:]):
+        with pytest.raises(N.HipJpegError):
+            lowlevel.entropy_decode_gpu_algorithm_host(bad)
+    for good in (b7, b1):
+        coefs, _ = lowlevel.entropy_decode_gpu_algorithm_host(good)
+        ref, _ = oracle.decode_coefficients(good)
+        assert all(np.array_equal(a, b) for a, b in zip(coefs, ref))
