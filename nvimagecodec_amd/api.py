@@ -408,6 +408,9 @@ class Encoder(_ExecMixin):
         n = len(ilist)
         sinks, streams, handles, keep = [], [], [], []
         stream_ptr = cuda_stream or torch.cuda.current_stream(self.device_id).cuda_stream
+        import time as _t
+        _dbg = os.environ.get("HIPJPEG_DEBUG_TIMING")
+        _t0 = _t.perf_counter()
 
         for im in ilist:
             arr = im._array
@@ -457,9 +460,12 @@ class Encoder(_ExecMixin):
         jp = A.init(A.JpegEncodeParams, A.ST_JPEG_ENCODE_PARAMS, optimized_huffman=int(params.jpeg_params.optimized_huffman))
         ep.struct_next = C.addressof(jp)
         fut = C.c_void_p()
+        _t1 = _t.perf_counter()
         _check(lib.nvimgcodecEncoderEncode(self._h, (C.c_void_p * n)(*handles), (C.c_void_p * n)(*streams), n, C.byref(ep), C.byref(fut)),
                "nvimgcodecEncoderEncode")
+        _t2 = _t.perf_counter()
         _check(lib.nvimgcodecFutureWaitForAll(fut), "nvimgcodecFutureWaitForAll")
+        _t3 = _t.perf_counter()
         st = (C.c_uint32 * n)()
         size = C.c_size_t()
         lib.nvimgcodecFutureGetProcessingStatus(fut, st, C.byref(size))
@@ -467,7 +473,10 @@ class Encoder(_ExecMixin):
         res = []
         for i in range(n):
             ok = st[i] == A.PS_SUCCESS and sinks[i]["buf"] is not None
-            res.append(bytes(sinks[i]["buf"].raw[: sinks[i]["size"]]) if ok else None)
+            res.append(C.string_at(sinks[i]["buf"], sinks[i]["size"]) if ok else None)
             lib.nvimgcodecImageDestroy(handles[i])
             lib.nvimgcodecCodeStreamDestroy(streams[i])
+        if _dbg:
+            _t4 = _t.perf_counter()
+            print("[api] encode setup %.2f ms, EncoderEncode %.2f ms, wait %.2f ms, collect %.2f ms" % ((_t1 - _t0) * 1e3, (_t2 - _t1) * 1e3, (_t3 - _t2) * 1e3, (_t4 - _t3) * 1e3), file=sys.stderr)
         return res[0] if single else res
