@@ -2,7 +2,7 @@
 entropy stage must reach the same verdict as the host entropy stage, identical pixels where both decode, and no kernel may
 fault or hang.  (tests/test_gpu_huffman.py holds a fixed-seed version of this.)"""
 import sys, os, random, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import oracle
 from nvimagecodec_amd.lowlevel import BatchDecoder

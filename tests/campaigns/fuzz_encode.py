@@ -3,7 +3,7 @@ pitches), every sampling, restart intervals, qualities 1..100 -- bitstreams must
 per-image optimized Huffman tables (which the oracle does not write) the decoded pixels must equal the decode of the
 oracle's standard-table stream (same coefficients)."""
 import sys, os, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import oracle
 from nvimagecodec_amd.lowlevel import BatchEncoder

@@ -1,8 +1,8 @@
 """Random regions of interest x EXIF orientations x image widths around the tile boundaries (dev tool, GPU box): the geometry
 pass on top of the tiled luma kernel must give exactly the oracle's full decode, cropped and turned with numpy."""
 import sys, os, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import oracle
 from nvimagecodec_amd.lowlevel import BatchDecoder

@@ -4,7 +4,7 @@ restart interval / Huffman tables through independent routes of the product, whi
   encode: two-lanes-per-block kernel (8-byte-aligned input) vs one-lane-per-block kernel (same pixels, misaligned base),
           GPU entropy coder vs host entropy coder; a sample also against the CPU oracle."""
 import sys, os, random, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import oracle
 from nvimagecodec_amd.lowlevel import BatchDecoder, BatchEncoder

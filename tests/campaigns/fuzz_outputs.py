@@ -3,7 +3,7 @@ outputs with arbitrary pitch and offset, checked against the oracle INCLUDING th
 the image rows may be written) -- the staged 16-byte store path, the direct 8-byte path and the byte path of the luma kernel,
 wide and narrow tiles."""
 import sys, os, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import oracle
 from nvimagecodec_amd.lowlevel import BatchDecoder

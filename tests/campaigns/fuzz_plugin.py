@@ -2,7 +2,7 @@
 pipelining, corrupt files sprinkled in, decoder options; every good sample must equal the oracle, every corrupt one must come
 back as None, order preserved."""
 import sys, os, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import oracle
 from nvimagecodec_amd import api

@@ -1,6 +1,6 @@
 """Ad-hoc timing of the decode phases with the GPU entropy stage (dev tool)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import oracle
 from nvimagecodec_amd.lowlevel import BatchDecoder

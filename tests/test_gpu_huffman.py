@@ -149,7 +149,7 @@ def test_randomly_damaged_streams_never_disagree_with_the_host_path(dec):
 
 
 def test_damaged_restart_intervals_are_handed_to_the_host_decoder(dec):
-    """Found by tools/fuzz_damage.py: inside a damaged restart interval the walk of the GPU stage can cross the next boundary
+    """Found by tests/campaigns/fuzz_damage.py: inside a damaged restart interval the walk of the GPU stage can cross the next boundary
     in the middle of an MCU and look healthy again one interval later (the block count happens to add up).  The invariant it
     now checks: the first block of every interval starts exactly at its boundary, and no walk reads past a boundary.  The
     three streams below used to decode "successfully" on the GPU while the host entropy decoder rejects them."""
