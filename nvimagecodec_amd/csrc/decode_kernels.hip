@@ -99,9 +99,10 @@ __device__ __forceinline__ void idct8(int (&d)[8])
 
 __device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }  // v_med3_i32
 
-// a * k + c on the full-rate 24-bit multiplier.  hipcc rewrites __mul24 of provably small operands into a plain 32-bit
-// multiply and then selects the quarter-rate v_mul_lo_u32 (seen in the ISA: 130 of them per lane in the colour stage), so
-// the colour arithmetic pins the instruction.  |a| < 2^8 and |k| < 2^17 here: exact.
+// a * k + c in ONE instruction.  hipcc rewrites __mul24 of provably small operands into a plain 32-bit multiply and then emits
+// v_mul_lo_u32 + v_add (seen in the ISA: 130 of them per lane in the colour stage); there is no 32-bit integer mad, so the
+// colour arithmetic pins the 24-bit one.  (v_mul_lo_u32 itself is not slow on gfx950 -- tools/valu_rate.hip -- the saving is
+// the fused add.)  |a| < 2^8 and |k| < 2^17 here: exact.
 __device__ __forceinline__ int mad24(int a, int k, int c)
 {
     int r;
