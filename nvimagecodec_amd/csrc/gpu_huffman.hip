@@ -84,6 +84,10 @@ struct DevEnv {
     {
         return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0x1FFu) << 7) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
     }
+    __device__ __forceinline__ uint32_t lookup_pair(uint32_t t, uint32_t w) const  // lookup1's address + a constant: one more LDS read, no more arithmetic
+    {
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + t + 2 * kPairOffset + ((w >> (31 - kHuffFastBits)) & ((2u << kHuffFastBits) - 2)));
+    }
 };
 
 __device__ __forceinline__ uint32_t boundary0_of(const HuffImage& im, uint32_t subseq)
@@ -509,6 +513,10 @@ struct TailEnv {
     __device__ __forceinline__ uint32_t lookup2(uint32_t e, uint32_t w) const
     {
         return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0x1FFu) << 7) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
+    }
+    __device__ __forceinline__ uint32_t lookup_pair(uint32_t t, uint32_t w) const  // lookup1's address + a constant: one more LDS read, no more arithmetic
+    {
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + t + 2 * kPairOffset + ((w >> (31 - kHuffFastBits)) & ((2u << kHuffFastBits) - 2)));
     }
 };
 

@@ -81,7 +81,7 @@ size_t table_words(const HuffSpec& s, bool is_dc)
 {
     if (!s.present) return 0;
     std::vector<uint8_t> has_sub(1u << kHuffFastBits, 0);
-    size_t words = 1u << kHuffFastBits;
+    size_t words = (1u << kHuffFastBits) + (is_dc ? 0u : kPairOffset);  // AC: first level + pair table
     bool bad = false;
     bool ok = for_each_code(s, [&](int l, uint32_t code, uint8_t sym) {
         if (is_dc && sym > 15) bad = true;
@@ -101,7 +101,7 @@ size_t expand_table(const HuffSpec& s, bool is_dc, uint16_t* pool, size_t base)
 {
     uint16_t* first = pool + base;
     for (int i = 0; i < (1 << kHuffFastBits); i++) first[i] = (uint16_t)kEntryInvalid;
-    size_t used = 1u << kHuffFastBits;
+    size_t used = (1u << kHuffFastBits) + (is_dc ? 0u : kPairOffset);
     for_each_code(s, [&](int l, uint32_t code, uint8_t sym) {
         const uint32_t nb = sym & 15u, run = sym >> 4;
         // DC: the symbol is the size category.  AC: (run, size); size 0 is EOB except for run 15 (ZRL, 16 zeros) -- libjpeg
@@ -123,6 +123,18 @@ size_t expand_table(const HuffSpec& s, bool is_dc, uint16_t* pool, size_t base)
             for (uint32_t j = 0; j < (1u << (16 - l)); j++) sub[lo + j] = e;
         }
     });
+    if (!is_dc) {
+        // pair table (huffman_gpu_core.h): window w = a first symbol of t1 bits and, in the 10 - t1 bits behind it, a whole second one
+        uint16_t* pair = first + kPairOffset;
+        for (uint32_t w = 0; w < (1u << kHuffFastBits); w++) {
+            pair[w] = 0;
+            const uint32_t e1 = first[w], t1 = e1 & 31u, z1 = e1 >> 9;
+            if (e1 == kEntryInvalid || z1 == kZadvLong || z1 == 64u || t1 + 2 > (uint32_t)kHuffFastBits) continue;
+            const uint32_t e2 = first[(w << t1) & ((1u << kHuffFastBits) - 1)], t2 = e2 & 31u, z2 = e2 >> 9;
+            if (e2 == kEntryInvalid || z2 == kZadvLong || t1 + t2 > (uint32_t)kHuffFastBits) continue;
+            pair[w] = (uint16_t)make_pair_entry(t1 + t2, z2 == 64u ? 63u : z1 + z2, 64u - z1);
+        }
+    }
     return used;
 }
 
@@ -155,13 +167,18 @@ void build_gpu_pool(const ScanHeader& sc, HuffImage* im, uint16_t* pool)
     size_t dc_off[4] = {0, 0, 0, 0}, ac_off[4] = {0, 0, 0, 0};
     bool dc_seen[4] = {false, false, false, false}, ac_seen[4] = {false, false, false, false};
     size_t used = 0;
+    // DC tables first, AC tables behind them: the walkers read the pair-table slot (kPairOffset entries behind the first level)
+    // of whatever table they are at -- behind a DC table that is some other table's entries, ignored, but inside the pool
     for (int i = 0; i < sc.ncomp; i++) {
-        const int td = sc.td[i], ta = sc.ta[i];
+        const int td = sc.td[i];
         if (!dc_seen[td]) {
             dc_seen[td] = true;
             dc_off[td] = used;
             used += expand_table(sc.dc[td], true, pool, used);
         }
+    }
+    for (int i = 0; i < sc.ncomp; i++) {
+        const int ta = sc.ta[i];
         if (!ac_seen[ta]) {
             ac_seen[ta] = true;
             ac_off[ta] = used;
@@ -217,6 +234,11 @@ struct HostEnv {
     uint32_t boundary(uint32_t i) const { return i < im->num_boundaries ? im->boundaries[i] : 0xFFFFFFFFu; }
     uint32_t lookup1(uint32_t t, uint32_t w) const { return im->pool[t + (w >> (32 - kHuffFastBits))]; }
     uint32_t lookup2(uint32_t e, uint32_t w) const { return im->pool[(e & 0x1FFu) * 64u + ((w >> 16) & ((1u << kHuffSubBits) - 1))]; }
+    uint32_t lookup_pair(uint32_t t, uint32_t w) const
+    {
+        const size_t i = (size_t)t + kPairOffset + (w >> (32 - kHuffFastBits));
+        return i < im->pool_words ? im->pool[i] : 0u;  // (behind the last DC table there may be nothing)
+    }
     uint32_t tables(int k) const { return (uint32_t)im->k[k].tdc | ((uint32_t)im->k[k].tac << 16); }
     int16_t* block_ptr(int k, uint32_t mx, uint32_t my) const
     {

@@ -53,6 +53,15 @@ constexpr int kMaxPoolWords = 12288;   // uint16 entries of lookup tables per im
 // the next kHuffSubBits bits: it trips the same "position past 63" test as the end of a block, so the common path has one
 // test for both.  "No such code" is total = 1, nb = 15 (impossible for a real symbol), zadv = 1.
 HJ_HD constexpr uint32_t make_entry(uint32_t total, uint32_t nb, uint32_t zadv) { return total | (nb << 5) | (zadv << 9); }
+// PAIR table of an AC table (directly behind its first level, same index): the walks that only track positions -- the
+// synchronisation passes and the position pass, 2/3 of the stage's time -- take two AC symbols per step where the window holds
+// both completely (half of all steps on a q90 photo).  Entry: bits 0-3 = bits of both symbols together (<= kHuffFastBits),
+// bits 4-9 = zigzag advance of both (63 when the second one is EOB: enough to end any block from an AC position), bits 10-15 =
+// the zigzag positions from which the pair may be taken: z < that many, i.e. 64 - the first symbol's own advance, so that the
+// first symbol keeps the block open; 0 = no pair here (first symbol EOB / long code / no second symbol in the window).  The
+// walker also wants the second symbol to start inside its range -- then the result is exactly that of two single steps.
+constexpr uint32_t kPairOffset = 1u << kHuffFastBits;  // entries between an AC table's first level and its pair table
+HJ_HD constexpr uint32_t make_pair_entry(uint32_t total, uint32_t zadv, uint32_t z_below) { return total | (zadv << 4) | (z_below << 10); }
 constexpr uint32_t kEntryInvalid = 1u | (15u << 5) | (1u << 9);
 constexpr uint32_t kZadvLong = 127;
 
@@ -225,12 +234,15 @@ struct RestartCursor {
 //                                        unit lookup1 wants
 //   uint32_t lookup1(uint32_t t, w)      first-level entry of table t for window w (index = top kHuffFastBits bits)
 //   uint32_t lookup2(uint32_t e, w)      second-level entry behind first-level entry e (index = next kHuffSubBits bits)
+//   uint32_t lookup_pair(uint32_t t, w)  pair-table entry of table t for window w (same index as lookup1, kPairOffset entries on)
 // RST: the scan has restart intervals; boundary0 = index of the first boundary at or behind the subsequence's first bit.
 template <bool RST, class Env>
 HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_t begin, uint32_t limit, int z, int k, uint32_t boundary0 = 0)
 {
     uint32_t pos = begin, nblocks = 0;
     const uint32_t end = limit < im.total_bits ? limit : im.total_bits;
+    // a pair's first symbol has at most kHuffFastBits - 2 bits: from here on the second one might start outside the range
+    const uint32_t pair_end = end > (uint32_t)kHuffFastBits - 2 ? end - ((uint32_t)kHuffFastBits - 2) : 0;  // pos + 8 < end
     const int bpm = (int)im.blocks_per_mcu;
     uint32_t tsel = env.tables(k);
     uint32_t tcur = z == 0 ? (tsel & 0xFFFFu) : (tsel >> 16);  // table of the next symbol: DC at the start of a block, AC after it
@@ -249,13 +261,17 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
     while (pos < end) {
         const uint32_t fetched = env.word(br.next);
         uint32_t e = env.lookup1(tcur, br.hi);
+        const uint32_t pr = env.lookup_pair(tcur, br.hi);  // means something behind an AC table only (z != 0)
+        const bool two = z != 0 && (uint32_t)z < (pr >> 10) && pos < pair_end;
+        uint32_t tot = two ? (pr & 15u) : (e & 31u);
         tcur = tsel >> 16;
-        z += (int)(e >> 9);
+        z += two ? (int)((pr >> 4) & 63u) : (int)(e >> 9);
         bool mcu_done = false;
         if (z >= 64) {  // end of a block, or a code that continues in a second-level table
-            if ((e >> 9) == kZadvLong) {
+            if (!two && (e >> 9) == kZadvLong) {
                 e = env.lookup2(e, br.hi);
                 z += (int)(e >> 9) - (int)kZadvLong;
+                tot = e & 31u;
             }
             if (z >= 64) {
                 z = 0;
@@ -266,8 +282,8 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
                 mcu_done = k == 0;
             }
         }
-        pos += e & 31u;
-        br.consume(e & 31u, fetched);
+        pos += tot;
+        br.consume(tot, fetched);
         if (RST && mcu_done && rc.normalise(env, br.hi, &pos, &z, &k)) {
             tsel = env.tables(k);
             tcur = tsel & 0xFFFFu;
@@ -294,6 +310,7 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
     // or after the decoder has read past it.
     uint32_t pos = begin, block = block0;
     const uint32_t end = limit < im.total_bits ? limit : im.total_bits;
+    const uint32_t pair_end = end > (uint32_t)kHuffFastBits - 2 ? end - ((uint32_t)kHuffFastBits - 2) : 0;  // see decode_subsequence
     const int bpm = (int)im.blocks_per_mcu;
     uint32_t tsel = env.tables(k);
     uint32_t tcur = z == 0 ? (tsel & 0xFFFFu) : (tsel >> 16);
@@ -319,10 +336,13 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
         }
         const uint32_t fetched = env.word(br.next);
         uint32_t e = env.lookup1(tcur, br.hi);
-        if ((e >> 9) == kZadvLong) e = env.lookup2(e, br.hi);
-        pos += e & 31u;
-        br.consume(e & 31u, fetched);
-        z += (int)(e >> 9);
+        const uint32_t pr = env.lookup_pair(tcur, br.hi);
+        const bool two = z != 0 && (uint32_t)z < (pr >> 10) && pos < pair_end;
+        if (!two && (e >> 9) == kZadvLong) e = env.lookup2(e, br.hi);
+        const uint32_t tot = two ? (pr & 15u) : (e & 31u);
+        pos += tot;
+        br.consume(tot, fetched);
+        z += two ? (int)((pr >> 4) & 63u) : (int)(e >> 9);
         tcur = tsel >> 16;
         if (z >= 64) {
             z = 0;
