@@ -218,6 +218,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The phases above (host entropy stage, H2D) leave the GPU idle long enough for its clocks to drop; the timed steps are
+    # meant to measure steady-state kernels, so the clocks are brought back up first -- untimed, disclosed as `prewarm_steps`.
+    PREWARM_STEPS = 60
+    for _ in range(PREWARM_STEPS):
+        dec.device_stage()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         dec.device_stage()
     # ---- timed region: exactly K steps
@@ -249,10 +255,11 @@ def main():
     #     Huffman decoding and the device stage all run on the GPU.  First its kernels alone on a resident batch ...
     dec.host_stage(jpegs, outs, "rgb", fancy=True, gpu_huffman=True)
     dec.transfer()
-    dec.device_stage(which=3)
+    for _ in range(6):   # clocks up first (see PREWARM_STEPS)
+        dec.device_stage(which=3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ent_reps = 3
+    ent_reps = 6
     for _ in range(ent_reps):
         dec.device_stage(which=3)   # blocks: ends with the read-back of the per-image verdicts
     t_entropy = (time.perf_counter() - t0) / ent_reps
@@ -286,6 +293,9 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 10
+        for _ in range(40):   # clocks up first (see PREWARM_STEPS)
+            enc.relaunch()
+        torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
             enc.relaunch()
@@ -347,7 +357,7 @@ def main():
         kernel_ms = k1_ms + k2_ms
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_h_hbm_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic.json")
         if os.path.exists(tp):
             try:
                 with open(tp) as f:
@@ -357,7 +367,7 @@ def main():
         line = {
             "metric": "images/sec, batched 1920x1080 4:2:0 baseline JPEG decode to interleaved RGB u8",
             "value": round(value, 1), "unit": "images/s", "mp_per_s": round(value * WIDTH * HEIGHT / 1e6, 1),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM_STEPS, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": data_desc,
             "timed_region": "device stage (coefficient blocks resident in HBM -> RGB in HBM); host Huffman and H2D reported separately",
             "config": {"workload": "configs[1]: batch=256 1920x1080 4:2:0 baseline JPEG -> I_RGB u8, fancy upsampling, ISLOW IDCT",
