@@ -1,6 +1,6 @@
 """Ad-hoc timing of the nvImageCodec-API route (Python surface -> host harness -> plugin).  Dev tool."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench, oracle
 from nvimagecodec_amd import api
