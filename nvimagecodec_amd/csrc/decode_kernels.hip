@@ -40,6 +40,10 @@ constexpr int kBlocksPerWave = 32;     // two lanes per block
 constexpr int kLdsBlockStride = 144;   // 128 B of coefficients + 16 B pad -> conflict-free ds_read_b128 at this lane stride
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+// Explicitly GLOBAL pointers for the hot loads and stores: through the generic pointers of the descriptors hipcc emits FLAT
+// instructions (64-bit address arithmetic per access, and they count against the LDS counter as well).
+#define HJ_GLOBAL __attribute__((address_space(1)))
 
 constexpr int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633;
 constexpr int F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
@@ -166,7 +170,7 @@ __device__ __forceinline__ void fetch_half_block(const DecodeComponent& cd, int 
     const int my_block = wave_first_block + (lane >> 1);
     const bool dc_apart = cd.dc_stride != 64;  // wave-uniform: host-decoded images carry the DC inside the block already
     unsigned dc = 0;
-    if (dc_apart && my_block < block_limit) dc = (unsigned short)cd.dc[my_block];
+    if (dc_apart && my_block < block_limit) dc = ((const HJ_GLOBAL unsigned short*)cd.dc)[my_block];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int g = k * 64 + lane;
@@ -174,7 +178,7 @@ __device__ __forceinline__ void fetch_half_block(const DecodeComponent& cd, int 
 #ifdef HJ_ABLATE_COEF
         if (g < nchunks) v = u32x4{(unsigned)g, 1u, 0u, 0u};
 #else
-        if (g < nchunks) v = __builtin_nontemporal_load(src + g);
+        if (g < nchunks) v = __builtin_nontemporal_load((const HJ_GLOBAL u32x4*)src + g);
 #endif
         *reinterpret_cast<u32x4*>(lds_wave + (g >> 3) * kLdsBlockStride + (g & 7) * 16) = v;
     }
@@ -195,14 +199,16 @@ __device__ __forceinline__ void fetch_tile_half_block(const DecodeComponent& cd,
     unsigned dc = 0;
     {
         const int j = lane >> 1, row = row0 + (j >> row_shift), col = col0 + (j & col_mask);
-        if (dc_apart && row < bh && col < bw) dc = (unsigned short)cd.dc[row * bw + col];
+        if (dc_apart && row < bh && col < bw) dc = *(const HJ_GLOBAL unsigned short*)((const HJ_GLOBAL char*)cd.dc + (unsigned)(row * bw + col) * 2u);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int g = k * 64 + lane, j = g >> 3;
         const int row = row0 + (j >> row_shift), col = col0 + (j & col_mask);
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < bh && col < bw) v = __builtin_nontemporal_load(src + ((size_t)(row * bw + col) * 8 + (g & 7)));
+        // byte offset in 32 bits (a component's blocks are far below 4 GB): SGPR base + VGPR offset addressing
+        if (row < bh && col < bw)
+            v = __builtin_nontemporal_load((const HJ_GLOBAL u32x4*)((const HJ_GLOBAL char*)src + ((unsigned)(row * bw + col) * 128u + (unsigned)(g & 7) * 16u)));
         *reinterpret_cast<u32x4*>(lds_wave + j * kLdsBlockStride + (g & 7) * 16) = v;
     }
     wave_lds_fence();
@@ -334,7 +340,11 @@ __device__ __forceinline__ void load_chroma_rows(const uint8_t* __restrict__ pla
 #ifdef HJ_ABLATE_CHROMA
         v = make_uint2(0x80808080u + (unsigned)(uintptr_t)src, 0x80808080u);
 #else
-        __builtin_memcpy(&v, src, 8);
+        {
+            typedef u32x2 __attribute__((aligned(1))) u32x2_unaligned;  // the window starts at any byte; gfx950 loads it in one go
+            const u32x2 t = *(const HJ_GLOBAL u32x2_unaligned*)src;
+            v = make_uint2(t.x, t.y);
+        }
 #endif
         rows[k] = v;
     }
@@ -619,7 +629,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 #ifdef HJ_ABLATE_STORE
                 if (v.x == 0x12345678u && v.y == 0x9abcdef0u)  // practically never: keeps the value live, drops the traffic
 #endif
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+                __builtin_nontemporal_store(v, (HJ_GLOBAL u32x4*)dst);
             } else {
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
                 for (int j = 0; j < row_bytes - off; j++) dst[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
