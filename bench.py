@@ -357,7 +357,7 @@ def main():
         kernel_ms = k1_ms + k2_ms
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_j_hbm_traffic.json")
         if os.path.exists(tp):
             try:
                 with open(tp) as f:
