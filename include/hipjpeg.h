@@ -40,7 +40,8 @@ typedef enum {
     HIPJPEG_STATUS_ALLOC_FAILED = 6,
     HIPJPEG_STATUS_HIP_ERROR = 7,
     HIPJPEG_STATUS_NO_DEVICE = 8,
-    HIPJPEG_STATUS_BUFFER_TOO_SMALL = 9
+    HIPJPEG_STATUS_BUFFER_TOO_SMALL = 9,
+    HIPJPEG_STATUS_INTERNAL_ERROR = 10   /* a C++ exception was caught at the C boundary (never propagated to the caller) */
 } hipjpegStatus_t;
 
 /* Output pixel layouts; numeric values equal hipjpeg::OutFormat (csrc/device_layout.h). They correspond to
@@ -103,6 +104,13 @@ typedef struct hipjpegHandle* hipjpegHandle_t;
 
 HIPJPEG_API const char* hipjpegStatusString(hipjpegStatus_t status);
 HIPJPEG_API int hipjpegVersion(void);
+/* Test hook (fault injection): the `countdown`-th passage of the named host-code site from now on throws a C++ exception
+ * inside the library, once; site NULL or "" disarms.  Sites: "plan", "entropy_stage", "finalize", "transfer", "launch",
+ * "resolve", "marshal".  The boundary must turn it into a status code / per-sample FAIL; tests/test_gpu_plugin.py relies on it. */
+HIPJPEG_API hipjpegStatus_t hipjpegTestSetFault(const char* site, int countdown);
+/* Test hook: how many times a plugin has reported a sample that had already been reported (must stay 0: exactly one
+ * imageReady per sample, reference src/processing_results.cpp:104-115). Counted by this library's host harness. */
+HIPJPEG_API int hipjpegTestDoubleReports(void);
 
 /* ---- host-only entry points (usable without a GPU) ---- */
 HIPJPEG_API hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t length, hipjpegImageInfo_t* info);

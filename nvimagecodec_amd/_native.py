@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhipjpeg_ext.so")
 
 STATUS_NAMES = {0: "SUCCESS", 1: "INVALID_ARGUMENT", 2: "BAD_JPEG", 3: "UNSUPPORTED", 4: "TRUNCATED", 5: "CORRUPT", 6: "ALLOC_FAILED",
-                7: "HIP_ERROR", 8: "NO_DEVICE", 9: "BUFFER_TOO_SMALL"}
+                7: "HIP_ERROR", 8: "NO_DEVICE", 9: "BUFFER_TOO_SMALL", 10: "INTERNAL_ERROR"}
 
 OUTPUT_RGBI, OUTPUT_BGRI, OUTPUT_RGB_PLANAR, OUTPUT_BGR_PLANAR, OUTPUT_Y, OUTPUT_YUV_PLANAR = range(6)
 FLAG_FANCY_UPSAMPLING = 1
@@ -62,6 +62,7 @@ def load():
     L.hipjpegStatusString.restype = ctypes.c_char_p
     L.hipjpegStatusString.argtypes = [i32]
     L.hipjpegVersion.restype = i32
+    L.hipjpegTestSetFault.argtypes = [ctypes.c_char_p, i32]
     L.hipjpegGetImageInfo.argtypes = [vp, sz, ctypes.POINTER(ImageInfo)]
     L.hipjpegEntropyDecodeHost.argtypes = [vp, sz, vp, sz, vp, vp]
     L.hipjpegEntropyDecodeGpuAlgorithmHost.argtypes = [vp, sz, vp, sz, vp, ctypes.POINTER(ctypes.c_int32)]

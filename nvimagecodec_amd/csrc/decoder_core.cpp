@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "decode_kernels.h"
+#include "diagnostics.h"
 #include "entropy_decode.h"
 #include "gpu_huffman_host.h"
 
@@ -150,12 +151,53 @@ bool choose_variant(const FrameInfo& f, OutFormat fmt, bool fancy, int* variant)
 
 }  // namespace
 
+// Largest frame the decoder takes: the reference's CPU path refuses width x height x components >= 2^29 before it allocates
+// anything (extensions/libjpeg_turbo/jpeg_mem.cpp:183-196), and a forged SOF of a few hundred bytes must not be able to
+// reserve tens of GB of pinned memory for the whole batch.  HIPJPEG_MAX_IMAGE_SAMPLES overrides the bound (tests).
+static uint64_t max_image_samples()
+{
+    static const uint64_t v = [] {
+        const char* e = getenv("HIPJPEG_MAX_IMAGE_SAMPLES");
+        const unsigned long long x = e ? strtoull(e, nullptr, 10) : 0ull;
+        return x ? (uint64_t)x : (uint64_t)1 << 29;
+    }();
+    return v;
+}
+
 hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
                                   hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
                                   const hipjpegOutputFormat_t* formats, ForkJoinPool* pool, const hipjpegTransform_t* transforms)
 {
+    // An allocation that fails costs only the images that made the arenas grow: the biggest remaining image is given up
+    // (ALLOC_FAILED) and the layout is computed again without it.
+    std::vector<char> give_up((size_t)std::max(n, 0), 0);
+    for (int attempt = 0;; attempt++) {
+        const hipjpegStatus_t st = plan_once(data, lengths, n, outputs, format, flags, statuses, formats, pool, transforms, give_up);
+        if (st != HIPJPEG_STATUS_ALLOC_FAILED || attempt >= 16) return st;
+        int worst = -1;
+        size_t worst_bytes = 0;
+        for (int i = 0; i < n; i++) {
+            if (images_[i].status != HIPJPEG_STATUS_SUCCESS) continue;
+            const size_t b = images_[i].frame.total_blocks() * 128 + (size_t)images_[i].frame.width * images_[i].frame.height;
+            if (b >= worst_bytes) {
+                worst_bytes = b;
+                worst = i;
+            }
+        }
+        if (worst < 0) return st;
+        give_up[worst] = 1;
+    }
+}
+
+hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
+                                       hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
+                                       const hipjpegOutputFormat_t* formats, ForkJoinPool* pool, const hipjpegTransform_t* transforms,
+                                       const std::vector<char>& give_up)
+{
     if (n < 0 || (n > 0 && (!data || !lengths || !outputs))) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     if ((int)format < 0 || (int)format > (int)HIPJPEG_OUTPUT_YUV_PLANAR) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    ScopedRange range("hipjpeg plan (parse headers, lay out staging)");
+    fault_point("plan");
     finalized_ = false;
     images_.assign(n, PlannedImage());
     desc_.assign(n, DecodeImage());
@@ -186,6 +228,9 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
         }
         const OutFormat fmt = (OutFormat)(formats ? formats[i] : format);
         im.status = data[i] ? status_from_parse(parse_jpeg(data[i], lengths[i], &im.frame)) : HIPJPEG_STATUS_INVALID_ARGUMENT;
+        if (im.status == HIPJPEG_STATUS_SUCCESS &&
+            ((uint64_t)im.frame.width * (uint64_t)im.frame.height * (uint64_t)im.frame.ncomp >= max_image_samples() || give_up[i]))
+            im.status = HIPJPEG_STATUS_ALLOC_FAILED;  // this image only; its neighbours decode
         if (im.status == HIPJPEG_STATUS_SUCCESS && !choose_variant(im.frame, fmt, fancy, &im.variant)) im.status = HIPJPEG_STATUS_UNSUPPORTED;
         const FrameInfo& f = im.frame;
         const int nplanes_out = (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR || fmt == kOutY) ? 1 : 3;
@@ -212,6 +257,23 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
                     im.has_transform = true;
                     im.transform = t;
                 }
+            }
+        }
+        if (im.status == HIPJPEG_STATUS_SUCCESS) {
+            // rows of the caller's buffer must hold a row of what is written there (nvJPEG checks the pitch for the reference;
+            // here a short pitch would make the kernels write overlapping rows or leave the buffer)
+            int ow = f.width;
+            if (im.has_transform) {
+                const int rw = im.transform.x1 - im.transform.x0, rh = im.transform.y1 - im.transform.y0;
+                ow = im.transform.orientation >= 5 ? rh : rw;
+            }
+            if (fmt == kOutPlanarYUV) {
+                for (int c = 0; c < f.ncomp; c++)
+                    if (outputs[i].pitch[c] < (uint32_t)f.comp[c].samp_w) im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
+            } else {
+                const uint32_t bpp = (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR) ? 3u : 1u;
+                for (int p = 0; p < nplanes_out; p++)
+                    if ((uint64_t)outputs[i].pitch[p] < (uint64_t)ow * bpp) im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
             }
         }
         if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && gpu_entropy_eligible(f)) {
@@ -443,6 +505,8 @@ void DecodeBatch::entropy_stage(int i)
 {
     PlannedImage& im = images_[i];
     if (im.status != HIPJPEG_STATUS_SUCCESS) return;
+    ScopedRange range(im.gpu_entropy ? "hipjpeg host stage (stage bitstream, is_gpu_huffman=1)" : "hipjpeg host stage (Huffman decode, is_gpu_huffman=0)");
+    fault_point("entropy_stage");
     if (im.gpu_entropy) {
         // host part of the GPU entropy path: stage the scan's bytes as they are (the device removes the byte stuffing),
         // expand the Huffman tables, describe the scan
@@ -492,6 +556,7 @@ void DecodeBatch::entropy_stage(int i)
 
 void DecodeBatch::finalize(hipjpegStatus_t* statuses)
 {
+    fault_point("finalize");
     generic_units_.clear();
     for (int e = 0; e < 2; e++) plane_units_[e].clear();
     for (int e = 0; e < kNumLumaFlavours; e++)
@@ -626,6 +691,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
 hipjpegStatus_t DecodeBatch::transfer(void* stream, bool kernels_on_other_stream)
 {
     if (!finalized_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    ScopedRange range("hipjpeg transfer to device");
+    fault_point("transfer");
     entropy_done_ = false;
     pixels_launched_ = false;
     if (h2d_bytes_ == 0) return HIPJPEG_STATUS_SUCCESS;
@@ -714,6 +781,8 @@ hipjpegStatus_t DecodeBatch::wait_done()
 hipjpegStatus_t DecodeBatch::resolve(void* stream)
 {
     if (!entropy_pending_) return HIPJPEG_STATUS_SUCCESS;
+    ScopedRange range("hipjpeg resolve (GPU entropy verdicts)");
+    fault_point("resolve");
     hipStream_t s = (hipStream_t)stream;
     // wait for THIS batch's work only (a later batch may already be queued on the same stream)
     if (in_flight_ ? hipEventSynchronize((hipEvent_t)done_event_) != hipSuccess : hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
@@ -831,6 +900,8 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
 hipjpegStatus_t DecodeBatch::launch(void* stream, int which, void* entropy_stream)
 {
     if (!finalized_) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    ScopedRange range("hipjpeg device stage (launch)");
+    fault_point("launch");
     // HIPJPEG_DEBUG_SYNC=1: synchronise after every launch and report which kernel failed (debug aid only)
     static const bool debug_sync = getenv("HIPJPEG_DEBUG_SYNC") != nullptr;
     auto check = [&](const char* what, int n) {
@@ -886,6 +957,19 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which, void* entropy_strea
     if (hipEventRecord((hipEvent_t)done_event_, (hipStream_t)stream) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     in_flight_ = true;
     return HIPJPEG_STATUS_SUCCESS;
+}
+
+void DecodeBatch::output_size(int i, int* w, int* h) const
+{
+    const PlannedImage& im = images_[i];
+    int ow = im.frame.width, oh = im.frame.height;
+    if (im.has_transform) {
+        const int rw = im.transform.x1 - im.transform.x0, rh = im.transform.y1 - im.transform.y0;
+        ow = im.transform.orientation >= 5 ? rh : rw;
+        oh = im.transform.orientation >= 5 ? rw : rh;
+    }
+    *w = ow;
+    *h = oh;
 }
 
 void DecodeBatch::stats(int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes) const

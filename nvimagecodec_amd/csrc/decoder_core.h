@@ -89,6 +89,13 @@ public:
                          hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
                          const hipjpegOutputFormat_t* formats = nullptr, ForkJoinPool* pool = nullptr,
                          const hipjpegTransform_t* transforms = nullptr);
+    // Between plan() and entropy_stage(): give up image i (e.g. the caller's image descriptor is too small for it).
+    void reject(int i, hipjpegStatus_t st)
+    {
+        if (i >= 0 && i < (int)images_.size() && images_[i].status == HIPJPEG_STATUS_SUCCESS) images_[i].status = st;
+    }
+    // Size of what image i writes into the caller's buffer: width x height after region of interest and orientation.
+    void output_size(int i, int* w, int* h) const;
     // Phase 1: entropy-decode image i into the pinned staging area.  Thread-safe for distinct i.
     void entropy_stage(int i);
     // Phase 1b: after every entropy_stage returned: final per-image flags, drop failed images from the unit tables.
@@ -116,6 +123,9 @@ public:
     void stats(int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes) const;
 
 private:
+    hipjpegStatus_t plan_once(const uint8_t* const* data, const size_t* lengths, int n, const hipjpegOutput_t* outputs,
+                              hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses, const hipjpegOutputFormat_t* formats,
+                              ForkJoinPool* pool, const hipjpegTransform_t* transforms, const std::vector<char>& give_up);
     int device_id_;
     Buffer pinned_, device_, planes_;
     std::vector<PlannedImage> images_;

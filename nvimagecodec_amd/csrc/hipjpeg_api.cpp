@@ -8,6 +8,7 @@
 
 #include "../../include/hipjpeg.h"
 #include "decoder_core.h"
+#include "diagnostics.h"
 #include "encoder_core.h"
 #include "entropy_decode.h"
 #include "gpu_huffman_host.h"
@@ -19,6 +20,22 @@
 #include <cstdlib>
 
 using namespace hipjpeg;
+
+namespace {
+// No C++ exception may cross the C boundary (the reference wraps every entry point the same way, e.g.
+// extensions/libjpeg_turbo/libjpeg_turbo_decoder.cpp:226-236): whatever is thrown below becomes a status code.
+template <class F>
+hipjpegStatus_t guarded(F&& body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return HIPJPEG_STATUS_ALLOC_FAILED;
+    } catch (...) {
+        return HIPJPEG_STATUS_INTERNAL_ERROR;
+    }
+}
+}  // namespace
 
 struct hipjpegHandle {
     int device_id = 0;
@@ -71,14 +88,24 @@ const char* hipjpegStatusString(hipjpegStatus_t s)
     case HIPJPEG_STATUS_HIP_ERROR: return "HIP runtime error";
     case HIPJPEG_STATUS_NO_DEVICE: return "no usable HIP device";
     case HIPJPEG_STATUS_BUFFER_TOO_SMALL: return "buffer too small";
+    case HIPJPEG_STATUS_INTERNAL_ERROR: return "internal error (exception caught at the C boundary)";
     }
     return "unknown status";
 }
 
-int hipjpegVersion(void) { return 100; }
+int hipjpegVersion(void) { return 200; }
+
+hipjpegStatus_t hipjpegTestSetFault(const char* site, int countdown)
+{
+    return guarded([&]() -> hipjpegStatus_t {
+        set_fault(site, countdown);
+        return HIPJPEG_STATUS_SUCCESS;
+    });
+}
 
 hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t length, hipjpegImageInfo_t* info)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!data || !info) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     FrameInfo f;
     ParseStatus ps = parse_jpeg(data, length, &f, /*headers_only=*/false);
@@ -102,11 +129,13 @@ hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t length, hipjpegI
     }
     info->coef_bytes = f.total_blocks() * 128;
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegEntropyDecodeHost(const uint8_t* data, size_t length, int16_t* coef, size_t coef_capacity_bytes,
                                          uint64_t comp_offsets[4], uint16_t qtables[256])
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!data || !coef) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     FrameInfo f;
     ParseStatus ps = parse_jpeg(data, length, &f);
@@ -127,11 +156,13 @@ hipjpegStatus_t hipjpegEntropyDecodeHost(const uint8_t* data, size_t length, int
     case kEntropyMissingTable: return HIPJPEG_STATUS_BAD_JPEG;
     default: return HIPJPEG_STATUS_CORRUPT;
     }
+    });
 }
 
 hipjpegStatus_t hipjpegEntropyDecodeGpuAlgorithmHost(const uint8_t* data, size_t length, int16_t* coef, size_t coef_capacity_bytes,
                                                      uint64_t comp_offsets[4], int32_t* sync_passes)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!data || !coef) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     FrameInfo f;
     ParseStatus ps = parse_jpeg(data, length, &f);
@@ -149,10 +180,12 @@ hipjpegStatus_t hipjpegEntropyDecodeGpuAlgorithmHost(const uint8_t* data, size_t
     int rc = emulate_gpu_entropy(data, length, f, ptr, &passes);
     if (sync_passes) *sync_passes = passes;
     return rc == 0 ? HIPJPEG_STATUS_SUCCESS : (rc == 2 ? HIPJPEG_STATUS_TRUNCATED : HIPJPEG_STATUS_CORRUPT);
+    });
 }
 
 hipjpegStatus_t hipjpegCreate(hipjpegHandle_t* handle, int device_id, int num_host_threads)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     *handle = nullptr;
     int count = 0;
@@ -167,28 +200,37 @@ hipjpegStatus_t hipjpegCreate(hipjpegHandle_t* handle, int device_id, int num_ho
     h->encode_view = h->encode.get();
     *handle = h;
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegDestroy(hipjpegHandle_t handle)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     (void)hipSetDevice(handle->device_id);
     if (handle->copy_stream) (void)hipStreamDestroy(handle->copy_stream);
     if (handle->entropy_stream) (void)hipStreamDestroy(handle->entropy_stream);
     for (auto& pg : handle->encode_pages) {
-        if (pg.result.valid()) (void)pg.result.get();
+        if (pg.result.valid()) {
+            try {
+                (void)pg.result.get();
+            } catch (...) {
+            }
+        }
         pg.batch.reset();
         if (pg.ready) (void)hipEventDestroy(pg.ready);
         if (pg.stream) (void)hipStreamDestroy(pg.stream);
     }
     delete handle;
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
                                        const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags,
                                        hipjpegStatus_t* statuses)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     handle->current = (handle->current + 1) % hipjpegHandle::kPages;
     DecodeBatch& b = handle->cur();
@@ -214,47 +256,59 @@ hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const uint8_t* co
                 handle->pool->num_threads());
     }
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchSetTransforms(hipjpegHandle_t handle, const hipjpegTransform_t* transforms, int batch_size)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle || batch_size < 0) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     if (transforms)
         handle->transforms.assign(transforms, transforms + batch_size);
     else
         handle->transforms.clear();
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchTransfer(hipjpegHandle_t handle, void* stream)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     return handle->cur().transfer(stream);
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, void* stream)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     return handle->cur().launch(stream);
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handle, int which, void* stream)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     return handle->cur().launch(stream, which);
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchStats(hipjpegHandle_t handle, int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     handle->cur().stats(num_units, coef_bytes, output_bytes);
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatch(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
                                    const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
                                    void* stream)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     hipjpegStatus_t st = hipjpegDecodeBatchHost(handle, data, lengths, batch_size, outputs, format, flags, statuses);
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     if ((st = hipjpegDecodeBatchTransfer(handle, stream)) != HIPJPEG_STATUS_SUCCESS) return st;
@@ -265,11 +319,13 @@ hipjpegStatus_t hipjpegDecodeBatch(hipjpegHandle_t handle, const uint8_t* const*
     if (statuses)
         for (int i = 0; i < batch_size; i++) statuses[i] = handle->cur().image(i).status;
     return st;
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
                                          const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags, void* stream)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     if (handle->num_submitted >= hipjpegHandle::kPages) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // every page in flight: Wait first
     if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
@@ -286,10 +342,12 @@ hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* 
     handle->submitted_stream[handle->num_submitted] = stream;
     handle->num_submitted++;
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle || handle->num_submitted == 0) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     DecodeBatch& b = *handle->batches[handle->submitted[0]];
     void* stream = handle->submitted_stream[0];
@@ -305,43 +363,53 @@ hipjpegStatus_t hipjpegDecodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* 
     if (statuses)
         for (int i = 0; i < batch_size; i++) statuses[i] = b.image(i).status;
     return st;
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchGetStatuses(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle || !statuses || batch_size != handle->cur().size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     hipjpegStatus_t st = handle->cur().resolve(handle->cur().last_stream());
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     for (int i = 0; i < batch_size; i++) statuses[i] = handle->cur().image(i).status;
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegDecodeBatchEntropyStats(hipjpegHandle_t handle, int32_t* gpu_images, int32_t* sync_launches, uint64_t* stream_bytes)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     if (gpu_images) *gpu_images = handle->cur().gpu_entropy_images();
     if (sync_launches) *sync_launches = handle->cur().last_sync_launches();
     if (stream_bytes) *stream_bytes = handle->cur().stream_bytes();
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 // ---------------------------------------------------------------- encode
 hipjpegStatus_t hipjpegEncodeBatchDevice(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
                                          int batch_size, hipjpegStatus_t* statuses, void* stream)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     handle->encode_view = handle->encode.get();
     return handle->encode->device_stage(inputs, params, batch_size, statuses, stream);
+    });
 }
 
 hipjpegStatus_t hipjpegEncodeBatchRelaunch(hipjpegHandle_t handle, void* stream)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     return handle->encode->relaunch(stream);
+    });
 }
 
 hipjpegStatus_t hipjpegEncodeBatchEntropy(hipjpegHandle_t handle, unsigned flags, hipjpegStatus_t* statuses)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     EncodeBatch& b = *handle->encode;
     std::vector<char> todo(b.size(), 1);
@@ -361,6 +429,7 @@ hipjpegStatus_t hipjpegEncodeBatchEntropy(hipjpegHandle_t handle, unsigned flags
     if (statuses)
         for (int i = 0; i < b.size(); i++) statuses[i] = b.image(i).status;
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegEncodeBatchHost(hipjpegHandle_t handle, hipjpegStatus_t* statuses) { return hipjpegEncodeBatchEntropy(handle, 0u, statuses); }
@@ -368,14 +437,17 @@ hipjpegStatus_t hipjpegEncodeBatchHost(hipjpegHandle_t handle, hipjpegStatus_t* 
 hipjpegStatus_t hipjpegEncodeBatch(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
                                    int batch_size, hipjpegStatus_t* statuses, void* stream)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     hipjpegStatus_t st = hipjpegEncodeBatchDevice(handle, inputs, params, batch_size, statuses, stream);
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     return hipjpegEncodeBatchHost(handle, statuses);
+    });
 }
 
 hipjpegStatus_t hipjpegEncodeBatchSubmit(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params, int batch_size,
                                          unsigned flags, void* stream)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle || batch_size < 0 || (batch_size > 0 && (!inputs || !params))) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     if (handle->encode_in_flight >= hipjpegHandle::kEncodePages) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // every page busy: Wait first
     if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
@@ -412,10 +484,12 @@ hipjpegStatus_t hipjpegEncodeBatchSubmit(hipjpegHandle_t handle, const hipjpegEn
     handle->encode_next = (handle->encode_next + 1) % hipjpegHandle::kEncodePages;
     handle->encode_in_flight++;
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegEncodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle || handle->encode_in_flight == 0) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     hipjpegHandle::EncodePage& pg = handle->encode_pages[handle->encode_oldest];
     handle->encode_oldest = (handle->encode_oldest + 1) % hipjpegHandle::kEncodePages;
@@ -427,20 +501,24 @@ hipjpegStatus_t hipjpegEncodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* 
         for (int i = 0; i < batch_size; i++) statuses[i] = pg.batch->image(i).status;
     }
     return st;
+    });
 }
 
 hipjpegStatus_t hipjpegEncodeGetBitstream(hipjpegHandle_t handle, int index, const uint8_t** data, size_t* length)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle || !data || !length || index < 0 || index >= handle->encode_view->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     PlannedEncode& im = handle->encode_view->image(index);
     if (im.status != HIPJPEG_STATUS_SUCCESS) return im.status;
     *data = im.file();
     *length = im.file_size();
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegEncodeGetCoefficients(hipjpegHandle_t handle, int index, int component, const int16_t** coef, int32_t grid[4])
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle || !coef || !grid || index < 0 || index >= handle->encode_view->size()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     PlannedEncode& im = handle->encode_view->image(index);
     if (im.status != HIPJPEG_STATUS_SUCCESS) return im.status;
@@ -453,20 +531,24 @@ hipjpegStatus_t hipjpegEncodeGetCoefficients(hipjpegHandle_t handle, int index, 
     grid[2] = im.geom.real_w[component];
     grid[3] = im.geom.real_h[component];
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegEncodeBatchStats(hipjpegHandle_t handle, int32_t* num_units, uint64_t* pixel_bytes, uint64_t* coef_bytes)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     if (num_units) *num_units = handle->encode_view->num_units();
     if (pixel_bytes) *pixel_bytes = handle->encode_view->pixel_bytes();
     if (coef_bytes) *coef_bytes = handle->encode_view->coef_bytes();
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 hipjpegStatus_t hipjpegEncodeFromCoefficientsHost(int32_t width, int32_t height, const hipjpegEncodeParams_t* params, const int16_t* const coef[3],
                                                   uint8_t* out, size_t capacity, size_t* length)
 {
+    return guarded([&]() -> hipjpegStatus_t {
     if (!params || !coef || !length || width < 1 || height < 1 || width > 65535 || height > 65535) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     EncodeGeometry g;
     g.width = width;
@@ -487,6 +569,7 @@ hipjpegStatus_t hipjpegEncodeFromCoefficientsHost(int32_t width, int32_t height,
     if (!out || capacity < bytes.size()) return HIPJPEG_STATUS_BUFFER_TOO_SMALL;
     memcpy(out, bytes.data(), bytes.size());
     return HIPJPEG_STATUS_SUCCESS;
+    });
 }
 
 }  // extern "C"

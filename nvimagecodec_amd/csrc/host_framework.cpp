@@ -525,12 +525,20 @@ struct nvimgcodecImage {
     nvimgcodecImageInfo_t info{};
 };
 
+// Samples reported more than once (the reference's promise throws logic_error on a double set, src/processing_results.cpp:
+// 104-115; here the first result wins and the event is counted so that tests can assert it never happens).
+static std::atomic<int> g_double_reports{0};
+extern "C" __attribute__((visibility("default"))) int hipjpegTestDoubleReports(void) { return g_double_reports.load(); }
+
 struct nvimgcodecFuture {
     explicit nvimgcodecFuture(size_t n) : status(n, NVIMGCODEC_PROCESSING_STATUS_UNKNOWN), remaining((int)n) {}
     void set(size_t i, nvimgcodecProcessingStatus_t s)
     {
         std::lock_guard<std::mutex> lk(m);
-        if (status[i] != NVIMGCODEC_PROCESSING_STATUS_UNKNOWN && s != NVIMGCODEC_PROCESSING_STATUS_UNKNOWN) return;  // first result wins
+        if (status[i] != NVIMGCODEC_PROCESSING_STATUS_UNKNOWN && s != NVIMGCODEC_PROCESSING_STATUS_UNKNOWN) {
+            g_double_reports.fetch_add(1);
+            return;  // first result wins
+        }
         status[i] = s;
         if (--remaining == 0) cv.notify_all();
     }

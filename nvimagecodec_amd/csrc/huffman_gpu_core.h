@@ -401,7 +401,9 @@ HJ_HD int decode_block(const HuffGeom& im, const Env& env, uint32_t pos, int k, 
         z += (int)zadv;
         tcur = tsel >> 16;
     }
-    if (z < 64) err = 1;  // the stream ended inside the block
+    // the stream ended inside the block, or its last symbol reaches into the slack behind the data (the host decoder calls
+    // that TRUNCATED, BitReader::overran in entropy_decode.cpp)
+    if (z < 64 || pos > im.total_bits) err = 1;
     if (err) *error = 1;
     return dc;
 }

@@ -203,6 +203,7 @@ ParseStatus parse_jpeg(const uint8_t* data, size_t size, FrameInfo* f, bool head
         case 0xDA: {
             if (!got_sof) return kParseBadStream;
             if (headers_only) return kParseOk;
+            if (L < 8) return kParseBadStream;  // shortest SOS: one component; also keeps seg[0] inside the segment
             ScanHeader sc;
             sc.ncomp = seg[0];
             if (sc.ncomp < 1 || sc.ncomp > 4 || L != 6 + 2 * sc.ncomp) return kParseBadStream;

@@ -18,12 +18,16 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <chrono>
 #include <mutex>
+#include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "decoder_core.h"
+#include "diagnostics.h"
 #include "plugin_common.h"
 #include "thread_pool.h"
 #include "plugin_objects.h"
@@ -89,6 +93,10 @@ private:
         void* mapped = nullptr;           // non-null if io_stream->map succeeded (must be unmapped)
         std::vector<uint8_t> owned;       // bitstream copy when map() is not available
         nvimgcodecProcessingStatus_t early_status = NVIMGCODEC_PROCESSING_STATUS_SUCCESS;  // set when the sample is rejected before planning
+        bool reported = false;            // imageReady has been called (exactly once per sample, whatever happens)
+        // what the caller's image descriptor says it can hold
+        uint32_t nplanes = 0, plane_w[3] = {0, 0, 0}, plane_h[3] = {0, 0, 0};
+        size_t buffer_size = 0, buffer_needed = 0;
     };
     struct Job {
         explicit Job(int device, const MemoryHooks* hooks) : batch(device, hooks) {}
@@ -99,6 +107,7 @@ private:
         std::mutex m;
         std::condition_variable cv;
         bool busy = false;
+        bool issued = false;  // H2D copy and kernels are queued on `stream`
         HipJpegDecoder* owner = nullptr;
         hipEvent_t event = nullptr;
         hipStream_t stream = nullptr;  // H2D copy and kernels of this job: jobs overlap each other on the device
@@ -107,8 +116,12 @@ private:
     void single_can_decode(nvimgcodecProcessingStatus_t* status, nvimgcodecCodeStreamDesc_t* cs, nvimgcodecImageDesc_t* image,
                            const nvimgcodecDecodeParams_t* params);
     static void host_task(int tid, int sample_idx, void* ctx);
-    void finish(Job* job);
+    void issue(Job* job);      // last host task of a job: descriptors, H2D copy, kernels -- nothing here waits for the device
+    void complete(Job* job);   // completion thread: device verdicts, user-stream ordering, imageReady, page release
+    void report(Job* job, int i, nvimgcodecProcessingStatus_t ps);
+    void release_job(Job* job);
     void release_inputs(Job* job);
+    void completion_loop();
 
     const nvimgcodecFrameworkDesc_t* fw_;
     const nvimgcodecExecutionParams_t* ep_;
@@ -125,6 +138,14 @@ private:
     // executor only takes per-sample tasks that report through imageReady, and the batch layout needs every header first.
     std::unique_ptr<hipjpeg::ForkJoinPool> parse_pool_;
     std::mutex decode_mutex_;  // decode() may be entered from the framework's worker thread and from a fallback re-dispatch
+    // Jobs whose device work is queued wait here for the completion thread: no executor thread ever blocks on the GPU, and
+    // decode() has long returned when the verdicts of the GPU entropy stage arrive (the host future only means "host work
+    // done", reference include/nvimgcodec.h:1455-1459; imageReady is still called once the status is final).
+    std::mutex done_mutex_;
+    std::condition_variable done_cv_;
+    std::deque<Job*> done_queue_;
+    bool stopping_ = false;
+    std::thread completion_thread_;
 };
 
 HipJpegDecoder::HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgcodecExecutionParams_t* ep, const char* options)
@@ -169,6 +190,7 @@ HipJpegDecoder::HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgc
             return;
         }
     }
+    completion_thread_ = std::thread([this] { completion_loop(); });
     ok_ = true;
 }
 
@@ -178,6 +200,14 @@ HipJpegDecoder::~HipJpegDecoder()
         if (!j) continue;
         std::unique_lock<std::mutex> lk(j->m);
         j->cv.wait(lk, [&] { return !j->busy; });
+    }
+    if (completion_thread_.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(done_mutex_);
+            stopping_ = true;
+        }
+        done_cv_.notify_all();
+        completion_thread_.join();
     }
     (void)hipSetDevice(device_);
     for (auto& j : jobs_) {
@@ -336,28 +366,95 @@ void HipJpegDecoder::release_inputs(Job* job)
     }
 }
 
+// Exactly one imageReady per sample: every path that reports goes through here.
+void HipJpegDecoder::report(Job* job, int i, nvimgcodecProcessingStatus_t ps)
+{
+    Sample& s = job->samples[i];
+    if (s.reported) return;
+    s.reported = true;
+    if (ps != NVIMGCODEC_PROCESSING_STATUS_SUCCESS)
+        HJ_LOG_WARNING(fw_, kDecoderId, "sample " << i << " not decoded, processing status 0x" << std::hex << ps);
+    s.image->imageReady(s.image->instance, ps);
+}
+
+void HipJpegDecoder::release_job(Job* job)
+{
+    {
+        std::lock_guard<std::mutex> lk(job->m);
+        job->busy = false;
+    }
+    job->cv.notify_all();
+}
+
+// Runs on the framework's executor threads (or inline for a single sample).  Nothing may escape: the executor swallows
+// exceptions (reference src/thread_pool.cpp:175-185), and a sample that never reports deadlocks the caller's future.
 void HipJpegDecoder::host_task(int /*tid*/, int sample_idx, void* ctx)
 {
     Job* job = static_cast<Job*>(ctx);
-    job->batch.entropy_stage(sample_idx);
-    if (job->remaining.fetch_sub(1) == 1) job->owner->finish(job);
+    try {
+        hipjpeg::ScopedRange range("hipjpeg_decoder host task");
+        job->batch.entropy_stage(sample_idx);
+    } catch (...) {
+        job->batch.reject(sample_idx, HIPJPEG_STATUS_INTERNAL_ERROR);
+    }
+    if (job->remaining.fetch_sub(1) == 1) job->owner->issue(job);
 }
 
-// Runs on whichever thread finished the last host task of the batch.
-void HipJpegDecoder::finish(Job* job)
+// Runs on whichever thread finished the last host task of the job: queue the device work, hand the job to the completion
+// thread.  Does not wait for the device.
+void HipJpegDecoder::issue(Job* job)
+{
+    bool ok = false;
+    try {
+        ok = hipSetDevice(device_) == hipSuccess;
+        job->batch.finalize(job->statuses.data());
+        if (ok) ok = job->batch.transfer(job->stream) == HIPJPEG_STATUS_SUCCESS;
+        if (ok) ok = job->batch.launch(job->stream) == HIPJPEG_STATUS_SUCCESS;
+    } catch (...) {
+        ok = false;
+    }
+    job->issued = ok;
+    {
+        std::lock_guard<std::mutex> lk(done_mutex_);
+        done_queue_.push_back(job);
+    }
+    done_cv_.notify_one();
+}
+
+void HipJpegDecoder::completion_loop()
+{
+    (void)hipSetDevice(device_);
+    for (;;) {
+        Job* job = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(done_mutex_);
+            done_cv_.wait(lk, [&] { return stopping_ || !done_queue_.empty(); });
+            if (done_queue_.empty()) return;  // stopping, nothing left
+            job = done_queue_.front();
+            done_queue_.pop_front();
+        }
+        complete(job);
+    }
+}
+
+// GPU-decoded streams: their verdicts come back from the device (resolve() waits for this job's kernels; the other job
+// pages keep going meanwhile).  Jobs that went through the host entropy stage only do not wait here at all.
+void HipJpegDecoder::complete(Job* job)
 {
     const int n = (int)job->samples.size();
-    bool gpu_ok = hipSetDevice(device_) == hipSuccess;
-    job->batch.finalize(job->statuses.data());
-    hipStream_t stream_ = job->stream;
-    if (gpu_ok) gpu_ok = job->batch.transfer(stream_) == HIPJPEG_STATUS_SUCCESS;
-    if (gpu_ok) gpu_ok = job->batch.launch(stream_) == HIPJPEG_STATUS_SUCCESS;
-    // GPU-decoded streams: their verdicts come back from the device (blocks; the other job page keeps the host stage of
-    // the next batch going meanwhile).  Batches that went through the host entropy stage only do not wait here.
-    if (gpu_ok) gpu_ok = job->batch.resolve(stream_) == HIPJPEG_STATUS_SUCCESS;
-    if (gpu_ok) gpu_ok = hipEventRecord(job->event, stream_) == hipSuccess;
-    for (int i = 0; i < n; i++) job->statuses[i] = job->batch.image(i).status;  // incl. what the GPU entropy stage reported
-    release_inputs(job);
+    bool gpu_ok = job->issued;
+    try {
+        if (gpu_ok) gpu_ok = job->batch.resolve(job->stream) == HIPJPEG_STATUS_SUCCESS;
+        if (gpu_ok) gpu_ok = hipEventRecord(job->event, job->stream) == hipSuccess;
+        for (int i = 0; i < n; i++) job->statuses[i] = job->batch.image(i).status;  // incl. what the GPU entropy stage reported
+    } catch (...) {
+        gpu_ok = false;
+    }
+    if (!gpu_ok) (void)hipStreamSynchronize(job->stream);  // whatever was queued must not outlive the caller's buffers
+    try {
+        release_inputs(job);
+    } catch (...) {
+    }
     for (int i = 0; i < n; i++) {
         Sample& s = job->samples[i];
         nvimgcodecProcessingStatus_t ps = s.early_status;
@@ -368,15 +465,12 @@ void HipJpegDecoder::finish(Job* job)
                 hipStreamWaitEvent((hipStream_t)s.user_stream, job->event, 0) != hipSuccess)
                 ps = NVIMGCODEC_PROCESSING_STATUS_FAIL;
         }
-        if (ps != NVIMGCODEC_PROCESSING_STATUS_SUCCESS)
-            HJ_LOG_WARNING(fw_, kDecoderId, "sample " << i << " not decoded, processing status 0x" << std::hex << ps);
-        s.image->imageReady(s.image->instance, ps);
+        try {
+            report(job, i, ps);
+        } catch (...) {  // a framework whose imageReady throws (double set) must not take the page down with it
+        }
     }
-    {
-        std::lock_guard<std::mutex> lk(job->m);
-        job->busy = false;
-    }
-    job->cv.notify_all();
+    release_job(job);
 }
 
 // A large batch is cut into up to three pieces, each a job of its own (own page, own stream): the host stage and the H2D copy of
@@ -404,6 +498,7 @@ nvimgcodecStatus_t HipJpegDecoder::decode_chunk(nvimgcodecCodeStreamDesc_t** cod
 {
     static const bool timing = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;  // debug aid: phase times of decode() on stderr
     const auto t_enter = std::chrono::steady_clock::now();
+    hipjpeg::ScopedRange range("hipjpeg_decoder decode (marshal + plan + schedule)");
     Job* job = jobs_[next_job_].get();
     next_job_ = (next_job_ + 1) % kJobPages;
     {
@@ -412,122 +507,189 @@ nvimgcodecStatus_t HipJpegDecoder::decode_chunk(nvimgcodecCodeStreamDesc_t** cod
         job->busy = true;
     }
     const int n = batch_size;
-    job->samples.assign(n, Sample());
-    job->statuses.assign(n, HIPJPEG_STATUS_SUCCESS);
-    std::vector<const uint8_t*> data(n, nullptr);
-    std::vector<size_t> sizes(n, 0);
-    std::vector<hipjpegOutput_t> outs(n);
-    std::vector<hipjpegOutputFormat_t> formats(n, HIPJPEG_OUTPUT_RGBI);
-    std::vector<hipjpegTransform_t> geometry(n, hipjpegTransform_t{0, 0, 0, 0, 1});
-    bool any_geometry = false;
-    memset(outs.data(), 0, sizeof(hipjpegOutput_t) * n);
+    // From here on the page is ours and every sample owes the framework one imageReady.  Whatever is thrown before the host
+    // tasks are scheduled ends in the handler at the bottom: all samples FAIL, page released, error code returned
+    // (reference extensions/nvjpeg/cuda_decoder.cpp:602-608).
+    bool scheduled = false;
+    try {
+        job->issued = false;
+        job->samples.assign(n, Sample());
+        for (int i = 0; i < n; i++) {
+            job->samples[i].code_stream = code_streams[i];
+            job->samples[i].image = images[i];
+        }
+        job->statuses.assign(n, HIPJPEG_STATUS_SUCCESS);
+        std::vector<const uint8_t*> data(n, nullptr);
+        std::vector<size_t> sizes(n, 0);
+        std::vector<hipjpegOutput_t> outs(n);
+        std::vector<hipjpegOutputFormat_t> formats(n, HIPJPEG_OUTPUT_RGBI);
+        std::vector<hipjpegTransform_t> geometry(n, hipjpegTransform_t{0, 0, 0, 0, 1});
+        bool any_geometry = false;
+        memset(outs.data(), 0, sizeof(hipjpegOutput_t) * n);
 
-    for (int i = 0; i < n; i++) {
-        Sample& s = job->samples[i];
-        s.code_stream = code_streams[i];
-        s.image = images[i];
-        nvimgcodecImageInfo_t info;
-        memset(&info, 0, sizeof info);
-        info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
-        info.struct_size = sizeof info;
-        if (s.image->getImageInfo(s.image->instance, &info) != NVIMGCODEC_STATUS_SUCCESS) {
-            s.early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
-            continue;
-        }
-        s.user_stream = info.cuda_stream;
-        if (info.buffer_kind != NVIMGCODEC_IMAGE_BUFFER_KIND_STRIDED_DEVICE || !info.buffer) {
-            // the framework bounces host buffers for GPU backends (reference src/work.h:144-169); a host pointer here is a caller bug
-            s.early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
-            continue;
-        }
-        if (!map_sample_format(info.sample_format, &formats[i])) {
-            s.early_status = NVIMGCODEC_PROCESSING_STATUS_SAMPLE_FORMAT_UNSUPPORTED;
-            continue;
-        }
-        if ((params->enable_roi && info.region.ndim > 0) || params->apply_exif_orientation) {
-            nvimgcodecImageInfo_t cs_info;
-            memset(&cs_info, 0, sizeof cs_info);
-            cs_info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
-            cs_info.struct_size = sizeof cs_info;
-            if (s.code_stream->getImageInfo(s.code_stream->instance, &cs_info) != NVIMGCODEC_STATUS_SUCCESS) {
+        auto marshal = [&](int i) {
+            Sample& s = job->samples[i];
+            hipjpeg::fault_point("marshal");
+            nvimgcodecImageInfo_t info;
+            memset(&info, 0, sizeof info);
+            info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+            info.struct_size = sizeof info;
+            if (s.image->getImageInfo(s.image->instance, &info) != NVIMGCODEC_STATUS_SUCCESS) {
                 s.early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
-                continue;
+                return;
             }
-            const int bad = sample_transform(info, cs_info, params, &geometry[i]);
-            if (bad) {  // canDecode said so already; a caller that insists gets the same verdict (cuda_decoder.cpp:452-461)
-                s.early_status = (bad & 1) ? NVIMGCODEC_PROCESSING_STATUS_ROI_UNSUPPORTED : NVIMGCODEC_PROCESSING_STATUS_ORIENTATION_UNSUPPORTED;
-                continue;
+            s.user_stream = info.cuda_stream;
+            if (info.buffer_kind != NVIMGCODEC_IMAGE_BUFFER_KIND_STRIDED_DEVICE || !info.buffer) {
+                // the framework bounces host buffers for GPU backends (reference src/work.h:144-169); a host pointer here is a caller bug
+                s.early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+                return;
             }
-            any_geometry = any_geometry || geometry[i].x1 != 0 || geometry[i].orientation != 1;
-        }
-        // planes are laid out back to back inside `buffer` (reference cuda_decoder.cpp:532-538)
-        uint8_t* p = static_cast<uint8_t*>(info.buffer);
-        for (uint32_t pl = 0; pl < info.num_planes && pl < 3; pl++) {
-            outs[i].plane[pl] = p;
-            outs[i].pitch[pl] = (uint32_t)info.plane_info[pl].row_stride;
-            p += info.plane_info[pl].row_stride * info.plane_info[pl].height;
-        }
-        // bitstream: zero-copy map when the stream offers it, else read into our own buffer (cuda_decoder.cpp:480-500)
-        nvimgcodecIoStreamDesc_t* io = s.code_stream->io_stream;
-        size_t size = 0;
-        if (io->size(io->instance, &size) != NVIMGCODEC_STATUS_SUCCESS || size == 0) {
-            s.early_status = NVIMGCODEC_PROCESSING_STATUS_IMAGE_CORRUPTED;
-            continue;
-        }
-        void* mapped = nullptr;
-        if (io->map(io->instance, &mapped, 0, size) == NVIMGCODEC_STATUS_SUCCESS && mapped) {
-            s.mapped = mapped;
-            s.data = static_cast<const uint8_t*>(mapped);
-        } else {
-            s.owned.resize(size);
-            size_t got = 0;
-            io->seek(io->instance, 0, SEEK_SET);
-            if (io->read(io->instance, &got, s.owned.data(), size) != NVIMGCODEC_STATUS_SUCCESS || got != size) {
+            if (!map_sample_format(info.sample_format, &formats[i])) {
+                s.early_status = NVIMGCODEC_PROCESSING_STATUS_SAMPLE_FORMAT_UNSUPPORTED;
+                return;
+            }
+            if ((params->enable_roi && info.region.ndim > 0) || params->apply_exif_orientation) {
+                nvimgcodecImageInfo_t cs_info;
+                memset(&cs_info, 0, sizeof cs_info);
+                cs_info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+                cs_info.struct_size = sizeof cs_info;
+                if (s.code_stream->getImageInfo(s.code_stream->instance, &cs_info) != NVIMGCODEC_STATUS_SUCCESS) {
+                    s.early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+                    return;
+                }
+                const int bad = sample_transform(info, cs_info, params, &geometry[i]);
+                if (bad) {  // canDecode said so already; a caller that insists gets the same verdict (cuda_decoder.cpp:452-461)
+                    s.early_status = (bad & 1) ? NVIMGCODEC_PROCESSING_STATUS_ROI_UNSUPPORTED : NVIMGCODEC_PROCESSING_STATUS_ORIENTATION_UNSUPPORTED;
+                    return;
+                }
+                any_geometry = any_geometry || geometry[i].x1 != 0 || geometry[i].orientation != 1;
+            }
+            // planes are laid out back to back inside `buffer` (reference cuda_decoder.cpp:532-538)
+            uint8_t* p = static_cast<uint8_t*>(info.buffer);
+            s.nplanes = std::min<uint32_t>(info.num_planes, 3u);
+            s.buffer_size = info.buffer_size;
+            for (uint32_t pl = 0; pl < s.nplanes; pl++) {
+                if (info.plane_info[pl].row_stride > 0xFFFFFFFFull) {  // the kernels address rows with 32-bit pitches
+                    s.early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+                    return;
+                }
+                outs[i].plane[pl] = p;
+                outs[i].pitch[pl] = (uint32_t)info.plane_info[pl].row_stride;
+                s.plane_w[pl] = info.plane_info[pl].width;
+                s.plane_h[pl] = info.plane_info[pl].height;
+                p += info.plane_info[pl].row_stride * info.plane_info[pl].height;
+            }
+            // bitstream: zero-copy map when the stream offers it, else read into our own buffer (cuda_decoder.cpp:480-500)
+            nvimgcodecIoStreamDesc_t* io = s.code_stream->io_stream;
+            size_t size = 0;
+            if (io->size(io->instance, &size) != NVIMGCODEC_STATUS_SUCCESS || size == 0) {
                 s.early_status = NVIMGCODEC_PROCESSING_STATUS_IMAGE_CORRUPTED;
-                continue;
+                return;
             }
-            s.data = s.owned.data();
+            void* mapped = nullptr;
+            if (io->map(io->instance, &mapped, 0, size) == NVIMGCODEC_STATUS_SUCCESS && mapped) {
+                s.mapped = mapped;
+                s.data = static_cast<const uint8_t*>(mapped);
+            } else {
+                s.owned.resize(size);
+                size_t got = 0;
+                io->seek(io->instance, 0, SEEK_SET);
+                if (io->read(io->instance, &got, s.owned.data(), size) != NVIMGCODEC_STATUS_SUCCESS || got != size) {
+                    s.early_status = NVIMGCODEC_PROCESSING_STATUS_IMAGE_CORRUPTED;
+                    return;
+                }
+                s.data = s.owned.data();
+            }
+            s.size = size;
+            data[i] = s.data;
+            sizes[i] = size;
+        };
+        for (int i = 0; i < n; i++) {
+            try {  // one sample's trouble (a throwing getImageInfo, no memory for its bitstream copy) stays that sample's
+                marshal(i);
+            } catch (...) {
+                job->samples[i].early_status = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+                data[i] = nullptr;
+                sizes[i] = 0;
+            }
         }
-        s.size = size;
-        data[i] = s.data;
-        sizes[i] = size;
-    }
 
-    const auto t_marshal = std::chrono::steady_clock::now();
-    bool planned = hipSetDevice(device_) == hipSuccess &&
-                   job->batch.plan(data.data(), sizes.data(), n, outs.data(), HIPJPEG_OUTPUT_RGBI,
-                                   (fancy_ ? HIPJPEG_FLAG_FANCY_UPSAMPLING : 0u) | (gpu_huffman_ ? HIPJPEG_FLAG_GPU_HUFFMAN : 0u),
-                                   job->statuses.data(), formats.data(), parse_pool_.get(), any_geometry ? geometry.data() : nullptr) == HIPJPEG_STATUS_SUCCESS;
-    if (!planned) {
-        // batch-level failure: every sample is reported failed and an error code is returned (cuda_decoder.cpp:602-608)
-        release_inputs(job);
-        for (int i = 0; i < n; i++) images[i]->imageReady(images[i]->instance, NVIMGCODEC_PROCESSING_STATUS_FAIL);
-        {
-            std::lock_guard<std::mutex> lk(job->m);
-            job->busy = false;
+        const auto t_marshal = std::chrono::steady_clock::now();
+        const bool planned = hipSetDevice(device_) == hipSuccess &&
+                             job->batch.plan(data.data(), sizes.data(), n, outs.data(), HIPJPEG_OUTPUT_RGBI,
+                                             (fancy_ ? HIPJPEG_FLAG_FANCY_UPSAMPLING : 0u) | (gpu_huffman_ ? HIPJPEG_FLAG_GPU_HUFFMAN : 0u),
+                                             job->statuses.data(), formats.data(), parse_pool_.get(),
+                                             any_geometry ? geometry.data() : nullptr) == HIPJPEG_STATUS_SUCCESS;
+        if (!planned) throw std::runtime_error("could not plan the decode batch");
+
+        // The caller's image descriptor must be able to hold what will be written: plane sizes and buffer_size against the
+        // decoded size after region of interest and orientation (nvJPEG checks its output descriptor for the reference).
+        for (int i = 0; i < n; i++) {
+            Sample& s = job->samples[i];
+            if (s.early_status != NVIMGCODEC_PROCESSING_STATUS_SUCCESS || job->statuses[i] != HIPJPEG_STATUS_SUCCESS) continue;
+            const hipjpeg::PlannedImage& im = job->batch.image(i);
+            int ow = 0, oh = 0;
+            job->batch.output_size(i, &ow, &oh);
+            bool fits = true;
+            size_t need = 0;
+            const int planes = formats[i] == HIPJPEG_OUTPUT_YUV_PLANAR ? im.frame.ncomp
+                               : (formats[i] == HIPJPEG_OUTPUT_RGB_PLANAR || formats[i] == HIPJPEG_OUTPUT_BGR_PLANAR) ? 3 : 1;
+            if ((int)s.nplanes < planes) fits = false;
+            for (int pl = 0; pl < planes && fits; pl++) {
+                const int pw = formats[i] == HIPJPEG_OUTPUT_YUV_PLANAR ? im.frame.comp[pl].samp_w : ow;
+                const int ph = formats[i] == HIPJPEG_OUTPUT_YUV_PLANAR ? im.frame.comp[pl].samp_h : oh;
+                if ((int64_t)s.plane_w[pl] < pw || (int64_t)s.plane_h[pl] < ph) fits = false;
+                need += (size_t)outs[i].pitch[pl] * s.plane_h[pl];
+            }
+            if (fits && s.buffer_size != 0 && s.buffer_size < need) fits = false;
+            if (!fits) {
+                job->batch.reject(i, HIPJPEG_STATUS_INVALID_ARGUMENT);
+                job->statuses[i] = HIPJPEG_STATUS_INVALID_ARGUMENT;
+            }
         }
-        job->cv.notify_all();
-        HJ_LOG_ERROR(fw_, kDecoderId, "could not plan the decode batch on device " << device_);
+
+        const auto t_plan = std::chrono::steady_clock::now();
+        job->remaining.store(n);
+        scheduled = true;  // from the first launch on, the host tasks own the samples
+        nvimgcodecExecutorDesc_t* ex = ep_->executor;
+        if (n == 1 || !ex) {
+            for (int i = 0; i < n; i++) host_task(0, i, job);  // single image: run inline like the reference (:565-566)
+        } else {
+            for (int i = 0; i < n; i++) {
+                bool handed = false;
+                try {
+                    handed = ex->launch(ex->instance, device_, i, job, &HipJpegDecoder::host_task) == NVIMGCODEC_STATUS_SUCCESS;
+                } catch (...) {
+                    handed = false;
+                }
+                if (!handed) host_task(0, i, job);  // host_task itself lets nothing escape
+            }
+        }
+        if (timing) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            const auto t_end = std::chrono::steady_clock::now();
+            fprintf(stderr, "[hipjpeg] plugin decode(%d): wait for a job page + marshal %.2f ms, plan %.2f ms, hand to executor %.2f ms\n", n,
+                    ms(t_enter, t_marshal), ms(t_marshal, t_plan), ms(t_plan, t_end));
+        }
+        return NVIMGCODEC_STATUS_SUCCESS;
+    } catch (...) {
+        if (scheduled) return NVIMGCODEC_STATUS_SUCCESS;  // every sample is in the hands of a host task: they report
+        try {
+            release_inputs(job);
+        } catch (...) {
+        }
+        for (int i = 0; i < n && i < (int)job->samples.size(); i++) {
+            try {
+                if (job->samples[i].image) report(job, i, NVIMGCODEC_PROCESSING_STATUS_FAIL);
+            } catch (...) {
+            }
+        }
+        if ((int)job->samples.size() < n)  // not even the sample table could be built: report straight from the arguments
+            for (int i = (int)job->samples.size(); i < n; i++) images[i]->imageReady(images[i]->instance, NVIMGCODEC_PROCESSING_STATUS_FAIL);
+        release_job(job);
+        HJ_LOG_ERROR(fw_, kDecoderId, "decode batch of " << n << " samples failed before it was scheduled on device " << device_);
         return NVIMGCODEC_STATUS_EXTENSION_EXECUTION_FAILED;
     }
-
-    const auto t_plan = std::chrono::steady_clock::now();
-    job->remaining.store(n);
-    nvimgcodecExecutorDesc_t* ex = ep_->executor;
-    if (n == 1 || !ex) {
-        for (int i = 0; i < n; i++) host_task(0, i, job);  // single image: run inline like the reference (:565-566)
-    } else {
-        for (int i = 0; i < n; i++) {
-            if (ex->launch(ex->instance, device_, i, job, &HipJpegDecoder::host_task) != NVIMGCODEC_STATUS_SUCCESS) host_task(0, i, job);
-        }
-    }
-    if (timing) {
-        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        const auto t_end = std::chrono::steady_clock::now();
-        fprintf(stderr, "[hipjpeg] plugin decode(%d): wait for a job page + marshal %.2f ms, plan %.2f ms, hand to executor %.2f ms\n", n,
-                ms(t_enter, t_marshal), ms(t_marshal, t_plan), ms(t_plan, t_end));
-    }
-    return NVIMGCODEC_STATUS_SUCCESS;
 }
 
 // ------------------------------------------------------------------------------------------------ plugin (factory) object

@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -58,6 +59,8 @@ public:
     int num_threads() const { return nthreads_; }
 
     // Runs fn(index, thread_id) for index in [0, n); indices are handed out dynamically.  Blocks until done.
+    // An exception thrown by fn on any thread stops the hand-out of further indices and is rethrown here, on the calling
+    // thread, once every helper has come back (a throw inside a helper thread would otherwise end the process).
     void parallel_for(int n, const std::function<void(int, int)>& fn)
     {
         if (n <= 0) return;
@@ -71,6 +74,7 @@ public:
             job_n_ = n;
             next_.store(0);
             pending_ = nthreads_ - 1;
+            failure_ = nullptr;
             generation_++;
         }
         cv_.notify_all();
@@ -78,6 +82,12 @@ public:
         std::unique_lock<std::mutex> lk(m_);
         done_cv_.wait(lk, [this] { return pending_ == 0; });
         job_ = nullptr;
+        if (failure_) {
+            std::exception_ptr e = failure_;
+            failure_ = nullptr;
+            lk.unlock();
+            std::rethrow_exception(e);
+        }
     }
 
 private:
@@ -86,7 +96,13 @@ private:
         for (;;) {
             int i = next_.fetch_add(1);
             if (i >= n) break;
-            fn(i, tid);
+            try {
+                fn(i, tid);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!failure_) failure_ = std::current_exception();
+                next_.store(n);  // nobody starts another index
+            }
         }
     }
     void worker_loop(int tid)
@@ -120,6 +136,7 @@ private:
     unsigned generation_ = 0;
     bool stop_ = false;
     std::atomic<int> next_{0};
+    std::exception_ptr failure_;
 };
 
 }  // namespace hipjpeg

@@ -1,0 +1,146 @@
+"""Parity at BASELINE.json's FULL sizes (round-1 verdict: the small goldens leave holes).  Every image of a 256 x 1080p batch
+on both entropy stages, the non-everyday kernel flavours (planar / BGR / unaligned / fancy_upsampling=0) at 1080p and 4K,
+and configs[4] (progressive 4:4:4 -> planar RGB) at 1920x1080.  Tolerance 0 -- the reference's own GPU test is a memcmp
+(test/extensions/nvjpeg_ext_decoder_test.cpp:108-145)."""
+import io
+
+import numpy as np
+import pytest
+
+import oracle
+from nvimagecodec_amd.synth import synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def dec(torch_mod):
+    from nvimagecodec_amd.lowlevel import BatchDecoder
+    d = BatchDecoder(device=0, num_threads=8)
+    yield d
+    d.close()
+
+
+def _progressive(im, quality, sub):
+    """Progressive inputs come from libjpeg-turbo itself (Pillow) where the box has it, else from the product's own
+    encoder once it writes progressive streams; a box with neither skips."""
+    try:
+        from PIL import Image
+    except ImportError:
+        pytest.skip("no progressive encoder on this box")
+    b = io.BytesIO()
+    Image.fromarray(im).save(b, "JPEG", quality=quality, subsampling={"444": 0, "422": 1, "420": 2}[sub], progressive=True)
+    return b.getvalue()
+
+
+@pytest.mark.parametrize("gpu_huffman", [False, True], ids=["host_entropy", "gpu_entropy"])
+def test_config1_every_image_of_the_256_batch(torch_mod, dec, gpu_huffman):
+    """BASELINE configs[1] at its stated size: batch 256, 1920x1080, 4:2:0, q90 -> I_RGB; all 256 outputs compared (on the
+    device, against the oracle's pixels of the 8 distinct sources)."""
+    torch = torch_mod
+    sources = [oracle.encode(synth_image(1920, 1080, seed=1234 + s), "420", 90) for s in range(8)]
+    refs = [torch.from_numpy(oracle.decode(j)).cuda() for j in sources]
+    jpegs = [sources[i % 8] for i in range(256)]
+    outs = dec.allocate_outputs(jpegs, "rgb")
+    for o in outs:
+        o.fill_(0x5A)
+    _, st = dec.decode(jpegs, fmt="rgb", outs=outs, gpu_huffman=gpu_huffman)
+    torch.cuda.synchronize()
+    assert all(s == 0 for s in st)
+    assert dec.stats()["gpu_entropy_images"] == (256 if gpu_huffman else 0)
+    bad = [i for i, o in enumerate(outs) if not torch.equal(o, refs[i % 8])]
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("gpu_huffman", [False, True], ids=["host_entropy", "gpu_entropy"])
+def test_config1_pipelined_submissions_every_image(torch_mod, dec, gpu_huffman):
+    """The same batch through hipjpegDecodeBatchSubmit/Wait, three batches in flight, every output of every batch."""
+    torch = torch_mod
+    sources = [oracle.encode(synth_image(1920, 1080, seed=1234 + s), "420", 90) for s in range(4)]
+    refs = [torch.from_numpy(oracle.decode(j)).cuda() for j in sources]
+    jpegs = [sources[(3 * i) % 4] for i in range(64)]
+    ring = [dec.allocate_outputs(jpegs, "rgb") for _ in range(3)]
+    for k in range(6):
+        for o in ring[k % 3]:
+            o.zero_()
+        dec.submit(jpegs, ring[k % 3], gpu_huffman=gpu_huffman)
+        if k >= 2:
+            assert all(s == 0 for s in dec.wait())
+    dec.wait()
+    dec.wait()
+    torch.cuda.synchronize()
+    for outs in ring:
+        for i, o in enumerate(outs):
+            assert torch.equal(o, refs[(3 * i) % 4]), i
+
+
+def _strided(torch, h, w, ch, pitch, offset):
+    buf = torch.full((h * pitch + 256,), 0xAB, dtype=torch.uint8, device="cuda")
+    return buf, torch.as_strided(buf, (h, w, ch), (pitch, ch, 1), storage_offset=offset)
+
+
+@pytest.mark.parametrize("shape", [(1920, 1080), (3840, 2160), (1913, 1075)], ids=["1080p", "4k", "odd"])
+@pytest.mark.parametrize("sub", ["420", "422", "444"])
+def test_generic_kernel_flavours_at_full_size(torch_mod, dec, shape, sub):
+    """Everything that is NOT the COMMON flavour of the luma/colour kernel, at 1080p and 4K: BGR, planar RGB/BGR, an
+    interleaved output that is not 16-byte aligned (odd offset, odd pitch), luma only, raw YUV planes, and
+    fancy_upsampling=0 (parity unpinned by libjpeg-turbo vectors: checked against the oracle's replication path only)."""
+    torch = torch_mod
+    w, h = shape
+    jpeg = oracle.encode(synth_image(w, h, seed=w + h + int(sub)), sub, 90)
+    rgb = oracle.decode(jpeg)
+    bgr = oracle.decode(jpeg, oracle.FMT_BGR)
+    for gh in (False, True):
+        for fmt, ref in (("bgr", bgr), ("rgb_planar", rgb.transpose(2, 0, 1)), ("bgr_planar", bgr.transpose(2, 0, 1)),
+                         ("y", oracle.decode(jpeg, oracle.FMT_GRAY))):
+            outs, _ = dec.decode([jpeg], fmt=fmt, gpu_huffman=gh)
+            torch.cuda.synchronize()
+            assert np.array_equal(outs[0].cpu().numpy(), ref), (fmt, gh)
+        outs, _ = dec.decode([jpeg], fmt="yuv_planar", gpu_huffman=gh)
+        torch.cuda.synchronize()
+        for a, b in zip(outs[0], oracle.decode_planes(jpeg)):
+            assert np.array_equal(a.cpu().numpy(), b), gh
+        # unaligned interleaved RGB
+        buf, view = _strided(torch, h, w, 3, w * 3 + 7, 3)
+        dec.decode([jpeg], fmt="rgb", outs=[view], gpu_huffman=gh)
+        torch.cuda.synchronize()
+        assert np.array_equal(view.cpu().numpy(), rgb), gh
+        assert int(buf[:3].min()) == 0xAB and int(buf[-200:].min()) == 0xAB
+        # replication instead of the triangle filter
+        outs, _ = dec.decode([jpeg], fmt="rgb", fancy=False, gpu_huffman=gh)
+        torch.cuda.synchronize()
+        assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(jpeg, oracle.FMT_RGB, fancy=False)), gh
+
+
+def test_config4_progressive_444_planar_at_1080p(torch_mod, dec):
+    """BASELINE configs[4] at its stated size: 1920x1080 progressive 4:4:4 (libjpeg-turbo's 10-scan script) -> P_RGB,
+    a batch with 4 distinct sources; host entropy stage and GPU entropy flag (progressive scans that the GPU stage takes
+    must give the same pixels; the ones it does not take stay on the host stage)."""
+    torch = torch_mod
+    sources = [_progressive(synth_image(1920, 1080, seed=900 + k), 90, "444") for k in range(4)]
+    refs = [torch.from_numpy(np.ascontiguousarray(oracle.decode(j).transpose(2, 0, 1))).cuda() for j in sources]
+    jpegs = [sources[i % 4] for i in range(16)]
+    for gh in (False, True):
+        outs, st = dec.decode(jpegs, fmt="rgb_planar", gpu_huffman=gh)
+        torch.cuda.synchronize()
+        assert all(s == 0 for s in st)
+        for i, o in enumerate(outs):
+            assert torch.equal(o, refs[i % 4]), (gh, i)
+
+
+def test_progressive_420_and_422_at_1080p(torch_mod, dec):
+    torch = torch_mod
+    for sub in ("420", "422"):
+        j = _progressive(synth_image(1920, 1080, seed=77), 85, sub)
+        ref = oracle.decode(j)
+        for gh in (False, True):
+            outs, _ = dec.decode([j, j], fmt="rgb", gpu_huffman=gh)
+            torch.cuda.synchronize()
+            assert np.array_equal(outs[1].cpu().numpy(), ref), (sub, gh)

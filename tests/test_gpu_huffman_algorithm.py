@@ -98,3 +98,42 @@ def test_damaged_restart_intervals_are_reported():
         coefs, _ = lowlevel.entropy_decode_gpu_algorithm_host(good)
         ref, _ = oracle.decode_coefficients(good)
         assert all(np.array_equal(a, b) for a, b in zip(coefs, ref))
+
+
+def test_damaged_streams_get_the_host_verdict():
+    """Host entropy decoder and GPU algorithm must agree on WHETHER a damaged stream decodes (a final symbol that reaches
+    into the slack behind the data used to be accepted by the GPU algorithm only), and on the coefficients when it does."""
+    import random
+    cases = [load_decode_case(e)[0] for e in _M["decode"] if not e["progressive"] and e["width"] <= 64]
+    rng = random.Random(20261004)
+    checked = 0
+    for _ in range(4000):
+        j = bytearray(rng.choice(cases))
+        sos = j.rfind(b"\xff\xda")
+        lo = sos + 4 + j[sos + 3]
+        if lo >= len(j) - 3:
+            continue
+        k = rng.randrange(lo, len(j) - 2)
+        mode = rng.randrange(3)
+        if mode == 0:
+            j[k] ^= 1 << rng.randrange(8)
+        elif mode == 1:
+            j = j[:k] + j[-2:]
+        else:
+            j[k] = rng.randrange(256)
+        j = bytes(j)
+
+        def run(fn):
+            try:
+                return 0, fn(j)[0]
+            except N.HipJpegError as e:
+                return e.status, None
+        sg, cg = run(lowlevel.entropy_decode_gpu_algorithm_host)
+        if sg == 3:
+            continue  # the damage made the stream ineligible (marker inside the scan): host stage only
+        sh, ch = run(lowlevel.entropy_decode_host)
+        assert (sh == 0) == (sg == 0), (sh, sg, j.hex())
+        if sh == 0:
+            assert all(np.array_equal(a[: b.shape[0]], b) for a, b in zip(cg, ch))
+        checked += 1
+    assert checked > 2000
