@@ -932,7 +932,7 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which, void* entropy_strea
         if (es_stream != stream && hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)copied_event_, 0) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
         copy_pending_ = false;
     }
-    if ((which < 0 && !entropy_done_) || which == 3) {
+    if ((which < 0 && !entropy_done_) || which == 3 || which == 6) {
         hipjpegStatus_t es = enqueue_gpu_entropy(es_stream);
         if (es != HIPJPEG_STATUS_SUCCESS) return es;
         if (which == 3) return resolve(stream);
@@ -947,7 +947,7 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which, void* entropy_strea
                 return HIPJPEG_STATUS_HIP_ERROR;
         }
     }
-    if (launch_pixel_kernels(stream, which) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (which != 6 && launch_pixel_kernels(stream, which) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (which < 0) pixels_launched_ = true;
     if (!done_event_) {
         hipEvent_t ev;
