@@ -12,6 +12,7 @@
 #include "diagnostics.h"
 #include "entropy_decode.h"
 #include "gpu_huffman_host.h"
+#include "progressive_gpu_host.h"
 
 namespace hipjpeg {
 
@@ -207,12 +208,17 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     entropy_pending_ = false;  // a caller that re-plans without resolve() gives up the statuses of the previous batch
     huff_images_.clear();
     huff_to_image_.clear();
+    prog_images_.clear();
+    prog_to_image_.clear();
+    prog_scan_total_ = 0;
+    prog_slot_words_ = 0;
+    max_prog_units_ = 0;
 
     size_t max_units = 0, coef_total = 0, plane_total = 0, max_xform_units = 0;
     std::vector<size_t> xform_plane_off;  // per TransformImage plane, in order
     xform_desc_.clear();
     size_t huff_stream_total = 0, huff_subseq_ub = 0, huff_pool_total = 0, huff_blocks_total = 0, huff_raw_total = 0, huff_chunks_total = 0;
-    size_t huff_blockpos_total = 0, huff_boundary_total = 0;
+    size_t huff_blockpos_total = 0, huff_boundary_total = 0, prog_pos_total = 0;
     max_huff_units_ = max_huff_wunits_ = 0;
     max_pool_words_ = 0;
     std::vector<size_t> plane_off((size_t)n * 4, (size_t)-1);
@@ -279,6 +285,9 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
         if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && gpu_entropy_eligible(f)) {
             im.gpu_entropy = true;
             im.pool_words = gpu_pool_words(f.scans[0]);
+        } else if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && gpu_progressive_eligible(f)) {
+            im.gpu_entropy = im.gpu_prog = true;
+            im.pool_words = prog_pool_words(f);
         }
     };
     if (pool && n > 1)
@@ -365,7 +374,41 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
             if (c == 0 && im.variant >= 0) max_units += (size_t)((k.blocks_w + kLumaTileW - 1) / kLumaTileW) * (size_t)((k.blocks_h + kLumaTileH - 1) / kLumaTileH);
         }
         if (im.variant == -1) max_units += (size_t)f.height;
-        if (im.gpu_entropy) {
+        if (im.gpu_prog) {
+            // progressive: every scan is staged and destuffed like a baseline scan; the walk and replay kernels take it from there
+            im.prog_index = (int)prog_to_image_.size();
+            prog_to_image_.push_back(i);
+            im.prog_huff_first = (uint32_t)prog_scan_total_;
+            prog_scan_total_ += f.scans.size();
+            for (size_t sidx = 0; sidx < f.scans.size(); sidx++) {
+                const ScanHeader& sc = f.scans[sidx];
+                const size_t raw_len = sc.data_end - sc.data_begin;
+                im.prog_raw_offset[sidx] = huff_raw_total;  // relative; rebased below
+                huff_raw_total += align_up(raw_len, 16) + 16;
+                im.prog_stream_offset[sidx] = huff_stream_total;
+                huff_stream_total += align_up(destuffed_capacity(sc), 64);
+                im.prog_first_chunk[sidx] = (uint32_t)huff_chunks_total;
+                huff_chunks_total += (raw_len + kDestuffChunk - 1) / kDestuffChunk;
+                if (sc.ss != 0) {
+                    const int cc = sc.comp_index[0];
+                    const size_t nb = (size_t)((f.comp[cc].samp_w + 7) / 8) * (size_t)((f.comp[cc].samp_h + 7) / 8);
+                    im.prog_pos_offset[sidx] = prog_pos_total * 4;
+                    prog_pos_total += (nb + 63) & ~(size_t)63;
+                    prog_slot_words_ = std::max<unsigned>(prog_slot_words_, (unsigned)prog_table_words(sc.ac[sc.ta[0]]));
+                } else if (sc.ah == 0) {
+                    for (int k = 0; k < sc.ncomp; k++)
+                        prog_slot_words_ = std::max<unsigned>(prog_slot_words_, (unsigned)prog_table_words(sc.dc[sc.td[k]]));
+                }
+            }
+            im.tables_offset = huff_pool_total;  // relative; rebased below
+            huff_pool_total += align_up(im.pool_words * 2, 64);
+            for (int c = 0; c < f.ncomp; c++) {  // compact DC planes, in the same scratch as the baseline path's
+                im.dc_plane_offset[c] = huff_blocks_total * 2;
+                const size_t nblk = (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+                huff_blocks_total += (nblk + 31) & ~(size_t)31;
+                max_prog_units_ += (nblk + 255) / 256;
+            }
+        } else if (im.gpu_entropy) {
             im.huff_index = (int)huff_to_image_.size();
             huff_to_image_.push_back(i);
             const size_t raw_len = f.scans[0].data_end - f.scans[0].data_begin;
@@ -410,14 +453,17 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     desc_offset_ = 0;
     units_offset_ = align_up(desc_offset_ + sizeof(DecodeImage) * (size_t)n, 256);
     huff_desc_offset_ = align_up(units_offset_ + sizeof(WorkUnit) * max_units, 256);
-    huff_units_offset_ = align_up(huff_desc_offset_ + sizeof(HuffImage) * ng, 256);
+    huff_units_offset_ = align_up(huff_desc_offset_ + sizeof(HuffImage) * (ng + prog_scan_total_), 256);
     huff_wunits_offset_ = align_up(huff_units_offset_ + sizeof(HuffUnit) * max_huff_units_, 256);
     huff_dc_units_offset_ = align_up(huff_wunits_offset_ + sizeof(HuffUnit) * max_huff_wunits_, 256);
     huff_list_offset_ = align_up(huff_dc_units_offset_ + sizeof(HuffUnit) * ng * 4, 256);
+    // (the HuffImage array holds the baseline images first, then one entry per scan of the progressive images)
     huff_chunk_units_offset_ = align_up(huff_list_offset_ + sizeof(uint32_t) * ng, 256);
     xform_desc_offset_ = align_up(huff_chunk_units_offset_ + sizeof(HuffUnit) * huff_chunks_total, 256);
     xform_units_offset_ = align_up(xform_desc_offset_ + sizeof(TransformImage) * xform_desc_.size(), 256);
-    const size_t tables_base = align_up(xform_units_offset_ + sizeof(WorkUnit) * max_xform_units, 256);
+    prog_desc_offset_ = align_up(xform_units_offset_ + sizeof(WorkUnit) * max_xform_units, 256);
+    prog_units_offset_ = align_up(prog_desc_offset_ + sizeof(ProgImage) * prog_to_image_.size(), 256);
+    const size_t tables_base = align_up(prog_units_offset_ + sizeof(HuffUnit) * max_prog_units_, 256);
     const size_t boundaries_base = align_up(tables_base + huff_pool_total, 256);
     const size_t streams_base = align_up(boundaries_base + huff_boundary_total, 256);
     coef_offset_ = align_up(streams_base + huff_raw_total, 256);
@@ -438,6 +484,8 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
                 im.raw_offset += streams_base;
                 im.boundary_offset += boundaries_base;
                 im.tables_offset += tables_base;
+                if (im.gpu_prog)
+                    for (size_t sidx = 0; sidx < im.frame.scans.size(); sidx++) im.prog_raw_offset[sidx] += streams_base;
             }
         }
     }
@@ -464,9 +512,11 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     work_dc_diff_ = align_up(work_tail_ + max_huff_units_ * 260, 256);
     work_block_pos_ = align_up(work_dc_diff_ + huff_blocks_total * 2, 256);
     work_drops_ = align_up(work_block_pos_ + huff_blockpos_total * 4, 256);
-    work_streams_ = align_up(work_drops_ + huff_chunks_total * 4, 256);
-    if (ng && (st = work_.reserve(work_streams_ + huff_stream_total + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
-    huff_images_.assign(ng, HuffImage());
+    work_prog_pos_ = align_up(work_drops_ + huff_chunks_total * 4, 256);
+    work_streams_ = align_up(work_prog_pos_ + prog_pos_total * 4, 256);
+    if ((ng || prog_scan_total_) && (st = work_.reserve(work_streams_ + huff_stream_total + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
+    huff_images_.assign(ng + prog_scan_total_, HuffImage());
+    prog_images_.assign(prog_to_image_.size(), ProgImage());
 
     for (int i = 0; i < n; i++) {
         if (images_[i].status != HIPJPEG_STATUS_SUCCESS) continue;
@@ -507,6 +557,25 @@ void DecodeBatch::entropy_stage(int i)
     if (im.status != HIPJPEG_STATUS_SUCCESS) return;
     ScopedRange range(im.gpu_entropy ? "hipjpeg host stage (stage bitstream, is_gpu_huffman=1)" : "hipjpeg host stage (Huffman decode, is_gpu_huffman=0)");
     fault_point("entropy_stage");
+    if (im.gpu_prog) {
+        // progressive: stage every scan's bytes as they are, expand the scans' Huffman tables, describe scans and chains
+        const FrameInfo& f = im.frame;
+        for (size_t sidx = 0; sidx < f.scans.size(); sidx++) {
+            const ScanHeader& sc = f.scans[sidx];
+            const size_t len = sc.data_end - sc.data_begin;
+            uint8_t* raw = pinned_.data() + im.prog_raw_offset[sidx];
+            memcpy(raw, im.data + sc.data_begin, len);
+            memset(raw + len, 0x01, align_up(len, 16) + 16 - len);  // neither FF nor 00
+            HuffImage& h = huff_images_[huff_to_image_.size() + im.prog_huff_first + sidx];
+            memset(&h, 0, sizeof h);
+            h.raw_bytes = (uint32_t)len;
+            h.first_chunk = im.prog_first_chunk[sidx];
+            im.stream_bytes += (uint32_t)len;
+        }
+        fill_prog_image(f, &prog_images_[im.prog_index], reinterpret_cast<uint16_t*>(pinned_.data() + im.tables_offset));
+        for (int c = 0; c < f.ncomp; c++) im.coef_or[c] = 32767u;  // successive approximation: any int16 may come out
+        return;
+    }
     if (im.gpu_entropy) {
         // host part of the GPU entropy path: stage the scan's bytes as they are (the device removes the byte stuffing),
         // expand the Huffman tables, describe the scan
@@ -646,7 +715,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
     huff_list_.clear();
     uint32_t first_subseq = 0;
     stream_bytes_total_ = 0;
-    for (size_t g = 0; g < huff_images_.size(); g++) {
+    for (size_t g = 0; g < huff_to_image_.size(); g++) {
         PlannedImage& im = images_[huff_to_image_[g]];
         HuffImage& h = huff_images_[g];
         if (im.status != HIPJPEG_STATUS_SUCCESS) {
@@ -676,6 +745,43 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         stream_bytes_total_ += im.stream_bytes;
     }
     total_subseq_ = first_subseq;
+    // progressive images: pointers of the scan descriptors, chunk units for the destuff kernels, units of the replay kernel
+    prog_units_.clear();
+    for (size_t q = 0; q < prog_images_.size(); q++) {
+        PlannedImage& im = images_[prog_to_image_[q]];
+        ProgImage& pi = prog_images_[q];
+        if (im.status != HIPJPEG_STATUS_SUCCESS) {
+            pi.num_scans = 0;
+            pi.ncomp = 0;
+            pi.dc_len = 0;
+            memset(pi.chain_len, 0, sizeof pi.chain_len);
+            continue;
+        }
+        const FrameInfo& f = im.frame;
+        for (size_t sidx = 0; sidx < f.scans.size(); sidx++) {
+            const size_t hidx = huff_to_image_.size() + im.prog_huff_first + sidx;
+            HuffImage& h = huff_images_[hidx];
+            h.stream = work_.data() + work_streams_ + im.prog_stream_offset[sidx];
+            h.raw = device_.data() + im.prog_raw_offset[sidx];
+            ProgScan& ps = pi.scan[sidx];
+            ps.stream = h.stream;
+            ps.huff_image = (uint32_t)hidx;
+            ps.block_pos = f.scans[sidx].ss != 0 ? reinterpret_cast<uint32_t*>(work_.data() + work_prog_pos_ + im.prog_pos_offset[sidx]) : nullptr;
+            for (uint32_t c = 0; c * (uint32_t)kDestuffChunk < h.raw_bytes; c++) huff_chunk_units_.push_back(HuffUnit{(uint32_t)hidx, c});
+        }
+        pi.pool = reinterpret_cast<const uint16_t*>(device_.data() + im.tables_offset);
+        for (int c = 0; c < f.ncomp; c++) {
+            pi.coef[c] = reinterpret_cast<int16_t*>(device_.data() + im.coef_offset[c]);
+            pi.dc_plane[c] = reinterpret_cast<int16_t*>(work_.data() + work_dc_diff_ + im.dc_plane_offset[c]);
+            const uint32_t nblk = (uint32_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+            for (uint32_t b = 0; b < nblk; b += 256) prog_units_.push_back(HuffUnit{(uint32_t)q, ((uint32_t)c << 28) | b});
+        }
+        stream_bytes_total_ += im.stream_bytes;
+    }
+    if (!prog_images_.empty()) {
+        memcpy(base + prog_desc_offset_, prog_images_.data(), sizeof(ProgImage) * prog_images_.size());
+        if (!prog_units_.empty()) memcpy(base + prog_units_offset_, prog_units_.data(), sizeof(HuffUnit) * prog_units_.size());
+    }
     if (!huff_images_.empty()) {
         memcpy(base + huff_desc_offset_, huff_images_.data(), sizeof(HuffImage) * huff_images_.size());
         if (!huff_units_.empty()) memcpy(base + huff_units_offset_, huff_units_.data(), sizeof(HuffUnit) * huff_units_.size());
@@ -722,12 +828,20 @@ hipjpegStatus_t DecodeBatch::enqueue_gpu_entropy(void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     entropy_done_ = true;
-    if (huff_units_.empty()) return HIPJPEG_STATUS_SUCCESS;
+    if (huff_units_.empty() && prog_units_.empty()) return HIPJPEG_STATUS_SUCCESS;
     EntropyLaunch L = entropy_launch_args();
     if (hipMemsetAsync(L.changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_destuff(L.dimg, reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(),
                        reinterpret_cast<uint32_t*>(work_.data() + work_drops_), stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
+    if (!prog_units_.empty()) {
+        const hipjpegStatus_t ps = enqueue_progressive(stream);
+        if (ps != HIPJPEG_STATUS_SUCCESS) return ps;
+    }
+    if (huff_units_.empty()) {
+        entropy_pending_ = true;
+        return HIPJPEG_STATUS_SUCCESS;
+    }
     static const int tail_after = getenv("HIPJPEG_TAIL_AFTER") ? atoi(getenv("HIPJPEG_TAIL_AFTER")) : 2;  // tuning aid; 0 = no tail kernel
     uint8_t* tail_tasks = work_.data() + work_tail_;
     uint32_t* tail_count = reinterpret_cast<uint32_t*>(work_.data() + work_tail_ + (size_t)max_huff_units_ * 256);
@@ -740,6 +854,21 @@ hipjpegStatus_t DecodeBatch::enqueue_gpu_entropy(void* stream)
     if (hipMemcpyAsync(L.host_changed, L.changed, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     if (hipMemcpyAsync(L.himg, L.dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     entropy_pending_ = true;
+    return HIPJPEG_STATUS_SUCCESS;
+}
+
+// Progressive images: walk (block start positions of every scan, DC planes), replay (coefficient blocks), verdicts back.
+hipjpegStatus_t DecodeBatch::enqueue_progressive(void* stream)
+{
+    ProgImage* dprog = reinterpret_cast<ProgImage*>(device_.data() + prog_desc_offset_);
+    const HuffImage* dimg = reinterpret_cast<const HuffImage*>(device_.data() + huff_desc_offset_);
+    const unsigned slot = (unsigned)align_up(std::max<unsigned>(prog_slot_words_, 256u), 64);
+    if (launch_prog_walk(dprog, dimg, (int)prog_images_.size(), slot, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+    if (launch_prog_replay(dprog, dimg, reinterpret_cast<const HuffUnit*>(device_.data() + prog_units_offset_), (int)prog_units_.size(), slot, stream) != 0)
+        return HIPJPEG_STATUS_HIP_ERROR;
+    if (hipMemcpyAsync(pinned_.data() + prog_desc_offset_, dprog, sizeof(ProgImage) * prog_images_.size(), hipMemcpyDeviceToHost,
+                       (hipStream_t)stream) != hipSuccess)
+        return HIPJPEG_STATUS_HIP_ERROR;
     return HIPJPEG_STATUS_SUCCESS;
 }
 
@@ -807,7 +936,8 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
         fprintf(stderr, "[hipjpeg] entropy: %d workgroups, launch 1 rounds avg %.2f max %u, tail rounds avg %.2f max %u; launch 2: %u rounds in total, max %u, %u boundary changes\n",
                 nunits, (double)sync_rounds_total_ / nunits, sync_rounds_max_, (double)host_changed[6] / nunits, host_changed[7], host_changed[4],
                 host_changed[5], host_changed[0]);
-    bool converged = *host_changed == 0;
+    const bool has_baseline = !huff_units_.empty();
+    bool converged = has_baseline ? *host_changed == 0 : true;
     if (!converged) {
         for (int pass = 0; pass < 64 && !converged; pass++) {
             if (hipMemsetAsync(changed, 0, sizeof(unsigned int), s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
@@ -828,12 +958,9 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
             redo_pixels = true;
         }
     }
-    for (size_t g = 0; g < huff_images_.size(); g++) {
-        PlannedImage& im = images_[huff_to_image_[g]];
-        if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
-        if (converged && himg[g].status == 0) continue;
-        // The kernels could not vouch for this stream: let the host entropy decoder produce either the coefficients or the
-        // precise error.  (Rare path: corrupt / truncated data.)
+    // The kernels could not vouch for a stream: the host entropy decoder produces either the coefficients or the precise
+    // error.  (Rare path: corrupt / truncated data.)
+    auto host_takes_over = [&](PlannedImage& im) -> hipjpegStatus_t {
         const FrameInfo& f = im.frame;
         std::vector<int16_t> tmp(f.total_blocks() * 64);
         int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -845,17 +972,41 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
         EntropyStatus es = decode_coefficients(im.data, im.size, f, coef, nullptr);
         if (es != kEntropyOk) {
             im.status = es == kEntropyTruncated ? HIPJPEG_STATUS_TRUNCATED : HIPJPEG_STATUS_CORRUPT;
-            continue;
+            return HIPJPEG_STATUS_SUCCESS;
         }
         for (int c = 0; c < f.ncomp; c++) {
             const size_t nblk = (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
             std::vector<int16_t> dc(nblk);  // the kernels take this image's DC values from its compact DC plane
-            for (size_t b = 0; b < nblk; b++) dc[b] = coef[c][b * 64];
+            for (size_t b = 0; b < nblk; b++) {
+                dc[b] = coef[c][b * 64];
+                coef[c][b * 64] = 0;
+            }
             if (hipMemcpy(device_.data() + im.coef_offset[c], coef[c], nblk * 128, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(work_.data() + work_dc_diff_ + im.dc_plane_offset[c], dc.data(), nblk * 2, hipMemcpyHostToDevice) != hipSuccess)
                 return HIPJPEG_STATUS_HIP_ERROR;
         }
         redo_pixels = true;
+        return HIPJPEG_STATUS_SUCCESS;
+    };
+    for (size_t g = 0; g < huff_to_image_.size(); g++) {
+        PlannedImage& im = images_[huff_to_image_[g]];
+        if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
+        if (converged && himg[g].status == 0) continue;
+        const hipjpegStatus_t hs = host_takes_over(im);
+        if (hs != HIPJPEG_STATUS_SUCCESS) return hs;
+    }
+    const ProgImage* hprog = reinterpret_cast<const ProgImage*>(pinned_.data() + prog_desc_offset_);
+    if (debug_stats && !prog_to_image_.empty()) {
+        const ProgImage& q0 = hprog[0];
+        for (uint32_t k = 0; k < q0.num_scans; k++)
+            fprintf(stderr, "[hipjpeg] progressive image 0 scan %u (ss %u se %u ah %u al %u): walk %.3f ms\n", k, q0.scan[k].ss, q0.scan[k].se, q0.scan[k].ah,
+                    q0.scan[k].al, q0.scan[k].walk_ticks * 1e-5);
+    }
+    for (size_t q = 0; q < prog_to_image_.size(); q++) {
+        PlannedImage& im = images_[prog_to_image_[q]];
+        if (im.status != HIPJPEG_STATUS_SUCCESS || hprog[q].status == 0) continue;
+        const hipjpegStatus_t hs = host_takes_over(im);
+        if (hs != HIPJPEG_STATUS_SUCCESS) return hs;
     }
     if (redo_pixels && pixels_launched_) {
         // the pixel kernels already ran on coefficients that have just been replaced

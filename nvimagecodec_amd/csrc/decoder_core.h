@@ -12,6 +12,7 @@
 #include "../../include/hipjpeg.h"
 #include "device_layout.h"
 #include "gpu_huffman.h"
+#include "progressive_gpu.h"
 #include "jpeg_syntax.h"
 #include "thread_pool.h"
 
@@ -76,6 +77,15 @@ struct PlannedImage {
     size_t dc_diff_offset = 0;
     size_t dc_plane_offset[4] = {0, 0, 0, 0};  // bytes into the same scratch: compact DC planes per component  // bytes into the DC-difference scratch
     uint32_t stream_bytes = 0;
+    // progressive scans on the GPU entropy stage (progressive_gpu_core.h): gpu_entropy is set as well (device-only coefficient
+    // arena, compact DC planes); every scan has a HuffImage of its own for the destuff kernels
+    bool gpu_prog = false;
+    int prog_index = -1;               // index into the ProgImage array
+    uint32_t prog_huff_first = 0;      // HuffImage index of scan 0, relative to the first progressive one
+    size_t prog_raw_offset[kProgMaxScans] = {0};     // staged copy of each scan's entropy-coded bytes (staging area)
+    size_t prog_stream_offset[kProgMaxScans] = {0};  // destuffed streams (device-only scratch)
+    uint32_t prog_first_chunk[kProgMaxScans] = {0};
+    size_t prog_pos_offset[kProgMaxScans] = {0};     // block positions of the AC scans (device-only scratch)
 };
 
 class DecodeBatch {
@@ -114,7 +124,7 @@ public:
     // Blocks until the kernels of the last launch() have finished (the event recorded behind them).
     hipjpegStatus_t wait_done();
     void* last_stream() const { return last_stream_; }
-    int gpu_entropy_images() const { return (int)huff_images_.size(); }
+    int gpu_entropy_images() const { return (int)(huff_to_image_.size() + prog_to_image_.size()); }
     int last_sync_launches() const { return last_sync_launches_; }
     uint64_t stream_bytes() const { return stream_bytes_total_; }
 
@@ -170,6 +180,13 @@ private:
     size_t xform_desc_offset_ = 0, xform_units_offset_ = 0;
     std::vector<HuffUnit> huff_wunits_;  // block kernel: kHuffMcusPerWg MCUs per workgroup
     std::vector<HuffUnit> huff_chunk_units_;  // offsets into work_
+    // progressive images of the batch
+    std::vector<ProgImage> prog_images_;
+    std::vector<int> prog_to_image_;
+    std::vector<HuffUnit> prog_units_;  // replay kernel: {ProgImage index, component << 28 | first block}
+    size_t prog_desc_offset_ = 0, prog_units_offset_ = 0, max_prog_units_ = 0, prog_scan_total_ = 0, work_prog_pos_ = 0;
+    unsigned prog_slot_words_ = 0;
+    hipjpegStatus_t enqueue_progressive(void* stream);
     uint64_t stream_bytes_total_ = 0;
     int last_sync_launches_ = 0;
     unsigned sync_rounds_total_ = 0, sync_rounds_max_ = 0;  // correction rounds of the first sync launch (sum over workgroups, maximum)

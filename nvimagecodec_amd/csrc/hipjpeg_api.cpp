@@ -12,6 +12,7 @@
 #include "encoder_core.h"
 #include "entropy_decode.h"
 #include "gpu_huffman_host.h"
+#include "progressive_gpu_host.h"
 #include "thread_pool.h"
 
 #include <chrono>
@@ -167,7 +168,8 @@ hipjpegStatus_t hipjpegEntropyDecodeGpuAlgorithmHost(const uint8_t* data, size_t
     FrameInfo f;
     ParseStatus ps = parse_jpeg(data, length, &f);
     if (ps != kParseOk) return status_from_parse(ps);
-    if (!gpu_entropy_eligible(f)) return HIPJPEG_STATUS_UNSUPPORTED;
+    const bool progressive = gpu_progressive_eligible(f);
+    if (!progressive && !gpu_entropy_eligible(f)) return HIPJPEG_STATUS_UNSUPPORTED;
     if (f.total_blocks() * 128 > coef_capacity_bytes) return HIPJPEG_STATUS_BUFFER_TOO_SMALL;
     int16_t* ptr[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t off = 0;
@@ -177,7 +179,7 @@ hipjpegStatus_t hipjpegEntropyDecodeGpuAlgorithmHost(const uint8_t* data, size_t
         off += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 64;
     }
     int passes = 0;
-    int rc = emulate_gpu_entropy(data, length, f, ptr, &passes);
+    int rc = progressive ? emulate_gpu_progressive(data, length, f, ptr) : emulate_gpu_entropy(data, length, f, ptr, &passes);
     if (sync_passes) *sync_passes = passes;
     return rc == 0 ? HIPJPEG_STATUS_SUCCESS : (rc == 2 ? HIPJPEG_STATUS_TRUNCATED : HIPJPEG_STATUS_CORRUPT);
     });

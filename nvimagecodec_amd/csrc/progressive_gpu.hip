@@ -1,0 +1,496 @@
+// progressive_gpu.hip -- gfx950 kernels for progressive (SOF2) scans on the GPU entropy stage.  Algorithm, data structures and
+// the reasons for the split into a sequential WALK and a parallel REPLAY: progressive_gpu_core.h.
+//
+//   prog_walk_kernel    grid = images x kProgChains workgroups of kProgMaxStages waves.  Workgroup (image, c < 4): the AC scans
+//                       of component c, one wave per scan, pipelined 64 blocks at a time through an LDS ring that carries the
+//                       blocks' history bitmaps from scan to scan.  Workgroup (image, 4): the DC scans, one wave, in file order
+//                       (first scans walked symbol by symbol into the compact DC planes, refinement scans 64 blocks per step).
+//                       A wave runs as a scalar machine: control flow, bit buffer, history bitmap, zigzag position are uniform
+//                       (SGPRs); what it indexes -- 64 stream words, a 64-entry first-level Huffman table, 64 history bitmaps,
+//                       the rank/select table of the current block -- sits in VGPRs and is read with v_readlane.
+//   prog_replay_kernel  one lane per block: all AC scans of the block from the recorded positions, coefficients assembled in
+//                       LDS, blocks stored as whole 128-byte lines (eight lanes per block).
+#include <hip/hip_runtime.h>
+
+#include "gpu_huffman.h"
+#include "progressive_gpu.h"
+#include "progressive_gpu_core.h"
+
+namespace hipjpeg {
+
+namespace {
+
+#define HJ_LDS __attribute__((address_space(3)))
+#define HJ_GLOBAL __attribute__((address_space(1)))
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWalkThreads = 64 * kProgMaxStages;
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+struct WalkShared {
+    unsigned long long ring[kProgMaxStages - 1][kProgRing][kProgGroup];  // history bitmaps handed from stage s to stage s + 1
+    uint32_t done[kProgMaxStages];   // groups stage s has published
+    uint32_t taken[kProgMaxStages];  // groups stage s has taken over from its predecessor
+    uint32_t abort_flag;
+};
+
+// The scalar machine of prog_walk_ac (progressive_gpu_core.h) on one wave.
+struct DevWalker {
+    // stream: the only state of the reader is the bit position p.  Words vbase .. vbase + 63 sit in W (lane j = word vbase + j,
+    // MSB first), W1 holds the same shifted by one lane (lane j = word vbase + j + 1), so a 64-bit window is two readlanes at
+    // ONE index.  X = the following 64 words (needed for W1's last lane), Y = the 64 words after those, as loaded, still in
+    // flight: requested 4096 bits before they are used.
+    const HJ_GLOBAL uint32_t* g;
+    uint32_t nwords;
+    uint32_t lane;
+    uint32_t W, W1, X, Y;
+    uint32_t vbase;
+    uint32_t p;
+    // table
+    uint32_t t6;                    // per lane: first-level entry for the 6-bit prefix `lane` (0 = look in the full table)
+    const HJ_LDS uint16_t* table;   // the scan's full lookup table
+    // per group
+    uint32_t hlo, hhi, pos_out;     // per lane: block 64 g + lane
+    uint32_t zpos;                  // per lane i: position of the i-th zero-history coefficient of the current block
+    int nz;
+    // pipeline
+    WalkShared* sh;
+    int stage, last_stage;
+    uint32_t* block_pos;
+    uint32_t nblocks;
+    bool aborted;
+
+    // 64 words from word `base` on, as they lie in memory (the address is clamped instead of branched around, so that the
+    // load needs no exec mask and nothing waits for it here); swap() turns them MSB first and fills in ones behind the end
+    __device__ __forceinline__ uint32_t fetch_raw(uint32_t base) const
+    {
+        const uint32_t i = base + lane;
+        return g[i < nwords ? i : nwords - 1];
+    }
+    __device__ __forceinline__ uint32_t swap(uint32_t raw, uint32_t base) const { return base + lane < nwords ? __builtin_bswap32(raw) : ~0u; }
+    __device__ __forceinline__ void make_shifted()
+    {
+        const uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 1) & 63u) * 4u), (int)W);  // lane j <- lane j + 1
+        const uint32_t first_of_next = lane_read(X, 0);
+        W1 = lane == 63 ? first_of_next : up;
+    }
+    __device__ __forceinline__ void reposition(uint32_t word_index)
+    {
+        if (word_index - vbase < 128u) {  // the usual step: the next 64 words become the current ones
+            vbase += 64;
+            W = X;
+            X = swap(Y, vbase + 64);
+        } else {                          // a long skip
+            vbase = word_index & ~63u;
+            W = swap(fetch_raw(vbase), vbase);
+            X = swap(fetch_raw(vbase + 64), vbase + 64);
+        }
+        Y = fetch_raw(vbase + 128);
+        make_shifted();
+    }
+    __device__ __forceinline__ void start(const uint32_t* stream, uint32_t stream_words)
+    {
+        g = (const HJ_GLOBAL uint32_t*)stream;
+        nwords = stream_words;
+        vbase = 0;
+        p = 0;
+        W = swap(fetch_raw(0), 0);
+        X = swap(fetch_raw(64), 64);
+        Y = fetch_raw(128);
+        make_shifted();
+    }
+    __device__ __forceinline__ uint32_t window()
+    {
+        uint32_t i = (p >> 5) - vbase;
+        if (__builtin_expect(i >= 64u, 0)) {  // rare: once per 2048 bits
+            reposition(p >> 5);
+            i = (p >> 5) - vbase;
+        }
+        const unsigned long long two = ((unsigned long long)lane_read(W, i) << 32) | lane_read(W1, i);
+        return (uint32_t)((two << (p & 31u)) >> 32);
+    }
+    __device__ __forceinline__ void advance(uint32_t n) { p += n; }
+    __device__ __forceinline__ uint32_t pos() const { return p; }
+    __device__ __forceinline__ uint32_t decode(uint32_t w) const
+    {
+        uint32_t e = lane_read(t6, w >> 26);
+        if (__builtin_expect(e == 0, 0)) {
+            e = table[w >> 24];
+            if (e & kProgLong) e = table[(e & 0x7FFFu) * 256u + ((w >> 16) & 255u)];
+            e = uni(e);
+        }
+        return e;
+    }
+    // 64-entry first-level table in a VGPR: entry j serves every code of at most 6 bits whose prefix is j
+    __device__ __forceinline__ void load_table(const HJ_LDS uint16_t* t)
+    {
+        table = t;
+        const uint32_t a = t[4 * lane], b = t[4 * lane + 1], c = t[4 * lane + 2], d = t[4 * lane + 3];
+        t6 = (a == b && b == c && c == d && !(a & kProgLong) && (a & 31u) <= 6u) ? a : 0u;
+    }
+
+    __device__ __forceinline__ bool wait_for(const uint32_t* counter, uint32_t above)
+    {
+        while (uni(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= above) {
+            if (uni(__hip_atomic_load(&sh->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+                aborted = true;
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return true;
+    }
+    __device__ __forceinline__ void group_begin(uint32_t gi)
+    {
+        hlo = hhi = 0;
+        pos_out = 0;
+        if (stage > 0 && !aborted) {
+            if (wait_for(&sh->done[stage - 1], gi)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const unsigned long long h = sh->ring[stage - 1][gi % kProgRing][lane];
+                hlo = (uint32_t)h;
+                hhi = (uint32_t)(h >> 32);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&sh->taken[stage], gi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __device__ __forceinline__ unsigned long long hist(int j) const
+    {
+        return ((unsigned long long)lane_read(hhi, (uint32_t)j) << 32) | lane_read(hlo, (uint32_t)j);
+    }
+    __device__ __forceinline__ void set_hist(int j, unsigned long long h)
+    {
+        const bool me = lane == (uint32_t)j;  // one compare, two selects (this toolchain has no writelane builtin)
+        hlo = me ? (uint32_t)h : hlo;
+        hhi = me ? (uint32_t)(h >> 32) : hhi;
+    }
+    __device__ __forceinline__ void set_pos(int j, uint32_t v) { pos_out = lane == (uint32_t)j ? v : pos_out; }
+    __device__ __forceinline__ void group_end(uint32_t gi)
+    {
+        const uint32_t b = gi * kProgGroup + lane;
+        if (b < nblocks) ((HJ_GLOBAL uint32_t*)block_pos)[b] = pos_out;
+        if (stage < last_stage && !aborted) {
+            // the slot is free once the next stage has taken group gi - kProgRing
+            if (gi >= (uint32_t)kProgRing && !wait_for(&sh->taken[stage + 1], gi - kProgRing)) return;
+            sh->ring[stage][gi % kProgRing][lane] = ((unsigned long long)hhi << 32) | hlo;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&sh->done[stage], gi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __device__ __forceinline__ void zeros_build(unsigned long long z)
+    {
+        const uint32_t zl = (uint32_t)z, zh = (uint32_t)(z >> 32);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(zh, __builtin_amdgcn_mbcnt_lo(zl, 0u));  // set bits of z below this lane
+        nz = __popcll(z);
+        const bool mine = (z >> lane) & 1ull;
+        const uint32_t target = mine ? rank : (uint32_t)nz + (lane - rank);  // a full permutation: zeros first, in order
+        zpos = (uint32_t)__builtin_amdgcn_ds_permute((int)(target * 4u), (int)lane);
+    }
+    __device__ __forceinline__ int zeros_count() const { return nz; }
+    __device__ __forceinline__ int zero_at(int i) const { return (int)lane_read(zpos, (uint32_t)i); }
+};
+
+// one scan's lookup table: pool (global) -> LDS slot, by one wave
+__device__ __forceinline__ void stage_table(HJ_LDS uint16_t* slot, const uint16_t* pool, uint32_t offset, uint32_t words, uint32_t lane)
+{
+    const HJ_GLOBAL uint32_t* src = (const HJ_GLOBAL uint32_t*)(pool + offset);  // tables start at multiples of 64 entries
+    HJ_LDS uint32_t* dst = (HJ_LDS uint32_t*)slot;
+    for (uint32_t i = lane; i < words / 2; i += 64) dst[i] = src[i];
+}
+
+// entries of the table at pool + offset: first level + the second-level tables it refers to
+__device__ __forceinline__ uint32_t table_words(const uint16_t* pool, uint32_t offset, uint32_t lane)
+{
+    const HJ_GLOBAL uint16_t* t = (const HJ_GLOBAL uint16_t*)(pool + offset);
+    uint32_t m = 0;
+    for (uint32_t i = lane; i < 256; i += 64) {
+        const uint32_t e = t[i];
+        if (e & kProgLong) m = max(m, e & 0x7FFFu);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    return (uni(m) + 1) * 256u;
+}
+
+// ---- DC scans -------------------------------------------------------------------------------------------------------------
+// scan-order block b of a DC scan -> (component, index into its DC plane)
+__device__ __forceinline__ void dc_block_address(const ProgImage& im, const ProgScan& sc, uint32_t b, uint32_t bpm, uint32_t* comp, uint32_t* index,
+                                                 uint32_t* slot)
+{
+    if (sc.ncomp == 1) {
+        const uint32_t c = sc.comps[0], nbx = im.nbx[c];
+        const uint32_t by = b / nbx, bx = b - by * nbx;
+        *comp = c;
+        *slot = 0;
+        *index = by * im.blocks_w[c] + bx;
+        return;
+    }
+    const uint32_t mcu = b / bpm;
+    uint32_t k = b - mcu * bpm;
+    const uint32_t my = mcu / im.mcus_x, mx = mcu - my * im.mcus_x;
+    uint32_t c = sc.comps[0], i = 0;
+    for (; i + 1 < sc.ncomp; i++) {
+        c = sc.comps[i];
+        const uint32_t n = im.comp_h[c] * im.comp_v[c];
+        if (k < n) break;
+        k -= n;
+    }
+    c = sc.comps[i];
+    const uint32_t h = im.comp_h[c], v = im.comp_v[c];
+    const uint32_t dy = k / h, dx = k - dy * h;
+    *comp = c;
+    *slot = i;
+    *index = (my * v + dy) * im.blocks_w[c] + mx * h + dx;
+}
+
+__device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint16_t* tables, uint32_t slot_words, uint32_t lane)
+{
+    DevWalker w;
+    w.lane = lane;
+    w.aborted = false;
+    for (int d = 0; d < (int)im.dc_len; d++) {
+        const ProgScan& sc = im.scan[im.dc_chain[d]];
+        const HuffImage& hi = himgs[sc.huff_image];
+        const uint32_t total_bits = hi.total_bits;
+        uint32_t bpm = 0;
+        for (uint32_t i = 0; i < sc.ncomp; i++) bpm += im.comp_h[sc.comps[i]] * im.comp_v[sc.comps[i]];
+        if (sc.ah != 0) {
+            // refinement: bit b of the scan belongs to block b -- 64 blocks per step
+            if (total_bits < sc.nblocks) return false;
+            const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)sc.stream;
+            for (uint32_t base = 0; base < sc.nblocks; base += 64) {
+                const uint32_t b = base + lane;
+                if (b < sc.nblocks) {
+                    const uint32_t wd = __builtin_bswap32(g[b >> 5]);
+                    if ((wd >> (31 - (b & 31))) & 1u) {
+                        uint32_t c, index, slot;
+                        dc_block_address(im, sc, b, bpm, &c, &index, &slot);
+                        HJ_GLOBAL int16_t* dst = (HJ_GLOBAL int16_t*)im.dc_plane[c] + index;
+                        *dst = (int16_t)(*dst | (1 << sc.al));
+                    }
+                }
+            }
+            __threadfence_block();
+            continue;
+        }
+        // first scan: the tables of its components, then symbol by symbol
+        for (uint32_t i = 0; i < sc.ncomp; i++) stage_table(tables + i * slot_words, im.pool, sc.table[i], table_words(im.pool, sc.table[i], lane), lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
+        int pred[4] = {0, 0, 0, 0};
+        // block order: MCU by MCU, the scan's components in turn (single-component scans: raster over the real blocks)
+        auto one = [&](uint32_t i, uint32_t c, uint32_t index) -> bool {
+            const HJ_LDS uint16_t* t = tables + i * slot_words;
+            const uint32_t win = w.window();
+            uint32_t e = t[win >> 24];
+            if (e & kProgLong) e = t[(e & 0x7FFFu) * 256u + ((win >> 16) & 255u)];
+            e = uni(e);
+            const uint32_t len = e & 31u, sz = (e >> 5) & 255u;
+            if (len == 0 || sz > 15) return false;
+            int diff = 0;
+            if (sz) {  // code (<= 16 bits) and value (<= 15 bits) lie in the same 32-bit window
+                const uint32_t v = (win << len) >> (32 - sz);
+                diff = v < (1u << (sz - 1)) ? (int)v - (int)(1u << sz) + 1 : (int)v;
+            }
+            w.advance(len + sz);
+            pred[i] += diff;
+            if (lane == 0) ((HJ_GLOBAL int16_t*)im.dc_plane[c])[index] = (int16_t)(pred[i] * (1 << sc.al));
+            return true;
+        };
+        if (sc.ncomp == 1) {
+            const uint32_t c = sc.comps[0], nbx = im.nbx[c], nby = im.nby[c], bw = im.blocks_w[c];
+            for (uint32_t by = 0; by < nby; by++)
+                for (uint32_t bx = 0; bx < nbx; bx++)
+                    if (!one(0, c, by * bw + bx)) return false;
+        } else {
+            for (uint32_t my = 0; my < im.mcus_y; my++)
+                for (uint32_t mx = 0; mx < im.mcus_x; mx++)
+                    for (uint32_t i = 0; i < sc.ncomp; i++) {
+                        const uint32_t c = sc.comps[i], h = im.comp_h[c], v = im.comp_v[c], bw = im.blocks_w[c];
+                        for (uint32_t dy = 0; dy < v; dy++)
+                            for (uint32_t dx = 0; dx < h; dx++)
+                                if (!one(i, c, (my * v + dy) * bw + mx * h + dx)) return false;
+                    }
+        }
+        if (w.pos() > total_bits) return false;
+        __threadfence_block();
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __restrict__ images, const HuffImage* __restrict__ himgs, uint32_t slot_words)
+{
+    __shared__ WalkShared sh;
+    extern __shared__ uint16_t dyn_tables[];  // kProgMaxStages slots of slot_words entries
+    HJ_LDS uint16_t* tables = (HJ_LDS uint16_t*)dyn_tables;
+    ProgImage& im = images[blockIdx.x / kProgChains];
+    const int chain = (int)(blockIdx.x % kProgChains);
+    // the wave number is the same in every lane, but only a readfirstlane tells the compiler so: everything the walk branches
+    // on derives from it (which scan, its band, its table), and must live in SGPRs
+    const int wave = (int)uni(threadIdx.x >> 6);
+    const uint32_t lane = lane_id();
+    if (threadIdx.x < kProgMaxStages) {
+        sh.done[threadIdx.x] = 0;
+        sh.taken[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) sh.abort_flag = 0;
+    __syncthreads();
+    bool ok = true;
+    if (chain == 4) {
+        if (wave != 0) return;
+        ok = walk_dc_chain(im, himgs, tables, slot_words, lane);
+    } else {
+        const int c = chain;
+        if (c >= (int)im.ncomp || wave >= (int)im.chain_len[c]) return;
+        const ProgScan& sc = im.scan[im.chain[c][wave]];
+        const HuffImage& hi = himgs[sc.huff_image];
+        HJ_LDS uint16_t* slot = tables + (size_t)wave * slot_words;
+        stage_table(slot, im.pool, sc.table[0], table_words(im.pool, sc.table[0], lane), lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        DevWalker w;
+        w.lane = lane;
+        w.sh = &sh;
+        w.stage = wave;
+        w.last_stage = (int)im.chain_len[c] - 1;
+        w.block_pos = sc.block_pos;
+        w.nblocks = sc.nblocks;
+        w.aborted = false;
+        w.nz = 0;
+        w.zpos = 0;
+        w.load_table(slot);
+        w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
+        const unsigned long long t0 = wall_clock64();
+        ok = prog_walk_ac(w, (int)sc.ss, (int)sc.se, (int)sc.ah, sc.nblocks, hi.total_bits);
+        if (lane == 0) im.scan[im.chain[c][wave]].walk_ticks = (uint32_t)(wall_clock64() - t0);
+        if (w.aborted) ok = false;
+        if (!ok && lane == 0) __hip_atomic_store(&sh.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (!ok && lane == 0) im.status = 1;  // benign race: every writer stores the same value
+}
+
+// ---- replay ---------------------------------------------------------------------------------------------------------------
+constexpr int kRThreads = 256;
+constexpr int kRBlockBytes = 144;  // 128 + 16: the lanes' buffers start in different banks
+
+struct ReplayShared {
+    __attribute__((aligned(16))) uint8_t blocks[kRThreads * kRBlockBytes];
+    int16_t* dst[kRThreads];
+    uint32_t zz[16];
+    uint32_t wave_max[4];
+    uint32_t err;
+};
+
+struct ReplayEnv {
+    const HuffImage* himgs;
+    const HJ_LDS uint16_t* tables;
+    uint32_t slot_words;
+    uint32_t buf;  // LDS byte address of this lane's block buffer
+    const HJ_LDS uint8_t* zz;
+    __device__ __forceinline__ uint32_t word(const ProgScan& sc, uint32_t i) const
+    {
+        const uint32_t n = himgs[sc.huff_image].stream_words;
+        return i < n ? __builtin_bswap32(((const HJ_GLOBAL uint32_t*)sc.stream)[i]) : ~0u;
+    }
+    __device__ __forceinline__ uint32_t lookup(const ProgScan& sc, uint32_t w) const
+    {
+        const HJ_LDS uint16_t* t = tables + (uint32_t)sc.stage * slot_words;
+        uint32_t e = t[w >> 24];
+        if (e & kProgLong) e = t[(e & 0x7FFFu) * 256u + ((w >> 16) & 255u)];
+        return e;
+    }
+    __device__ __forceinline__ int get(int k) const { return *(const HJ_LDS int16_t*)(uintptr_t)(buf + (uint32_t)zz[k] * 2u); }
+    __device__ __forceinline__ void put(int k, int v) const { *(HJ_LDS int16_t*)(uintptr_t)(buf + (uint32_t)zz[k] * 2u) = (int16_t)v; }
+};
+
+// unit = {image, (component << 28) | first block of the allocation grid}
+__global__ __launch_bounds__(kRThreads) void prog_replay_kernel(ProgImage* __restrict__ images, const HuffImage* __restrict__ himgs,
+                                                                const HuffUnit* __restrict__ units, uint32_t slot_words)
+{
+    __shared__ ReplayShared sh;
+    extern __shared__ uint16_t dyn_tables[];
+    HJ_LDS uint16_t* tables = (HJ_LDS uint16_t*)dyn_tables;
+    const HuffUnit u = units[blockIdx.x];
+    ProgImage& im = images[u.image];
+    const int c = (int)(u.first >> 28);
+    const uint32_t first = u.first & 0x0FFFFFFFu;
+    const int t = threadIdx.x;
+    // the component's tables (all waves cooperate), the zigzag permutation, a zeroed buffer per lane
+    for (int st = 0; st < (int)im.chain_len[c]; st++) {
+        const ProgScan& sc = im.scan[im.chain[c][st]];
+        const HJ_GLOBAL uint16_t* src16 = (const HJ_GLOBAL uint16_t*)(im.pool + sc.table[0]);
+        uint32_t m = 0;
+        const uint32_t e = src16[t];
+        if (e & kProgLong) m = e & 0x7FFFu;
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        if ((t & 63) == 0) sh.wave_max[t >> 6] = m;
+        __syncthreads();
+        const uint32_t words = (max(max(sh.wave_max[0], sh.wave_max[1]), max(sh.wave_max[2], sh.wave_max[3])) + 1) * 256u;
+        const HJ_GLOBAL uint32_t* src = (const HJ_GLOBAL uint32_t*)src16;
+        HJ_LDS uint32_t* dst = (HJ_LDS uint32_t*)(tables + (size_t)st * slot_words);
+        for (uint32_t i = t; i < words / 2; i += kRThreads) dst[i] = src[i];
+        __syncthreads();
+    }
+    if (t < 16) {
+        constexpr uint8_t zz[64] = HJ_ZIGZAG_DEVICE_TABLE;
+        sh.zz[t] = (uint32_t)zz[4 * t] | ((uint32_t)zz[4 * t + 1] << 8) | ((uint32_t)zz[4 * t + 2] << 16) | ((uint32_t)zz[4 * t + 3] << 24);
+    }
+    if (t == 0) sh.err = 0;
+    HJ_LDS u32x4* my_buf = (HJ_LDS u32x4*)&sh.blocks[t * kRBlockBytes];
+#pragma unroll
+    for (int i = 0; i < kRBlockBytes / 16; i++) my_buf[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    const uint32_t bw = im.blocks_w[c], total = bw * im.blocks_h[c];
+    const uint32_t a = first + (uint32_t)t;  // block of the allocation grid
+    int16_t* dst = nullptr;
+    if (a < total) {
+        dst = im.coef[c] + (size_t)a * 64;
+        const uint32_t by = a / bw, bx = a - by * bw;
+        if (bx < im.nbx[c] && by < im.nby[c]) {  // blocks of the MCU padding carry no AC data
+            ReplayEnv env;
+            env.himgs = himgs;
+            env.tables = tables;
+            env.slot_words = slot_words;
+            env.buf = (uint32_t)(uintptr_t)(HJ_LDS uint8_t*)&sh.blocks[t * kRBlockBytes];
+            env.zz = (const HJ_LDS uint8_t*)sh.zz;
+            if (!prog_replay_block(env, im, c, by * im.nbx[c] + bx)) sh.err = 1;
+        }
+    }
+    sh.dst[t] = dst;
+    __syncthreads();
+    // eight lanes per block, 16 bytes each: every store instruction writes eight whole lines
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int blk = (t & ~63) + 8 * i + ((t & 63) >> 3), chunk = t & 7;
+        int16_t* p = sh.dst[blk];
+        if (p) {
+            const u32x4 v = *(const HJ_LDS u32x4*)&sh.blocks[blk * kRBlockBytes + chunk * 16];
+            __builtin_nontemporal_store(v, (HJ_GLOBAL u32x4*)p + chunk);
+        }
+    }
+    if (t == 0 && sh.err) im.status = 1;
+}
+
+}  // namespace
+
+int launch_prog_walk(ProgImage* images, const HuffImage* himgs, int nimages, unsigned slot_words, void* stream)
+{
+    if (nimages <= 0) return 0;
+    hipLaunchKernelGGL(prog_walk_kernel, dim3(nimages * kProgChains), dim3(kWalkThreads), slot_words * 2u * kProgMaxStages, (hipStream_t)stream, images,
+                       himgs, slot_words);
+    return (int)hipGetLastError();
+}
+
+int launch_prog_replay(ProgImage* images, const HuffImage* himgs, const HuffUnit* units, int nunits, unsigned slot_words, void* stream)
+{
+    if (nunits <= 0) return 0;
+    hipLaunchKernelGGL(prog_replay_kernel, dim3(nunits), dim3(kRThreads), slot_words * 2u * kProgMaxStages, (hipStream_t)stream, images, himgs, units,
+                       slot_words);
+    return (int)hipGetLastError();
+}
+
+}  // namespace hipjpeg

@@ -1,0 +1,346 @@
+// progressive_gpu_core.h -- progressive (SOF2) scans on the GPU entropy stage: data structures and the parse logic shared by
+// the kernels (progressive_gpu.hip) and their host emulation (progressive_gpu_host.cpp, used by the CPU tests).
+//
+// What can and what cannot be parallelised (ITU T.81 Annex G):
+//   * DC refinement scans are one raw bit per block: position = block index.  Fully parallel.
+//   * DC first / AC first scans are Huffman streams like a baseline scan.
+//   * AC REFINEMENT scans interleave Huffman symbols with raw "correction" bits, one for every coefficient of the block that
+//     earlier scans left non-zero and that the decoder passes while it counts zero-history coefficients.  How many bits
+//     follow a symbol depends on the history of the very block being decoded, i.e. on the block INDEX -- and the index of
+//     the block a bit belongs to is only known once everything in front of it has been parsed.  A decoder dropped into the
+//     middle of such a scan cannot parse at all, so the self-synchronising subsequence trick of the baseline path
+//     (huffman_gpu_core.h) does not apply: the parse of a refinement scan is a sequential chain.  In libjpeg's standard
+//     script those scans carry ~3/4 of the bits of a q90 photo.
+// Therefore the work is split in two:
+//   walk   one WAVE per scan walks it sequentially, as a scalar machine (uniform control flow, tables and per-block history
+//          bitmaps in registers read with v_readlane, stream words 64 at a time in a VGPR), and records nothing but WHERE
+//          every block's data starts.  It never touches a coefficient: the correction bits after a symbol are counted from
+//          the block's history bitmap with popcounts and a rank/select table, not looped over.  The scans of one component
+//          run as a pipeline of waves in one workgroup (scan n+1 needs the history scan n leaves behind, 64 blocks at a
+//          time, through an LDS ring), the components and the DC scans in other workgroups, all images at once -- the
+//          parallelism that exists: images x components x pipeline stages.
+//   replay one LANE per block replays all scans of its block from those positions (now every block is independent), builds
+//          the 64 coefficients in LDS and stores the block once, as a whole 128-byte line.
+// DC values go to the compact DC planes the IDCT kernels already read for GPU-decoded baseline images.
+//
+// All arithmetic is integer/bit exact; results are compared with the host entropy decoder and the oracle in tests/.
+#pragma once
+#include <cstdint>
+
+#include "huffman_gpu_core.h"
+
+#define HJ_LIKELY(x) __builtin_expect(!!(x), 1)
+#define HJ_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
+namespace hipjpeg {
+
+constexpr int kProgMaxScans = 24;     // scans per image the GPU path takes (libjpeg's script has 10; more -> host entropy stage)
+constexpr int kProgMaxStages = 6;     // AC scans per component = pipeline stages (= waves) of a walker workgroup
+constexpr int kProgChains = 5;        // walker workgroups per image: one per component (up to 4) + one for the DC scans
+constexpr int kProgGroup = 64;        // blocks per hand-over unit between pipeline stages (one lane per block)
+constexpr int kProgRing = 8;          // groups a stage may run ahead of its successor
+constexpr int kProgTableMax = 2560;   // uint16 entries of one scan's lookup table the kernels accept (first level + 9 second-level)
+constexpr uint32_t kProgInRun = 0x80000000u;  // block_pos flag: the block lies inside an end-of-band run (no symbols of its own)
+
+// Lookup-table entry (uint16): bits 0-4 code length (0 = no such code), bits 5-12 the symbol byte.  Bit 15 set = the code is
+// longer than 8 bits: bits 0-14 = number of the 256-entry second-level table (in units of 256 entries from the table's
+// start), indexed by the next 8 bits.
+constexpr uint32_t kProgLong = 0x8000u;
+HJ_HD constexpr uint32_t prog_entry(uint32_t len, uint32_t sym) { return len | (sym << 5); }
+
+// NB every member that the kernels index with a run-time (wave-uniform) index is a 32-bit word: hipcc folds such an index into
+// the offset of a scalar load, and a scalar load from an address that is not dword aligned returns the wrong dword on gfx950
+// (DESIGN.md "A compiler hazard"; tests/test_code_object_hazards.py keeps watch).
+struct alignas(16) ProgScan {
+    const uint8_t* stream;    // destuffed entropy-coded bytes (written by the destuff kernels)
+    uint32_t* block_pos;      // AC scans: where each block's data starts (bit offset; kProgInRun set inside an end-of-band run)
+    uint32_t huff_image;      // the HuffImage the destuff kernels filled for this scan (total_bits, stream_words)
+    uint32_t nblocks;         // AC scans: nbx * nby of the component; DC scans: blocks in the scan
+    uint32_t table[4];        // pool offset (uint16 units) of the lookup table: AC scans [0]; DC first scans one per scan component
+    uint32_t comps[4];        // DC scans: the components in scan order
+    uint32_t ncomp, comp;     // comp: AC scans
+    uint32_t ss, se, ah, al;
+    uint32_t stage;           // AC scans: position in the component's chain (0 = first)
+    uint32_t walk_ticks;      // written by the walk kernel: how long this scan's walk took, in 10 ns ticks (profiling aid)
+};
+
+struct alignas(16) ProgImage {
+    ProgScan scan[kProgMaxScans];
+    uint32_t num_scans;
+    uint32_t ncomp, mcus_x, mcus_y;
+    uint32_t comp_h[4], comp_v[4];
+    uint32_t blocks_w[4], blocks_h[4];  // allocation grid (MCU padded)
+    uint32_t nbx[4], nby[4];            // real blocks: ceil(samp / 8)
+    int16_t* coef[4];                   // coefficient blocks (device layout), written whole by the replay kernel
+    int16_t* dc_plane[4];               // compact DC planes (raster over the allocation grid)
+    const uint16_t* pool;               // lookup tables of all scans
+    uint32_t pool_words;
+    uint32_t status;                    // written by the kernels: 0 ok, 1 = the stream cannot be what it claims to be
+    uint32_t chain_len[4];              // AC scans of component c, in file order ...
+    uint32_t chain[4][kProgMaxStages];  // ... as indices into scan[]
+    uint32_t dc_len, dc_chain[kProgMaxScans];  // DC scans in file order
+    uint32_t pad[3];
+};
+
+// ---------------------------------------------------------------------------------------------------------- shared helpers
+HJ_HD uint64_t prog_band_mask(int ss, int se)
+{
+    const uint64_t upto = se >= 63 ? ~0ull : ((1ull << (se + 1)) - 1);
+    return upto & ~((1ull << ss) - 1);
+}
+HJ_HD uint64_t prog_from_mask(int k) { return k >= 64 ? 0ull : ~((1ull << k) - 1); }  // bits k..63
+HJ_HD int prog_popc64(uint64_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(v);
+#else
+    return __builtin_popcountll(v);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------- the walk
+// Walks one AC scan and records the start of every block.  `W` supplies the machine:
+//   uint32_t window()           the next 32 bits of the stream, MSB first, without consuming
+//   void advance(uint32_t n)    any n: the position moves on by n bits
+//   uint32_t pos()              bit position of the next unread bit
+//   uint32_t decode(uint32_t w) lookup-table entry for the code at the top of window w (0 = invalid)
+//   void group_begin(uint32_t g)   history bitmaps of blocks [64 g, 64 g + 64) become available (waits for the previous stage)
+//   uint64_t hist(int j) / void set_hist(int j, uint64_t)   history bitmap of block j of the current group
+//   void set_pos(int j, uint32_t)  block_pos of block j of the current group
+//   void group_end(uint32_t g)  stores the positions, hands the bitmaps to the next stage
+//   void zeros_build(uint64_t z)   rank/select over the set bits of z:  int zeros_count(),  int zero_at(int i) = position of the
+//                                  i-th set bit (i < zeros_count())
+// Everything is wave-uniform on the device; the only state of the bit reader is the position (a symbol never needs more than
+// the 32 bits of one window: code <= 16 bits, end-of-band run length <= 14 bits), so a step is straight-line code.
+// Returns false when the stream breaks the rules (the host decoder then takes the image and names the error).
+template <class W>
+HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t total_bits)
+{
+    const uint64_t band = prog_band_mask(ss, se);
+    uint32_t eobrun = 0;
+    bool ok = true;
+    for (uint32_t g = 0; g * kProgGroup < nblocks; g++) {
+        w.group_begin(g);
+        const int n = (int)((nblocks - g * kProgGroup) < (uint32_t)kProgGroup ? (nblocks - g * kProgGroup) : (uint32_t)kProgGroup);
+        for (int j = 0; j < n; j++) {
+            uint64_t h = w.hist(j);
+            if (HJ_UNLIKELY(eobrun != 0)) {
+                // inside an end-of-band run: a first scan has nothing for this block, a refinement scan one correction bit per
+                // coefficient of the band that is already non-zero
+                w.set_pos(j, w.pos() | kProgInRun);
+                if (ah) w.advance((uint32_t)prog_popc64(h & band));
+                eobrun--;
+                continue;
+            }
+            w.set_pos(j, w.pos());
+            int k = ss;
+            if (ah == 0) {
+                while (k <= se) {
+                    const uint32_t win = w.window();
+                    const uint32_t e = w.decode(win);
+                    const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
+                    if (HJ_UNLIKELY(len == 0)) { ok = false; break; }
+                    if (HJ_LIKELY(s != 0)) {
+                        k += (int)r;
+                        if (HJ_UNLIKELY(k > se)) { ok = false; break; }
+                        h |= 1ull << k;
+                        k++;
+                        w.advance(len + s);
+                    } else if (r == 15) {
+                        k += 16;
+                        w.advance(len);
+                    } else {
+                        eobrun = (1u << r) - 1 + (r ? (win << len) >> (32 - r) : 0u);
+                        w.advance(len + r);
+                        break;
+                    }
+                }
+            } else {
+                w.zeros_build(~h & band);
+                const int nz = w.zeros_count();
+                int zr = 0;  // zero-history coefficients of the band below k
+                while (k <= se) {
+                    const uint32_t win = w.window();
+                    const uint32_t e = w.decode(win);
+                    const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
+                    if (HJ_UNLIKELY(len == 0 || s > 1)) { ok = false; break; }
+                    if (HJ_LIKELY(s == 1)) {
+                        // a new coefficient: behind r zero-history coefficients; code, sign bit, then one correction bit for
+                        // every non-zero-history coefficient passed on the way
+                        const int zi = zr + (int)r;
+                        if (HJ_UNLIKELY(zi >= nz)) { ok = false; break; }
+                        const int t = w.zero_at(zi);
+                        w.advance(len + 1u + (uint32_t)(t - k - (int)r));
+                        h |= 1ull << t;
+                        k = t + 1;
+                        zr = zi + 1;
+                    } else if (r == 15) {
+                        // sixteen zero-history coefficients are skipped (or the rest of the band, if it has fewer)
+                        const int zi = zr + 15;
+                        if (zi >= nz) {
+                            w.advance(len + (uint32_t)prog_popc64(h & band & prog_from_mask(k)));
+                            k = se + 1;
+                        } else {
+                            const int t = w.zero_at(zi);
+                            w.advance(len + (uint32_t)(t - k - 15));
+                            k = t + 1;
+                            zr = zi + 1;
+                        }
+                    } else {
+                        eobrun = (1u << r) + (r ? (win << len) >> (32 - r) : 0u) - 1;  // this block is the run's first
+                        w.advance(len + r + (uint32_t)prog_popc64(h & band & prog_from_mask(k)));  // + the rest of this block's band
+                        break;
+                    }
+                }
+            }
+            if (HJ_UNLIKELY(!ok)) break;
+            w.set_hist(j, h);
+        }
+        w.group_end(g);
+        if (!ok) break;
+    }
+    // nothing may be read from behind the data (the host decoder calls that TRUNCATED)
+    if (ok && w.pos() > total_bits) ok = false;
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------- the replay
+// One block, all AC scans of its component, from the recorded positions.  `E` supplies per-lane accessors:
+//   uint32_t word(const ProgScan&, uint32_t i)          32-bit word i of the scan's stream, MSB first (ones behind the end)
+//   uint32_t lookup(const ProgScan&, uint32_t w)        lookup-table entry for the window w (next 32 bits, MSB first)
+//   int get(int zz) / void put(int zz, int v)           coefficient at ZIGZAG index zz of the block being built
+// Returns false for a stream that breaks the rules.  `block` = index of the block in scan order of its component.
+struct ProgBits {  // MSB-first reader over E::word, positions in bits
+    uint32_t hi, lo, nbits, next;
+    template <class E>
+    HJ_HD void start(const E& e, const ProgScan& sc, uint32_t pos)
+    {
+        const uint32_t i = pos >> 5, sh = pos & 31;
+        const uint32_t w0 = e.word(sc, i), w1 = e.word(sc, i + 1);
+        hi = (w0 << sh) | ((w1 >> 1) >> (sh ^ 31));
+        lo = w1 << sh;
+        nbits = 64 - sh;
+        next = i + 2;
+    }
+    template <class E>
+    HJ_HD void consume(const E& e, const ProgScan& sc, uint32_t c)  // c <= 31
+    {
+        if (c == 0) return;
+        hi = (hi << c) | (lo >> (32 - c));
+        lo <<= c;
+        nbits -= c;
+        if (nbits < 32) {
+            const uint32_t f = e.word(sc, next++);
+            hi |= f >> (nbits & 31);
+            lo = nbits ? f << (32 - nbits) : f;  // nbits >= 1 here whenever c <= 31 and nbits was >= 32
+            nbits += 32;
+        }
+    }
+    HJ_HD uint32_t peek(uint32_t n) const { return n ? hi >> (32 - n) : 0u; }  // n <= 31
+};
+
+template <class E>
+HJ_HD bool prog_replay_block(E& env, const ProgImage& im, int comp, uint32_t block)
+{
+    uint64_t nonzero = 0;  // bit zz set = coefficient zz is non-zero so far
+    for (int st = 0; st < (int)im.chain_len[comp]; st++) {
+        const ProgScan& sc = im.scan[im.chain[comp][st]];
+        const uint32_t bp = ((const uint32_t*)sc.block_pos)[block];
+        const int ss = sc.ss, se = sc.se, al = sc.al;
+        const uint64_t band = prog_band_mask(ss, se);
+        ProgBits br;
+        if (sc.ah == 0) {
+            if (bp & kProgInRun) continue;
+            br.start(env, sc, bp);
+            int k = ss;
+            while (k <= se) {
+                const uint32_t e = env.lookup(sc, br.hi);
+                const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
+                if (len == 0) return false;
+                br.consume(env, sc, len);
+                if (s) {
+                    k += (int)r;
+                    if (k > se) return false;
+                    const uint32_t v = br.peek(s);
+                    br.consume(env, sc, s);
+                    const int val = v < (1u << (s - 1)) ? (int)v - (int)(1u << s) + 1 : (int)v;
+                    env.put(k, val * (1 << al));
+                    nonzero |= 1ull << k;
+                    k++;
+                } else if (r == 15) {
+                    k += 16;
+                } else {
+                    break;  // end of band (the run length concerns the following blocks; the walk has dealt with it)
+                }
+            }
+        } else {
+            const int p1 = 1 << al, m1 = -(1 << al);
+            br.start(env, sc, bp & ~kProgInRun);
+            // one correction bit for coefficient zz (non-zero history): T.81 G.1.2.3
+            auto correct = [&](int zz) {
+                const uint32_t bit = br.peek(1);
+                br.consume(env, sc, 1);
+                if (bit) {
+                    const int c = env.get(zz);
+                    if ((c & p1) == 0) env.put(zz, c >= 0 ? c + p1 : c + m1);
+                }
+            };
+            auto correct_range = [&](int from, int to) {  // every non-zero-history coefficient in [from, to)
+                uint64_t m = nonzero & band & prog_from_mask(from) & ~prog_from_mask(to);
+                while (m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const int zz = __ffsll((unsigned long long)m) - 1;
+#else
+                    const int zz = __builtin_ctzll(m);
+#endif
+                    m &= m - 1;
+                    correct(zz);
+                }
+            };
+            if (bp & kProgInRun) {
+                correct_range(ss, se + 1);
+                continue;
+            }
+            int k = ss;
+            while (k <= se) {
+                const uint32_t e = env.lookup(sc, br.hi);
+                const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
+                if (len == 0 || s > 1) return false;
+                br.consume(env, sc, len);
+                if (s == 1 || r == 15) {
+                    int newval = 0;
+                    if (s == 1) {
+                        newval = br.peek(1) ? p1 : m1;
+                        br.consume(env, sc, 1);
+                    }
+                    // the (r+1)-th zero-history coefficient at or behind k
+                    uint64_t z = ~nonzero & band & prog_from_mask(k);
+                    int t = se + 1;
+                    for (uint32_t i = 0; i <= r && z; i++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                        const int p = __ffsll((unsigned long long)z) - 1;
+#else
+                        const int p = __builtin_ctzll(z);
+#endif
+                        z &= z - 1;
+                        if (i == r) t = p;
+                    }
+                    if (t > se && s == 1) return false;  // fewer zero-history coefficients left than the run says
+                    correct_range(k, t > se ? se + 1 : t);
+                    if (s == 1) {
+                        env.put(t, newval);
+                        nonzero |= 1ull << t;  // positions below the new k are never looked at again in this scan
+                    }
+                    k = t + 1;
+                } else {
+                    br.consume(env, sc, r);  // the run length's extra bits (the walk has used them)
+                    correct_range(k, se + 1);
+                    break;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+}  // namespace hipjpeg

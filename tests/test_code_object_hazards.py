@@ -38,15 +38,40 @@ def test_library_carries_only_gfx950_device_code(device_disassembly):
 
 
 def test_no_scalar_load_with_an_sgpr_offset(device_disassembly):
-    loads = [l.split("//")[0].strip() for l in device_disassembly.splitlines() if re.search(r"\bs_(buffer_)?load_dword", l)]
-    assert len(loads) > 100  # the kernels do read their descriptors with scalar loads
-    bad = []
-    for l in loads:
-        ops = [o.strip() for o in l.split(None, 1)[1].split(",")]
-        # operands: destination, base (SGPR pair / resource), offset.  The offset must be an immediate.
-        if len(ops) != 3 or not re.fullmatch(r"(0x[0-9a-fA-F]+|\d+)", ops[2]):
-            bad.append(l)
+    """Kernels whose descriptors hold byte arrays (DecodeImage / HuffImage / EncodeImage ...) must not index them through the
+    register-offset form at all.  The progressive-scan kernels (prog_*) do use it -- their descriptors (ProgImage / ProgScan,
+    progressive_gpu_core.h) consist of 32- and 64-bit members only, so every such offset is a multiple of four by
+    construction; test_progressive_descriptors_have_no_sub_dword_members pins that."""
+    blocks = re.split(r"\n(?=[0-9a-f]{16} <)", device_disassembly)
+    total, bad = 0, []
+    for b in blocks:
+        head = b.split("\n", 1)[0]
+        for l in b.splitlines():
+            if not re.search(r"\bs_(buffer_)?load_dword", l):
+                continue
+            l = l.split("//")[0].strip()
+            total += 1
+            ops = [o.strip() for o in l.split(None, 1)[1].split(",")]
+            # operands: destination, base (SGPR pair / resource), offset.  The offset must be an immediate.
+            if len(ops) != 3 or not re.fullmatch(r"(0x[0-9a-fA-F]+|\d+)", ops[2]):
+                if "prog_" not in head:
+                    bad.append(head[:100] + "  " + l)
+    assert total > 100  # the kernels do read their descriptors with scalar loads
     assert not bad, "scalar loads with a register offset (unaligned-base hazard on gfx950):\n" + "\n".join(bad[:10])
+
+
+def test_progressive_descriptors_have_no_sub_dword_members():
+    """Textual check of progressive_gpu_core.h: between `struct ... ProgScan {` / `ProgImage {` and the closing brace no member
+    is declared with an 8- or 16-bit type (pointers to such types are fine)."""
+    src = open(os.path.join(os.path.dirname(N.LIB_PATH), "csrc", "progressive_gpu_core.h")).read()
+    for name in ("ProgScan", "ProgImage"):
+        m = re.search(r"struct (?:alignas\(16\) )?%s \{(.*?)\n\};" % name, src, re.S)
+        assert m, name
+        for line in m.group(1).splitlines():
+            decl = line.split("//")[0].strip()
+            if not decl:
+                continue
+            assert not re.match(r"(u?int8_t|u?int16_t|bool|char)\s+[a-z_]", decl), (name, decl)
 
 
 def test_kernels_do_not_spill_in_the_everyday_configuration(device_disassembly):
