@@ -271,7 +271,26 @@ def config4_progressive(dec, host_threads):
         t = (time.perf_counter() - t0) / reps
         res[label + "_images_per_s"] = round(128 / t, 1)
         res[label + "_gpu_decoded_images"] = dec.stats()["gpu_entropy_images"]
-    res["images_per_s"] = max(res["host_entropy_images_per_s"], res["gpu_entropy_images_per_s"])
+    # the GPU path with three batches in flight (hipjpegDecodeBatchSubmit/Wait), as configs[1]'s end-to-end figure is taken: the
+    # walk of a progressive scan is a sequential chain per scan, so a batch's time is the longest chain's -- batches in flight
+    # fill the rest of the chip
+    ring = [outs, dec.allocate_outputs(batch, "rgb_planar"), dec.allocate_outputs(batch, "rgb_planar")]
+    dec.submit(batch, ring[1], fmt="rgb_planar")
+    dec.wait()
+    torch.cuda.synchronize()
+    nb = 9
+    t0 = time.perf_counter()
+    for i in range(nb):
+        dec.submit(batch, ring[i % 3], fmt="rgb_planar")
+        if i > 1:
+            dec.wait()
+    dec.wait()
+    dec.wait()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / nb
+    res["gpu_entropy_pipelined_images_per_s"] = round(128 / t, 1)
+    res["images_per_s"] = max(res["host_entropy_images_per_s"], res["gpu_entropy_images_per_s"], res["gpu_entropy_pipelined_images_per_s"])
+    res["path"] = "host JPEG bytes -> P_RGB in HBM; best of: host entropy stage, GPU walk + replay one batch at a time, the same with three batches in flight"
     res["host_threads"] = host_threads
     return res
 

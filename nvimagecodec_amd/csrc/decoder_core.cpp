@@ -1076,7 +1076,7 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which, void* entropy_strea
     last_stream_ = stream;
     // With an entropy stream the (latency-bound) entropy kernels of this batch run beside the (VALU-bound) pixel kernels of
     // the batch before it; the pixel kernels on `stream` wait for them on the device.
-    void* es_stream = (entropy_stream && which < 0 && !entropy_done_ && !huff_units_.empty()) ? entropy_stream : stream;
+    void* es_stream = (entropy_stream && which < 0 && !entropy_done_ && !(huff_units_.empty() && prog_units_.empty())) ? entropy_stream : stream;
     if (copied_event_ && copy_pending_) {
         // the H2D copy went out on another stream: the kernels wait for it on the device, the host does not
         if (hipStreamWaitEvent((hipStream_t)es_stream, (hipEvent_t)copied_event_, 0) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;

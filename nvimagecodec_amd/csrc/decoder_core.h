@@ -126,6 +126,7 @@ public:
     void* last_stream() const { return last_stream_; }
     int gpu_entropy_images() const { return (int)(huff_to_image_.size() + prog_to_image_.size()); }
     int last_sync_launches() const { return last_sync_launches_; }
+    bool has_progressive() const { return !prog_to_image_.empty(); }
     uint64_t stream_bytes() const { return stream_bytes_total_; }
 
     int size() const { return (int)images_.size(); }

@@ -56,6 +56,9 @@ struct hipjpegHandle {
     int num_submitted = 0;
     hipStream_t copy_stream = nullptr;  // H2D copies of submitted batches: they overlap the kernels of the batch before
     hipStream_t entropy_stream = nullptr;  // GPU entropy stage of submitted batches: beside the pixel kernels of the batch before
+    // batches with progressive images: the walk of a progressive scan is one wave per scan and leaves most of the chip idle, so
+    // the entropy stages of consecutive batches run beside EACH OTHER, one stream per page
+    hipStream_t page_entropy_stream[3] = {nullptr, nullptr, nullptr};
     std::unique_ptr<EncodeBatch> encode;
     EncodeBatch* encode_view = nullptr;  // the batch hipjpegEncodeGetBitstream / GetCoefficients / Stats talk about
     // pipelined encoding (hipjpegEncodeBatchSubmit / Wait): three pages, each driven by its own host thread on its own
@@ -212,6 +215,8 @@ hipjpegStatus_t hipjpegDestroy(hipjpegHandle_t handle)
     (void)hipSetDevice(handle->device_id);
     if (handle->copy_stream) (void)hipStreamDestroy(handle->copy_stream);
     if (handle->entropy_stream) (void)hipStreamDestroy(handle->entropy_stream);
+    for (hipStream_t ps : handle->page_entropy_stream)
+        if (ps) (void)hipStreamDestroy(ps);
     for (auto& pg : handle->encode_pages) {
         if (pg.result.valid()) {
             try {
@@ -339,7 +344,13 @@ hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* 
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     DecodeBatch& b = handle->cur();
     if ((st = b.transfer(handle->copy_stream, true)) != HIPJPEG_STATUS_SUCCESS) return st;
-    if ((st = b.launch(stream, -1, handle->entropy_stream)) != HIPJPEG_STATUS_SUCCESS) return st;
+    hipStream_t es = handle->entropy_stream;
+    if (two_streams && b.has_progressive()) {
+        hipStream_t& ps = handle->page_entropy_stream[handle->current];
+        if (!ps && hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        es = ps;
+    }
+    if ((st = b.launch(stream, -1, es)) != HIPJPEG_STATUS_SUCCESS) return st;
     handle->submitted[handle->num_submitted] = handle->current;
     handle->submitted_stream[handle->num_submitted] = stream;
     handle->num_submitted++;

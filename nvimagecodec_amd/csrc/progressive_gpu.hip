@@ -50,7 +50,7 @@ struct DevWalker {
     uint32_t vbase;
     uint32_t p;
     // table
-    uint32_t t6;                    // per lane: first-level entry for the 6-bit prefix `lane` (0 = look in the full table)
+    uint32_t pre, pbase;            // symbols decoded ahead: per lane, for the bit offsets pbase + lane
     const HJ_LDS uint16_t* table;   // the scan's full lookup table
     // per group
     uint32_t hlo, hhi, pos_out;     // per lane: block 64 g + lane
@@ -114,24 +114,35 @@ struct DevWalker {
     }
     __device__ __forceinline__ void advance(uint32_t n) { p += n; }
     __device__ __forceinline__ uint32_t pos() const { return p; }
-    __device__ __forceinline__ uint32_t decode(uint32_t w) const
+    // Symbols decoded ahead: lane o of `pre` = the lookup-table entry of the code that starts at bit pbase + o, for all 64
+    // offsets at once (vector work: two crossbar reads for the stream words, the table lookups in LDS).  The walk's dependent
+    // chain then costs ONE readlane per symbol instead of two for the window, a shift, and one for the table.
+    __device__ __forceinline__ void predecode()
     {
-        uint32_t e = lane_read(t6, w >> 26);
-        if (__builtin_expect(e == 0, 0)) {
-            e = table[w >> 24];
-            if (e & kProgLong) e = table[(e & 0x7FFFu) * 256u + ((w >> 16) & 255u)];
-            e = uni(e);
+        pbase = p;
+        const uint32_t q = p + lane;
+        uint32_t wi = (q >> 5) - vbase;  // p's word lies inside W (window() / symbol() make sure); q's may reach two words into X
+        const uint32_t x0 = lane_read(X, 0), x1 = lane_read(X, 1), x2 = lane_read(X, 2);
+        const uint32_t in_w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((wi & 63u) * 4u), (int)W);
+        const uint32_t in_w1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((wi & 63u) * 4u), (int)W1);
+        const uint32_t hi = wi < 64u ? in_w : (wi == 64u ? x0 : x1);
+        const uint32_t lo = wi < 64u ? in_w1 : (wi == 64u ? x1 : x2);
+        const uint32_t sh = q & 31u;
+        const uint32_t win = sh ? (hi << sh) | (lo >> (32u - sh)) : hi;
+        uint32_t e = table[win >> 24];
+        if (e & kProgLong) e = table[(e & 0x7FFFu) * 256u + ((win >> 16) & 255u)];
+        pre = e;
+    }
+    __device__ __forceinline__ uint32_t symbol()
+    {
+        uint32_t d = p - pbase;
+        if (__builtin_expect(d >= 64u, 0)) {
+            if (__builtin_expect((p >> 5) - vbase >= 64u, 0)) reposition(p >> 5);
+            predecode();
+            d = 0;
         }
-        return e;
+        return lane_read(pre, d);
     }
-    // 64-entry first-level table in a VGPR: entry j serves every code of at most 6 bits whose prefix is j
-    __device__ __forceinline__ void load_table(const HJ_LDS uint16_t* t)
-    {
-        table = t;
-        const uint32_t a = t[4 * lane], b = t[4 * lane + 1], c = t[4 * lane + 2], d = t[4 * lane + 3];
-        t6 = (a == b && b == c && c == d && !(a & kProgLong) && (a & 31u) <= 6u) ? a : 0u;
-    }
-
     __device__ __forceinline__ bool wait_for(const uint32_t* counter, uint32_t above)
     {
         while (uni(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= above) {
@@ -362,8 +373,9 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         w.aborted = false;
         w.nz = 0;
         w.zpos = 0;
-        w.load_table(slot);
+        w.table = slot;
         w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
+        w.predecode();
         const unsigned long long t0 = wall_clock64();
         ok = prog_walk_ac(w, (int)sc.ss, (int)sc.se, (int)sc.ah, sc.nblocks, hi.total_bits);
         if (lane == 0) im.scan[im.chain[c][wave]].walk_ticks = (uint32_t)(wall_clock64() - t0);

@@ -100,10 +100,10 @@ HJ_HD int prog_popc64(uint64_t v)
 
 // ---------------------------------------------------------------------------------------------------------- the walk
 // Walks one AC scan and records the start of every block.  `W` supplies the machine:
-//   uint32_t window()           the next 32 bits of the stream, MSB first, without consuming
+//   uint32_t symbol()           lookup-table entry for the code at the current position (0 = invalid), nothing consumed
+//   uint32_t window()           the next 32 bits of the stream, MSB first, without consuming (end-of-band run lengths only)
 //   void advance(uint32_t n)    any n: the position moves on by n bits
 //   uint32_t pos()              bit position of the next unread bit
-//   uint32_t decode(uint32_t w) lookup-table entry for the code at the top of window w (0 = invalid)
 //   void group_begin(uint32_t g)   history bitmaps of blocks [64 g, 64 g + 64) become available (waits for the previous stage)
 //   uint64_t hist(int j) / void set_hist(int j, uint64_t)   history bitmap of block j of the current group
 //   void set_pos(int j, uint32_t)  block_pos of block j of the current group
@@ -111,7 +111,9 @@ HJ_HD int prog_popc64(uint64_t v)
 //   void zeros_build(uint64_t z)   rank/select over the set bits of z:  int zeros_count(),  int zero_at(int i) = position of the
 //                                  i-th set bit (i < zeros_count())
 // Everything is wave-uniform on the device; the only state of the bit reader is the position (a symbol never needs more than
-// the 32 bits of one window: code <= 16 bits, end-of-band run length <= 14 bits), so a step is straight-line code.
+// the 32 bits of one window: code <= 16 bits, end-of-band run length <= 14 bits), so a step is straight-line code.  A lone
+// wave pays ~9 cycles per dependent scalar instruction and ~24 more per taken branch or VGPR->SGPR read (tools/
+// scalar_chain_rate.hip), which is what bounds the walk: ~40 instructions per symbol.
 // Returns false when the stream breaks the rules (the host decoder then takes the image and names the error).
 template <class W>
 HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t total_bits)
@@ -136,8 +138,7 @@ HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t
             int k = ss;
             if (ah == 0) {
                 while (k <= se) {
-                    const uint32_t win = w.window();
-                    const uint32_t e = w.decode(win);
+                    const uint32_t e = w.symbol();
                     const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
                     if (HJ_UNLIKELY(len == 0)) { ok = false; break; }
                     if (HJ_LIKELY(s != 0)) {
@@ -150,7 +151,7 @@ HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t
                         k += 16;
                         w.advance(len);
                     } else {
-                        eobrun = (1u << r) - 1 + (r ? (win << len) >> (32 - r) : 0u);
+                        eobrun = (1u << r) - 1 + (r ? (w.window() << len) >> (32 - r) : 0u);
                         w.advance(len + r);
                         break;
                     }
@@ -160,8 +161,7 @@ HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t
                 const int nz = w.zeros_count();
                 int zr = 0;  // zero-history coefficients of the band below k
                 while (k <= se) {
-                    const uint32_t win = w.window();
-                    const uint32_t e = w.decode(win);
+                    const uint32_t e = w.symbol();
                     const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
                     if (HJ_UNLIKELY(len == 0 || s > 1)) { ok = false; break; }
                     if (HJ_LIKELY(s == 1)) {
@@ -187,7 +187,7 @@ HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t
                             zr = zi + 1;
                         }
                     } else {
-                        eobrun = (1u << r) + (r ? (win << len) >> (32 - r) : 0u) - 1;  // this block is the run's first
+                        eobrun = (1u << r) + (r ? (w.window() << len) >> (32 - r) : 0u) - 1;  // this block is the run's first
                         w.advance(len + r + (uint32_t)prog_popc64(h & band & prog_from_mask(k)));  // + the rest of this block's band
                         break;
                     }

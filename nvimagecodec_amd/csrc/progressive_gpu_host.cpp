@@ -230,7 +230,7 @@ struct HostWalker {
     }
     void advance(uint32_t n) { p += n; }
     uint32_t pos() const { return p; }
-    uint32_t decode(uint32_t w) const { return host_lookup(table, w); }
+    uint32_t symbol() const { return host_lookup(table, window()); }
     void group_begin(uint32_t g) { group = g; }
     uint64_t hist(int j) const { return hist_all[(size_t)group * kProgGroup + j]; }
     void set_hist(int j, uint64_t h) { hist_all[(size_t)group * kProgGroup + j] = h; }
