@@ -38,7 +38,7 @@ constexpr int kProgMaxScans = 24;     // scans per image the GPU path takes (lib
 constexpr int kProgMaxStages = 6;     // AC scans per component = pipeline stages (= waves) of a walker workgroup
 constexpr int kProgChains = 5;        // walker workgroups per image: one per component (up to 4) + one for the DC scans
 constexpr int kProgGroup = 64;        // blocks per hand-over unit between pipeline stages (one lane per block)
-constexpr int kProgRing = 8;          // groups a stage may run ahead of its successor
+constexpr int kProgRing = 4;          // groups a stage may run ahead of its successor
 constexpr int kProgTableMax = 2560;   // uint16 entries of one scan's lookup table the kernels accept (first level + 9 second-level)
 constexpr uint32_t kProgInRun = 0x80000000u;  // block_pos flag: the block lies inside an end-of-band run (no symbols of its own)
 
