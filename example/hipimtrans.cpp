@@ -1,0 +1,312 @@
+// hipimtrans -- batched JPEG transcoder / decode benchmark over the public nvimgcodec C API, for the MI355X build.
+//
+// The counterpart of the reference's sample application (example/nvimtrans/main.cpp:561-690): read a batch of files, parse,
+// nvimgcodecDecoderDecode into device buffers, nvimgcodecEncoderEncode into files, with wall-clock timers around every stage
+// and the same closing report ("Avg decoding speed (in images per sec)" ...).  Everything goes through the function tables of
+// include/nvimgcodec_abi.h, i.e. through the priority chain into the hipjpeg_decoder / hipjpeg_encoder plugins -- this is
+// the API route of DESIGN.md, measured without any Python in the way.
+//
+//   hipimtrans -i <file|dir> [-o <dir>] [-b batch] [-w warmup batches] [-r repeats] [-q quality] [-s 444|422|420|gray]
+//              [-d device] [-t cpu threads] [--skip_encode] [--options "<plugin options>"] [-v]
+#include <dirent.h>
+#include <hip/hip_runtime_api.h>
+#include <sys/stat.h>
+#include <time.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/nvimgcodec_abi.h"
+
+namespace {
+
+double wtime()
+{
+    timespec tp;
+    clock_gettime(CLOCK_MONOTONIC, &tp);
+    return tp.tv_nsec * 1e-9 + (double)tp.tv_sec;
+}
+
+#define CHECK_API(call)                                                                   \
+    do {                                                                                  \
+        nvimgcodecStatus_t _s = (call);                                                   \
+        if (_s != NVIMGCODEC_STATUS_SUCCESS) {                                            \
+            fprintf(stderr, "%s failed with status %d (%s:%d)\n", #call, (int)_s, __FILE__, __LINE__); \
+            return EXIT_FAILURE;                                                          \
+        }                                                                                 \
+    } while (0)
+#define CHECK_HIP(call)                                                                   \
+    do {                                                                                  \
+        hipError_t _e = (call);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            fprintf(stderr, "%s failed: %s (%s:%d)\n", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return EXIT_FAILURE;                                                          \
+        }                                                                                 \
+    } while (0)
+
+struct Params {
+    std::string input, output, options;
+    int batch = 16, warmup = 1, repeats = 1, quality = 90, device = 0, threads = 0, verbose = 0;
+    std::string subsampling = "420";
+    bool skip_encode = false;
+};
+
+bool is_dir(const std::string& p)
+{
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+std::vector<std::string> list_inputs(const std::string& p)
+{
+    std::vector<std::string> out;
+    if (!is_dir(p)) {
+        out.push_back(p);
+        return out;
+    }
+    if (DIR* d = opendir(p.c_str())) {
+        while (dirent* e = readdir(d)) {
+            std::string n = e->d_name;
+            if (n.size() > 4 && (n.substr(n.size() - 4) == ".jpg" || n.substr(n.size() - 5) == ".jpeg")) out.push_back(p + "/" + n);
+        }
+        closedir(d);
+    }
+    std::sort(out.begin(), out.end());
+    return out;
+}
+
+bool read_file(const std::string& path, std::vector<unsigned char>* data)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    data->resize((size_t)n);
+    const bool ok = fread(data->data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Params p;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "-i") p.input = next();
+        else if (a == "-o") p.output = next();
+        else if (a == "-b") p.batch = atoi(next());
+        else if (a == "-w") p.warmup = atoi(next());
+        else if (a == "-r") p.repeats = atoi(next());
+        else if (a == "-q") p.quality = atoi(next());
+        else if (a == "-s") p.subsampling = next();
+        else if (a == "-d") p.device = atoi(next());
+        else if (a == "-t") p.threads = atoi(next());
+        else if (a == "--options") p.options = next();
+        else if (a == "--skip_encode") p.skip_encode = true;
+        else if (a == "-v") p.verbose++;
+        else {
+            fprintf(stderr, "usage: %s -i <file|dir> [-o dir] [-b batch] [-w warmup] [-r repeats] [-q quality] [-s 444|422|420|gray] [-d device] "
+                            "[-t threads] [--skip_encode] [--options str] [-v]\n", argv[0]);
+            return EXIT_FAILURE;
+        }
+    }
+    if (p.input.empty() || p.batch < 1) {
+        fprintf(stderr, "an input (-i) and a positive batch size are needed\n");
+        return EXIT_FAILURE;
+    }
+    if (p.output.empty()) p.skip_encode = true;
+    std::vector<std::string> names = list_inputs(p.input);
+    if (names.empty()) {
+        fprintf(stderr, "no .jpg files under %s\n", p.input.c_str());
+        return EXIT_FAILURE;
+    }
+    CHECK_HIP(hipSetDevice(p.device));
+
+    nvimgcodecInstance_t instance = nullptr;
+    nvimgcodecInstanceCreateInfo_t ci{};
+    ci.struct_type = NVIMGCODEC_STRUCTURE_TYPE_INSTANCE_CREATE_INFO;
+    ci.struct_size = sizeof ci;
+    ci.load_builtin_modules = 1;
+    ci.load_extension_modules = 1;
+    ci.create_debug_messenger = p.verbose > 0;
+    ci.message_severity = NVIMGCODEC_DEBUG_MESSAGE_SEVERITY_ERROR | NVIMGCODEC_DEBUG_MESSAGE_SEVERITY_FATAL |
+                          (p.verbose > 1 ? NVIMGCODEC_DEBUG_MESSAGE_SEVERITY_WARNING : 0);
+    ci.message_category = NVIMGCODEC_DEBUG_MESSAGE_CATEGORY_ALL;
+    CHECK_API(nvimgcodecInstanceCreate(&instance, &ci));
+
+    nvimgcodecExecutionParams_t ep{};
+    ep.struct_type = NVIMGCODEC_STRUCTURE_TYPE_EXECUTION_PARAMS;
+    ep.struct_size = sizeof ep;
+    ep.device_id = p.device;
+    ep.max_num_cpu_threads = p.threads;
+    nvimgcodecDecoder_t decoder = nullptr;
+    nvimgcodecEncoder_t encoder = nullptr;
+    CHECK_API(nvimgcodecDecoderCreate(instance, &decoder, &ep, p.options.c_str()));
+    if (!p.skip_encode) CHECK_API(nvimgcodecEncoderCreate(instance, &encoder, &ep, p.options.c_str()));
+
+    nvimgcodecDecodeParams_t dparams{NVIMGCODEC_STRUCTURE_TYPE_DECODE_PARAMS, sizeof(nvimgcodecDecodeParams_t), nullptr, 1, 0};
+    nvimgcodecJpegEncodeParams_t jparams{NVIMGCODEC_STRUCTURE_TYPE_JPEG_ENCODE_PARAMS, sizeof(nvimgcodecJpegEncodeParams_t), nullptr, 0};
+    nvimgcodecEncodeParams_t eparams{NVIMGCODEC_STRUCTURE_TYPE_ENCODE_PARAMS, sizeof(nvimgcodecEncodeParams_t), &jparams, (float)p.quality, 50.f};
+    const nvimgcodecChromaSubsampling_t css = p.subsampling == "444"   ? NVIMGCODEC_SAMPLING_444
+                                              : p.subsampling == "422" ? NVIMGCODEC_SAMPLING_422
+                                              : p.subsampling == "gray" ? NVIMGCODEC_SAMPLING_GRAY
+                                                                        : NVIMGCODEC_SAMPLING_420;
+
+    const size_t total_images = names.size() * (size_t)p.repeats;
+    std::vector<std::vector<unsigned char>> file_data(p.batch);
+    std::vector<void*> buffers(p.batch, nullptr);
+    std::vector<size_t> buffer_bytes(p.batch, 0);
+    double t_read = 0, t_parse = 0, t_decode = 0, t_encode = 0;
+    size_t processed = 0, failed = 0, cursor = 0;
+    int warm = 0;
+    const double t_start = wtime();
+    double t_timed_start = t_start;
+    while (processed < total_images) {
+        const int n = (int)std::min<size_t>((size_t)p.batch, total_images - processed);
+        // ---- read
+        double t0 = wtime();
+        std::vector<std::string> current(n);
+        for (int i = 0; i < n; i++) {
+            current[i] = names[(cursor + i) % names.size()];
+            if (!read_file(current[i], &file_data[i])) {
+                fprintf(stderr, "cannot read %s\n", current[i].c_str());
+                return EXIT_FAILURE;
+            }
+        }
+        const double reading = wtime() - t0;
+        // ---- parse: code streams, output images (interleaved RGB u8 on the device, row_stride = width * 3)
+        t0 = wtime();
+        std::vector<nvimgcodecCodeStream_t> in_streams(n, nullptr);
+        std::vector<nvimgcodecImage_t> images(n, nullptr);
+        std::vector<nvimgcodecImageInfo_t> infos(n);
+        for (int i = 0; i < n; i++) {
+            CHECK_API(nvimgcodecCodeStreamCreateFromHostMem(instance, &in_streams[i], file_data[i].data(), file_data[i].size()));
+            nvimgcodecImageInfo_t info{};
+            info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+            info.struct_size = sizeof info;
+            CHECK_API(nvimgcodecCodeStreamGetImageInfo(in_streams[i], &info));
+            const uint32_t w = info.plane_info[0].width, h = info.plane_info[0].height;
+            info.sample_format = NVIMGCODEC_SAMPLEFORMAT_I_RGB;
+            info.color_spec = NVIMGCODEC_COLORSPEC_SRGB;
+            info.chroma_subsampling = NVIMGCODEC_SAMPLING_NONE;
+            info.num_planes = 1;
+            info.plane_info[0].num_channels = 3;
+            info.plane_info[0].row_stride = (size_t)w * 3;
+            info.plane_info[0].sample_type = NVIMGCODEC_SAMPLE_DATA_TYPE_UINT8;
+            info.buffer_size = (size_t)w * 3 * h;
+            info.buffer_kind = NVIMGCODEC_IMAGE_BUFFER_KIND_STRIDED_DEVICE;
+            if (buffer_bytes[i] < info.buffer_size) {
+                if (buffers[i]) CHECK_HIP(hipFree(buffers[i]));
+                CHECK_HIP(hipMalloc(&buffers[i], info.buffer_size));
+                buffer_bytes[i] = info.buffer_size;
+            }
+            info.buffer = buffers[i];
+            info.cuda_stream = nullptr;
+            infos[i] = info;
+            CHECK_API(nvimgcodecImageCreate(instance, &images[i], &info));
+        }
+        const double parsing = wtime() - t0;
+        // ---- decode
+        t0 = wtime();
+        nvimgcodecFuture_t future = nullptr;
+        CHECK_API(nvimgcodecDecoderDecode(decoder, in_streams.data(), images.data(), n, &dparams, &future));
+        CHECK_API(nvimgcodecFutureWaitForAll(future));
+        CHECK_HIP(hipDeviceSynchronize());
+        const double decoding = wtime() - t0;
+        size_t count = 0;
+        nvimgcodecFutureGetProcessingStatus(future, nullptr, &count);
+        std::vector<nvimgcodecProcessingStatus_t> status(count);
+        nvimgcodecFutureGetProcessingStatus(future, status.data(), &count);
+        nvimgcodecFutureDestroy(future);
+        std::vector<int> good;
+        for (int i = 0; i < n; i++) {
+            if (status[i] == NVIMGCODEC_PROCESSING_STATUS_SUCCESS)
+                good.push_back(i);
+            else {
+                failed++;
+                fprintf(stderr, "Error: something went wrong during decoding image %s (status 0x%x), it will not be encoded\n", current[i].c_str(),
+                        (unsigned)status[i]);
+            }
+        }
+        // ---- encode
+        double encoding = 0;
+        if (!p.skip_encode && !good.empty()) {
+            std::vector<nvimgcodecCodeStream_t> out_streams;
+            std::vector<nvimgcodecImage_t> enc_images;
+            for (int i : good) {
+                nvimgcodecImageInfo_t out_info = infos[i];
+                strcpy(out_info.codec_name, "jpeg");
+                out_info.chroma_subsampling = css;
+                std::string base = current[i].substr(current[i].find_last_of('/') + 1);
+                std::string path = p.output + "/" + base;
+                nvimgcodecCodeStream_t cs = nullptr;
+                CHECK_API(nvimgcodecCodeStreamCreateToFile(instance, &cs, path.c_str(), &out_info));
+                out_streams.push_back(cs);
+                enc_images.push_back(images[i]);
+            }
+            t0 = wtime();
+            nvimgcodecFuture_t ef = nullptr;
+            CHECK_API(nvimgcodecEncoderEncode(encoder, enc_images.data(), out_streams.data(), (int)enc_images.size(), &eparams, &ef));
+            CHECK_API(nvimgcodecFutureWaitForAll(ef));
+            CHECK_HIP(hipDeviceSynchronize());
+            encoding = wtime() - t0;
+            size_t ec = 0;
+            nvimgcodecFutureGetProcessingStatus(ef, nullptr, &ec);
+            std::vector<nvimgcodecProcessingStatus_t> es(ec);
+            nvimgcodecFutureGetProcessingStatus(ef, es.data(), &ec);
+            for (size_t k = 0; k < ec; k++)
+                if (es[k] != NVIMGCODEC_PROCESSING_STATUS_SUCCESS) {
+                    failed++;
+                    fprintf(stderr, "Error: something went wrong during encoding image #%zu, it will not be saved\n", k);
+                }
+            nvimgcodecFutureDestroy(ef);
+            for (auto cs : out_streams) nvimgcodecCodeStreamDestroy(cs);
+        }
+        for (auto cs : in_streams) nvimgcodecCodeStreamDestroy(cs);
+        for (auto im : images) nvimgcodecImageDestroy(im);
+        if (p.verbose) fprintf(stderr, "batch of %d: read %.2f ms, parse %.2f ms, decode %.2f ms, encode %.2f ms\n", n, reading * 1e3, parsing * 1e3,
+                               decoding * 1e3, encoding * 1e3);
+        if (warm < p.warmup) {
+            warm++;  // the batch is processed again once the warm-up is over
+            t_timed_start = wtime();
+            continue;
+        }
+        cursor += (size_t)n;
+        processed += (size_t)n;
+        t_read += reading;
+        t_parse += parsing;
+        t_decode += decoding;
+        t_encode += encoding;
+        putchar('.');
+        fflush(stdout);
+    }
+    const double total = wtime() - t_timed_start;
+    for (void* b : buffers)
+        if (b) (void)hipFree(b);
+    if (decoder) nvimgcodecDecoderDestroy(decoder);
+    if (encoder) nvimgcodecEncoderDestroy(encoder);
+    nvimgcodecInstanceDestroy(instance);
+
+    const double nb = (double)((total_images + p.batch - 1) / p.batch);
+    auto report = [&](const char* what, double t) {
+        printf("Total %s time: %f\n", what, t);
+        printf("Avg %s time per image: %f\n", what, t / total_images);
+        printf("Avg %s speed  (in images per sec): %f\n", what, t > 0 ? total_images / t : 0.0);
+        printf("Avg %s time per batch: %f\n\n", what, t / nb);
+    };
+    printf("\nTotal images: %zu (failed: %zu), batch size %d\n", total_images, failed, p.batch);
+    report(p.skip_encode ? "processing" : "transcoding", total);
+    report("reading", t_read);
+    report("parsing", t_parse);
+    report("decoding", t_decode);
+    if (!p.skip_encode) report("encoding", t_encode);
+    return failed ? EXIT_FAILURE : EXIT_SUCCESS;
+}

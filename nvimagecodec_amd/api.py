@@ -126,7 +126,8 @@ class Image:
 
     @property
     def dtype(self):
-        return np.dtype(np.uint8)
+        d = self._array.dtype
+        return np.dtype(d) if isinstance(d, np.dtype) else np.dtype(str(d).replace("torch.", ""))
 
     @property
     def precision(self):
@@ -169,19 +170,45 @@ class Image:
         return Image(torch.from_numpy(np.ascontiguousarray(self._array)).cuda(), ImageBufferKind.STRIDED_DEVICE)
 
 
+def _is_dlpack_capsule(obj):
+    return type(obj).__name__ == "PyCapsule"
+
+
+def _from_dlpack_object(source):
+    """DLPack import (python/dlpack_utils.cpp): a PyCapsule named "dltensor", or any object with __dlpack__ /
+    __dlpack_device__.  Zero copy: the tensor torch builds on top of the capsule keeps the producer's memory alive."""
+    import torch
+    t = torch.utils.dlpack.from_dlpack(source) if _is_dlpack_capsule(source) else torch.from_dlpack(source)
+    if t.is_cuda:
+        return Image(t, ImageBufferKind.STRIDED_DEVICE)
+    return Image(t.numpy(), ImageBufferKind.STRIDED_HOST)
+
+
 def as_image(source, cuda_stream=0):
-    """Wrap anything exposing __cuda_array_interface__ / a torch CUDA tensor / a numpy array (python/module.cpp:91-105)."""
+    """Wrap an external buffer as an Image and tie its lifetime to the Image (python/module.cpp:91-105): a DLPack capsule, or an
+    object with __cuda_array_interface__ / __array_interface__ / __dlpack__ + __dlpack_device__ (torch tensors, numpy arrays)."""
     import torch
     if isinstance(source, Image):
         return source
     if isinstance(source, torch.Tensor):
-        return Image(source, ImageBufferKind.STRIDED_DEVICE if source.is_cuda else ImageBufferKind.STRIDED_HOST) if source.is_cuda else Image(
-            source.numpy(), ImageBufferKind.STRIDED_HOST)
+        return Image(source, ImageBufferKind.STRIDED_DEVICE) if source.is_cuda else Image(source.numpy(), ImageBufferKind.STRIDED_HOST)
     if isinstance(source, np.ndarray):
         return Image(source, ImageBufferKind.STRIDED_HOST)
     if hasattr(source, "__cuda_array_interface__"):
         return Image(torch.as_tensor(source, device="cuda"), ImageBufferKind.STRIDED_DEVICE)
+    if _is_dlpack_capsule(source) or (hasattr(source, "__dlpack__") and hasattr(source, "__dlpack_device__")):
+        return _from_dlpack_object(source)
+    if hasattr(source, "__array_interface__"):
+        return Image(np.asarray(source), ImageBufferKind.STRIDED_HOST)
     raise TypeError("unsupported image source")
+
+
+def from_dlpack(source, cuda_stream=0):
+    """Zero-copy conversion from a DLPack tensor to an Image (python/module.cpp:134-150): `source` is a PyCapsule holding a
+    DLPack tensor, or an (array) object with __dlpack__ and __dlpack_device__."""
+    if not (_is_dlpack_capsule(source) or (hasattr(source, "__dlpack__") and hasattr(source, "__dlpack_device__"))):
+        raise TypeError("from_dlpack needs a DLPack capsule or an object with __dlpack__ and __dlpack_device__")
+    return _from_dlpack_object(source)
 
 
 def as_images(sources, cuda_stream=0):
