@@ -15,6 +15,8 @@ enum LumaFlavour { kLumaMul24 = 0, kLumaExact = 1, kLumaCommon = 2, kNumLumaFlav
 int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K3: per-pixel colour stage from planes (replication upsampling) for uncommon sampling layouts.
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+// Four-component frames (CMYK / YCCK): upsampling + the reference's CMYK -> RGB step, one WorkUnit per pixel row.
+int launch_cmyk_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // Geometry pass (region of interest + EXIF orientation): WorkUnit{image = TransformImage index, block_base = first output row}.
 int launch_transform(const TransformImage* images, const WorkUnit* units, int nunits, void* stream);
 

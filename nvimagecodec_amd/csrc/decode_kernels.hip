@@ -704,6 +704,101 @@ __global__ __launch_bounds__(kThreads) void generic_color_kernel(const DecodeIma
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Four-component frames (CMYK, YCCK): every component sits in its plane; the kernel brings each to full size the way
+// libjpeg-turbo does (jdsample.c: h2v1 / h2v2 / h1v2 triangle filters when fancy upsampling is on and they apply, else
+// replication), turns a YCCK frame into CMYK (jdcolor.c ycck_cmyk_convert) and then applies the reference extension's own
+// CMYK -> RGB step (extensions/libjpeg_turbo/jpeg_mem.cpp:292-337): with an Adobe marker r = k*c/255, without one
+// r = (255-k)*(255-c)/255; P_Y = (uint8)(0.299f r + 0.587f g + 0.114f b).  One thread = one pixel; rare path.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ int upsampled_sample(const DecodeImage& im, int x, int y, bool fancy)
+{
+    const DecodeComponent& k = im.comp[C];
+    const int fx = (int)im.hmax / (int)k.h, fy = (int)im.vmax / (int)k.v;
+    const int dw = k.samp_w, dh = k.samp_h;
+    const uint8_t* plane = k.plane;
+    const size_t pitch = k.plane_pitch;
+    if (fx == 1 && fy == 1) return plane[(size_t)y * pitch + x];
+    if (fx == 2 && fy == 1 && fancy && dw > 2) {
+        const uint8_t* p = plane + (size_t)y * pitch;
+        const int i = x >> 1;
+        if (x == 0) return p[0];
+        if (x == 2 * dw - 1) return p[dw - 1];
+        return (x & 1) ? (3 * p[i] + p[i + 1] + 2) >> 2 : (3 * p[i] + p[i - 1] + 1) >> 2;
+    }
+    if (fx == 2 && fy == 2 && fancy && dw > 2) {
+        const int r0 = y >> 1, r1 = min(max((y & 1) ? r0 + 1 : r0 - 1, 0), dh - 1);
+        const uint8_t* p0 = plane + (size_t)r0 * pitch;
+        const uint8_t* p1 = plane + (size_t)r1 * pitch;
+        const int i = x >> 1, cs = 3 * p0[i] + p1[i];
+        if (x == 0) return (cs * 4 + 8) >> 4;
+        if (x == 2 * dw - 1) return (cs * 4 + 7) >> 4;
+        return (x & 1) ? (3 * cs + (3 * p0[i + 1] + p1[i + 1]) + 7) >> 4 : (3 * cs + (3 * p0[i - 1] + p1[i - 1]) + 8) >> 4;
+    }
+    if (fx == 1 && fy == 2 && fancy) {
+        const int r0 = y >> 1, r1 = min(max((y & 1) ? r0 + 1 : r0 - 1, 0), dh - 1);
+        return (3 * plane[(size_t)r0 * pitch + x] + plane[(size_t)r1 * pitch + x] + ((y & 1) ? 2 : 1)) >> 2;
+    }
+    return plane[(size_t)(y / fy) * pitch + x / fx];
+}
+
+__global__ __launch_bounds__(kThreads) void cmyk_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
+{
+    const WorkUnit u = units[blockIdx.x];
+    const DecodeImage& im = images[u.image];
+    const int W = im.width, H = im.height;
+    const int y = u.block_base;
+    if (y >= H) return;
+    const int fmt = im.out_format;
+    const bool planar = fmt == kOutPlanarRGB || fmt == kOutPlanarBGR;
+    const bool bgr = fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR;
+    const bool fancy = (im.flags & kFlagFancyUpsampling) != 0, adobe = (im.flags & kFlagAdobeMarker) != 0;
+    const bool ycck = im.color_model == 4;
+    for (int x = threadIdx.x; x < W; x += kThreads) {
+        int c = upsampled_sample<0>(im, x, y, fancy), m = upsampled_sample<1>(im, x, y, fancy), ye = upsampled_sample<2>(im, x, y, fancy);
+        const int k = upsampled_sample<3>(im, x, y, fancy);
+        if (ycck) {
+            const int rr = (ye * 91881 + (32768 - 128 * 91881)) >> 16;
+            const int bb = (m * 116130 + (32768 - 128 * 116130)) >> 16;
+            const int gg = (m * -22554 + ye * -46802 + (32768 + 128 * 22554 + 128 * 46802)) >> 16;
+            const int r = min(max(c + rr, 0), 255), g = min(max(c + gg, 0), 255), b = min(max(c + bb, 0), 255);
+            c = 255 - r;
+            m = 255 - g;
+            ye = 255 - b;
+        }
+        int R, G, B;
+        if (adobe) {
+            R = (k * c) / 255;
+            G = (k * m) / 255;
+            B = (k * ye) / 255;
+        } else {
+            R = (255 - k) * (255 - c) / 255;
+            G = (255 - k) * (255 - m) / 255;
+            B = (255 - k) * (255 - ye) / 255;
+        }
+        if (fmt == kOutY) {
+            im.out[0][(size_t)y * im.out_pitch[0] + x] = (uint8_t)(0.299f * (float)R + 0.587f * (float)G + 0.114f * (float)B);
+            continue;
+        }
+        if (bgr) {
+            const int t = R;
+            R = B;
+            B = t;
+        }
+        if (planar) {
+            im.out[0][(size_t)y * im.out_pitch[0] + x] = (uint8_t)R;
+            im.out[1][(size_t)y * im.out_pitch[1] + x] = (uint8_t)G;
+            im.out[2][(size_t)y * im.out_pitch[2] + x] = (uint8_t)B;
+        } else {
+            uint8_t* p = im.out[0] + (size_t)y * im.out_pitch[0] + (size_t)x * 3;
+            p[0] = (uint8_t)R;
+            p[1] = (uint8_t)G;
+            p[2] = (uint8_t)B;
+        }
+    }
+}
+
 
 // Geometry pass: region of interest + EXIF orientation (DecodeBatch plans it for the images that ask for it; the pixel
 // kernels have written those images into an intermediate buffer in stored-image coordinates).
@@ -792,6 +887,13 @@ int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int n
 {
     if (nunits <= 0) return 0;
     hipLaunchKernelGGL(generic_color_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    return (int)hipGetLastError();
+}
+
+int launch_cmyk_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    hipLaunchKernelGGL(cmyk_color_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
     return (int)hipGetLastError();
 }
 

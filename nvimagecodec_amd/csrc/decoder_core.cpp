@@ -114,10 +114,17 @@ namespace {
 // Decide which kernels handle this frame.  Returns false when the layout is outside the decoder's scope.
 bool choose_variant(const FrameInfo& f, OutFormat fmt, bool fancy, int* variant)
 {
-    if (f.color == ColorModel::CMYK || f.color == ColorModel::YCCK) return false;
-    if (f.ncomp != 1 && f.ncomp != 3) return false;
+    const bool four = f.color == ColorModel::CMYK || f.color == ColorModel::YCCK;
+    if (four ? f.ncomp != 4 : (f.ncomp != 1 && f.ncomp != 3)) return false;
     for (int c = 0; c < f.ncomp; c++)
         if (f.hmax % f.comp[c].h || f.vmax % f.comp[c].v) return false;  // fractional upsampling: libjpeg refuses too
+    if (four) {
+        // CMYK / YCCK: all four components through planes, then cmyk_color_kernel -- the formats the reference's CPU path
+        // produces from such files (extensions/libjpeg_turbo/jpeg_mem.cpp:318-337: I_RGB, I_BGR, P_Y) and their planar twins
+        if (fmt == kOutPlanarYUV) return false;
+        *variant = -3;
+        return true;
+    }
     if (fmt == kOutPlanarYUV) {
         *variant = -2;
         return true;
@@ -310,7 +317,7 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
         d.vmax = (uint32_t)f.vmax;
         d.color_model = (uint32_t)f.color;
         d.out_format = (uint32_t)fmt;
-        d.flags = fancy ? kFlagFancyUpsampling : 0;
+        d.flags = (fancy ? kFlagFancyUpsampling : 0) | (f.saw_adobe ? kFlagAdobeMarker : 0);
         for (int p = 0; p < 3; p++) {
             d.out[p] = static_cast<uint8_t*>(outputs[i].plane[p]);
             d.out_pitch[p] = outputs[i].pitch[p];
@@ -363,7 +370,7 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
             const size_t nblk = (size_t)k.blocks_w * k.blocks_h;
             const size_t units = (nblk + kBlocksPerUnit - 1) / kBlocksPerUnit;
             // which components go through an intermediate plane
-            bool needs_plane = (im.variant == -1) || (im.variant >= kVar11 && c > 0);
+            bool needs_plane = (im.variant == -1) || (im.variant == -3) || (im.variant >= kVar11 && c > 0);
             bool to_output = (im.variant == -2) && (fmt == kOutPlanarYUV || c == 0);
             if (needs_plane) {
                 dc.plane_pitch = (uint32_t)align_up((size_t)k.blocks_w * 8 + 16, 16);
@@ -373,7 +380,7 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
             if (needs_plane || to_output) max_units += units;
             if (c == 0 && im.variant >= 0) max_units += (size_t)((k.blocks_w + kLumaTileW - 1) / kLumaTileW) * (size_t)((k.blocks_h + kLumaTileH - 1) / kLumaTileH);
         }
-        if (im.variant == -1) max_units += (size_t)f.height;
+        if (im.variant == -1 || im.variant == -3) max_units += (size_t)f.height;
         if (im.gpu_prog) {
             // progressive: every scan is staged and destuffed like a baseline scan; the walk and replay kernels take it from there
             im.prog_index = (int)prog_to_image_.size();
@@ -627,6 +634,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
 {
     fault_point("finalize");
     generic_units_.clear();
+    cmyk_units_.clear();
     for (int e = 0; e < 2; e++) plane_units_[e].clear();
     for (int e = 0; e < kNumLumaFlavours; e++)
         for (auto& v : luma_units_[e]) v.clear();
@@ -648,7 +656,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         const OutFormat fmt = (OutFormat)d.out_format;
         for (int c = 0; c < f.ncomp; c++) {
             const uint32_t nblk = (uint32_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
-            bool needs_plane = (im.variant == -1) || (im.variant >= kVar11 && c > 0);
+            bool needs_plane = (im.variant == -1) || (im.variant == -3) || (im.variant >= kVar11 && c > 0);
             bool to_output = (im.variant == -2) && (fmt == kOutPlanarYUV || c == 0);
             if (needs_plane || to_output) {
                 uint32_t mode = to_output ? (uint32_t)(kToOutput | (c << 8)) : (uint32_t)kToPlane;
@@ -681,6 +689,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
                     luma_units_[flavour][im.variant].push_back(WorkUnit{(uint32_t)i, wide_end, by, 1u});
         } else if (im.variant == -1) {
             for (int y = 0; y < f.height; y++) generic_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});
+        } else if (im.variant == -3) {
+            for (int y = 0; y < f.height; y++) cmyk_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});
         }
     }
     // write descriptors + unit tables into the staging area
@@ -696,6 +706,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
     for (int e = 0; e < kNumLumaFlavours; e++)
         for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[e][k], &unit_off_luma_[e][k]);
     put(generic_units_, &unit_off_generic_);
+    put(cmyk_units_, &unit_off_cmyk_);
     // geometry pass
     xform_units_.clear();
     for (int i = 0; i < n; i++) {
@@ -1046,6 +1057,10 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
     if (rc == 0 && (which < 0 || which == 2)) {
         rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
         check("generic_color", (int)generic_units_.size());
+    }
+    if (rc == 0 && (which < 0 || which == 2)) {
+        rc = launch_cmyk_color(dimg, units_at(unit_off_cmyk_), (int)cmyk_units_.size(), stream);
+        check("cmyk_color", (int)cmyk_units_.size());
     }
     if (rc == 0 && (which < 0 || which == 4)) {
         rc = launch_transform(reinterpret_cast<const TransformImage*>(device_.data() + xform_desc_offset_),

@@ -58,7 +58,7 @@ struct PlannedImage {
     const uint8_t* data = nullptr;
     size_t size = 0;
     size_t coef_offset[4] = {0, 0, 0, 0};  // byte offset of component c inside the staging area
-    int variant = -1;                      // KernelVariant, or -1 = generic colour path, -2 = planes-to-output only
+    int variant = -1;                      // KernelVariant, or -1 = generic colour path, -2 = planes-to-output only, -3 = CMYK / YCCK
     uint32_t coef_or[4] = {0, 0, 0, 0};    // OR of |coefficient| per component (from the entropy stage)
     // GPU entropy decoding (flag HIPJPEG_FLAG_GPU_HUFFMAN and an eligible stream): the host only destuffs the scan
     bool gpu_entropy = false;
@@ -142,9 +142,9 @@ private:
     std::vector<PlannedImage> images_;
     std::vector<DecodeImage> desc_;  // host copy (device pointers inside)
     // index [0] = 24-bit multiplier kernels, [1] = exact 32-bit multiplier kernels
-    std::vector<WorkUnit> plane_units_[2], luma_units_[3][kNumLumaVariants], generic_units_;  // luma: [LumaFlavour]
+    std::vector<WorkUnit> plane_units_[2], luma_units_[3][kNumLumaVariants], generic_units_, cmyk_units_;  // luma: [LumaFlavour]
     size_t desc_offset_ = 0, units_offset_ = 0, coef_offset_ = 0, staging_bytes_ = 0, plane_bytes_ = 0;
-    size_t unit_off_plane_[2] = {0, 0}, unit_off_luma_[3][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0;
+    size_t unit_off_plane_[2] = {0, 0}, unit_off_luma_[3][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0, unit_off_cmyk_ = 0;
     uint64_t coef_bytes_ = 0, output_bytes_ = 0;
     bool finalized_ = false;
     // ---- GPU entropy stage

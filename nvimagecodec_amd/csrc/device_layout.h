@@ -26,6 +26,7 @@ enum OutFormat : uint8_t {
 enum ImageFlags : uint8_t {
     kFlagFancyUpsampling = 1,  // libjpeg do_fancy_upsampling
     kFlagExactMul32 = 2,       // coefficient range too wide for 24-bit multiplies in IDCT pass 1
+    kFlagAdobeMarker = 4,      // the file carries an Adobe APP14 segment (selects the reference's CMYK -> RGB formula)
 };
 
 // Per-component part of the descriptor.  Kept as one aligned record per component (rather than parallel arrays inside

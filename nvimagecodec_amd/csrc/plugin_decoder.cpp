@@ -5,7 +5,7 @@
 // (extensions/nvjpeg/cuda_decoder.cpp).  Behavioural contract mirrored from there:
 //   * create() refuses NVIMGCODEC_DEVICE_CPU_ONLY (cuda_decoder.cpp:272-273), honours the user's allocators (:221-237)
 //   * canDecode() fills every status; acceptance rules follow cuda_decoder.cpp:52-122 minus what this decoder hands
-//     to the fallback chain (CMYK/YCCK, ROI, EXIF rotation)
+//     to the fallback chain (12-bit, arithmetic coding, regions that leave the image)
 //   * decode() is asynchronous and calls imageReady exactly once per sample; the user's stream is ordered after our
 //     work with an event before imageReady(SUCCESS) (cuda_decoder.cpp:552-558)
 // What is different by design: the reference issues one nvJPEG device call per image from per-thread streams; here the
@@ -282,12 +282,14 @@ void HipJpegDecoder::single_can_decode(nvimgcodecProcessingStatus_t* status, nvi
         *status = NVIMGCODEC_PROCESSING_STATUS_ENCODING_UNSUPPORTED;
         return;
     }
-    // four-component streams (CMYK / YCCK) and 12-bit streams belong to another decoder in the chain
-    if (cs_info.color_spec == NVIMGCODEC_COLORSPEC_CMYK || cs_info.color_spec == NVIMGCODEC_COLORSPEC_YCCK ||
-        (cs_info.num_planes > 0 && cs_info.plane_info[0].sample_type != NVIMGCODEC_SAMPLE_DATA_TYPE_UINT8)) {
+    // 12-bit streams belong to another decoder in the chain.  Four-component streams (CMYK / YCCK) are taken like the
+    // reference's plugins take them (extensions/nvjpeg/cuda_decoder.cpp:85-89; pixels as extensions/libjpeg_turbo/
+    // jpeg_mem.cpp:292-337 makes them), except as raw component planes.
+    if (cs_info.num_planes > 0 && cs_info.plane_info[0].sample_type != NVIMGCODEC_SAMPLE_DATA_TYPE_UINT8) {
         *status = NVIMGCODEC_PROCESSING_STATUS_CODESTREAM_UNSUPPORTED;
         return;
     }
+    const bool four_components = cs_info.color_spec == NVIMGCODEC_COLORSPEC_CMYK || cs_info.color_spec == NVIMGCODEC_COLORSPEC_YCCK;
     if (cs_info.chroma_subsampling == NVIMGCODEC_SAMPLING_UNSUPPORTED) *status |= NVIMGCODEC_PROCESSING_STATUS_SAMPLING_UNSUPPORTED;
 
     nvimgcodecImageInfo_t info;
@@ -320,6 +322,8 @@ void HipJpegDecoder::single_can_decode(nvimgcodecProcessingStatus_t* status, nvi
         } else if (fmt == HIPJPEG_OUTPUT_Y) {
             if (info.num_planes != 1) *status |= NVIMGCODEC_PROCESSING_STATUS_NUM_PLANES_UNSUPPORTED;
             if (info.plane_info[0].num_channels != 1) *status |= NVIMGCODEC_PROCESSING_STATUS_NUM_CHANNELS_UNSUPPORTED;
+        } else if (four_components) {
+            *status |= NVIMGCODEC_PROCESSING_STATUS_SAMPLE_FORMAT_UNSUPPORTED;  // P_YUV / P_UNCHANGED of a CMYK / YCCK stream
         } else if (info.num_planes != cs_info.num_planes) {
             *status |= NVIMGCODEC_PROCESSING_STATUS_NUM_PLANES_UNSUPPORTED;
         }

@@ -47,6 +47,7 @@ def lib():
         L.oj_decode_coefficients.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, u8p, u8p]
         L.oj_decode_component_plane.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, u8p, ctypes.c_int]
         L.oj_decode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_int]
+        L.oj_decode_cmyk.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, u8p, ctypes.c_int]
         L.oj_quality_tables.argtypes = [ctypes.c_int, u8p, u8p]
         L.oj_quality_tables.restype = None
         L.oj_enc_geometry.argtypes = [ctypes.c_int] * 5 + [u8p, u8p]
@@ -117,6 +118,17 @@ def decode(data, fmt=FMT_RGB, fancy=True):
     rc = lib().oj_decode(p, n, fmt, 1 if fancy else 0, out.ctypes.data, out.strides[0])
     if rc:
         raise OracleError(rc, "decode")
+    return out
+
+
+def decode_cmyk(data, fancy=True):
+    """Four-component frames: libjpeg-turbo's JCS_CMYK output, HxWx4 (YCCK frames converted the way jdcolor.c does)."""
+    info = read_info(data)
+    a, p, n = _buf(data)
+    out = np.zeros((info["height"], info["width"], 4), dtype=np.uint8)
+    rc = lib().oj_decode_cmyk(p, n, 1 if fancy else 0, out.ctypes.data, out.strides[0])
+    if rc:
+        raise OracleError(rc, "decode_cmyk")
     return out
 
 

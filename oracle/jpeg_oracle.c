@@ -23,7 +23,7 @@
  * git-LFS stubs in this snapshot.
  *
  * Scope: 8-bit Huffman JPEG, SOF0/SOF1/SOF2, 1 or 3 components (gray / YCbCr / Adobe-RGB), restart
- * intervals, multi-scan.  Arithmetic coding, 12-bit, lossless, CMYK/YCCK are rejected (the real
+ * intervals, multi-scan, four-component CMYK/YCCK frames.  Arithmetic coding, 12-bit, lossless are rejected (the real
  * framework hands those to another decoder).
  */
 #include <stdint.h>
@@ -930,15 +930,110 @@ int oj_decode_component_plane(const uint8_t* data, size_t len, int ci, uint8_t* 
     return rc;
 }
 
+/* Four-component frames, the way the reference's CPU path gets them out of libjpeg-turbo with out_color_space = JCS_CMYK
+ * (extensions/libjpeg_turbo/jpeg_mem.cpp:168-172): every component upsampled to full size; a CMYK frame is handed through
+ * as it is (jdcolor.c null_convert), a YCCK frame has its first three components turned into R,G,B and complemented, the
+ * fourth passed on (jdcolor.c ycck_cmyk_convert: C = 255 - R, M = 255 - G, Y = 255 - B, K = K).  full[c] = dw x dh = width x
+ * height planes.  out = 4 bytes per pixel. */
+static void oj_cmyk_pixel(const oj_dec* d, uint8_t* const full[4], size_t i, uint8_t cmyk[4])
+{
+    if (d->colorspace == OJ_CS_YCCK) {
+        uint8_t r, g, b;
+        oj_ycc_to_rgb(full[0][i], full[1][i], full[2][i], &r, &g, &b);
+        cmyk[0] = (uint8_t)(255 - r);
+        cmyk[1] = (uint8_t)(255 - g);
+        cmyk[2] = (uint8_t)(255 - b);
+    } else {
+        cmyk[0] = full[0][i];
+        cmyk[1] = full[1][i];
+        cmyk[2] = full[2][i];
+    }
+    cmyk[3] = full[3][i];
+}
+
+int oj_decode_cmyk(const uint8_t* data, size_t len, int fancy, uint8_t* out, int stride)
+{
+    oj_dec d;
+    uint8_t* full[4] = {NULL, NULL, NULL, NULL};
+    int rc = oj_parse(&d, data, len, 1), c, x, y;
+    if (rc != OJ_OK) goto done;
+    if (d.colorspace != OJ_CS_CMYK && d.colorspace != OJ_CS_YCCK) {
+        rc = OJ_ERR_ARG;
+        goto done;
+    }
+    for (c = 0; c < 4; c++) {
+        uint8_t* pl = oj_idct_component(&d, c);
+        if (!pl) {
+            rc = OJ_ERR_ARG;
+            goto done;
+        }
+        full[c] = oj_upsample(&d, c, pl, fancy);
+        free(pl);
+        if (!full[c]) {
+            rc = OJ_ERR_UNSUPPORTED;
+            goto done;
+        }
+    }
+    for (y = 0; y < d.height; y++)
+        for (x = 0; x < d.width; x++) oj_cmyk_pixel(&d, full, (size_t)y * d.width + x, out + (size_t)y * stride + 4 * x);
+done:
+    for (c = 0; c < 4; c++) free(full[c]);
+    oj_free(&d);
+    return rc;
+}
+
 /* Full decode to interleaved RGB / BGR (3 bytes per pixel) or a single gray plane. */
 int oj_decode(const uint8_t* data, size_t len, int fmt, int fancy, uint8_t* out, int stride)
 {
     oj_dec d;
-    uint8_t* full[3] = {NULL, NULL, NULL};
+    uint8_t* full[4] = {NULL, NULL, NULL, NULL};
     int rc = oj_parse(&d, data, len, 1), c, x, y, ncolor;
     if (rc != OJ_OK) goto done;
     if (d.colorspace == OJ_CS_CMYK || d.colorspace == OJ_CS_YCCK) {
-        rc = OJ_ERR_UNSUPPORTED;
+        /* the reference converts libjpeg's CMYK output itself, per pixel (extensions/libjpeg_turbo/jpeg_mem.cpp:292-337):
+         * with an Adobe marker r = k*c/255, without one r = (255-k)*(255-c)/255 (integer division); P_Y = the float expression
+         * 0.299f*r + 0.587f*g + 0.114f*b stored into a byte */
+        for (c = 0; c < 4; c++) {
+            uint8_t* pl = oj_idct_component(&d, c);
+            if (!pl) {
+                rc = OJ_ERR_ARG;
+                goto done;
+            }
+            full[c] = oj_upsample(&d, c, pl, fancy);
+            free(pl);
+            if (!full[c]) {
+                rc = OJ_ERR_UNSUPPORTED;
+                goto done;
+            }
+        }
+        for (y = 0; y < d.height; y++) {
+            uint8_t* o = out + (size_t)y * stride;
+            for (x = 0; x < d.width; x++) {
+                uint8_t q[4];
+                int r, g, b;
+                oj_cmyk_pixel(&d, full, (size_t)y * d.width + x, q);
+                if (d.saw_adobe) {
+                    r = (q[3] * q[0]) / 255;
+                    g = (q[3] * q[1]) / 255;
+                    b = (q[3] * q[2]) / 255;
+                } else {
+                    r = (255 - q[3]) * (255 - q[0]) / 255;
+                    g = (255 - q[3]) * (255 - q[1]) / 255;
+                    b = (255 - q[3]) * (255 - q[2]) / 255;
+                }
+                if (fmt == OJ_FMT_GRAY) {
+                    o[x] = (uint8_t)(0.299f * r + 0.587f * g + 0.114f * b);
+                } else if (fmt == OJ_FMT_BGR) {
+                    o[3 * x] = (uint8_t)b;
+                    o[3 * x + 1] = (uint8_t)g;
+                    o[3 * x + 2] = (uint8_t)r;
+                } else {
+                    o[3 * x] = (uint8_t)r;
+                    o[3 * x + 1] = (uint8_t)g;
+                    o[3 * x + 2] = (uint8_t)b;
+                }
+            }
+        }
         goto done;
     }
     ncolor = (fmt == OJ_FMT_GRAY && d.colorspace != OJ_CS_RGB) ? 1 : d.ncomp;
@@ -992,7 +1087,7 @@ int oj_decode(const uint8_t* data, size_t len, int fmt, int fancy, uint8_t* out,
         }
     }
 done:
-    for (c = 0; c < 3; c++) free(full[c]);
+    for (c = 0; c < 4; c++) free(full[c]);
     oj_free(&d);
     return rc;
 }
