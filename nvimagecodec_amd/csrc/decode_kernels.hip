@@ -778,7 +778,15 @@ __global__ __launch_bounds__(kThreads) void cmyk_color_kernel(const DecodeImage*
             B = (255 - k) * (255 - ye) / 255;
         }
         if (fmt == kOutY) {
-            im.out[0][(size_t)y * im.out_pitch[0] + x] = (uint8_t)(0.299f * (float)R + 0.587f * (float)G + 0.114f * (float)B);
+            // three products and two sums, each rounded to float on its own, as the reference's x86 build computes them
+            // (a fused multiply-add would round differently)
+            float yf;
+            {
+#pragma clang fp contract(off)
+                const float pr = 0.299f * (float)R, pg = 0.587f * (float)G, pb = 0.114f * (float)B;
+                yf = (pr + pg) + pb;
+            }
+            im.out[0][(size_t)y * im.out_pitch[0] + x] = (uint8_t)yf;
             continue;
         }
         if (bgr) {

@@ -290,7 +290,8 @@ void HipJpegDecoder::single_can_decode(nvimgcodecProcessingStatus_t* status, nvi
         return;
     }
     const bool four_components = cs_info.color_spec == NVIMGCODEC_COLORSPEC_CMYK || cs_info.color_spec == NVIMGCODEC_COLORSPEC_YCCK;
-    if (cs_info.chroma_subsampling == NVIMGCODEC_SAMPLING_UNSUPPORTED) *status |= NVIMGCODEC_PROCESSING_STATUS_SAMPLING_UNSUPPORTED;
+    // the framework's parser names no sampling for four components (reference src/parsers/jpeg.cpp:70-114 returns UNSUPPORTED)
+    if (!four_components && cs_info.chroma_subsampling == NVIMGCODEC_SAMPLING_UNSUPPORTED) *status |= NVIMGCODEC_PROCESSING_STATUS_SAMPLING_UNSUPPORTED;
 
     nvimgcodecImageInfo_t info;
     memset(&info, 0, sizeof info);
