@@ -7,7 +7,9 @@
 // the API route of DESIGN.md, measured without any Python in the way.
 //
 //   hipimtrans -i <file|dir> [-o <dir>] [-b batch] [-w warmup batches] [-r repeats] [-q quality] [-s 444|422|420|gray]
-//              [-d device] [-t cpu threads] [--skip_encode] [--options "<plugin options>"] [-v]
+//              [-d device] [-t cpu threads] [-p batches in flight (decode only)] [--skip_encode] [--options "<plugin options>"] [-v]
+// -p N > 1 uses what the API offers for throughput: nvimgcodecDecoderDecode returns a future as soon as the batch is scheduled
+// (include/nvimgcodec_abi.h; reference nvimgcodec.h:1455-1459), so the caller submits batch n+1 before it waits for batch n.
 #include <dirent.h>
 #include <hip/hip_runtime_api.h>
 #include <sys/stat.h>
@@ -50,7 +52,7 @@ double wtime()
 
 struct Params {
     std::string input, output, options;
-    int batch = 16, warmup = 1, repeats = 1, quality = 90, device = 0, threads = 0, verbose = 0;
+    int batch = 16, warmup = 1, repeats = 1, quality = 90, device = 0, threads = 0, verbose = 0, in_flight = 1;
     std::string subsampling = "420";
     bool skip_encode = false;
 };
@@ -109,6 +111,7 @@ int main(int argc, char** argv)
         else if (a == "-s") p.subsampling = next();
         else if (a == "-d") p.device = atoi(next());
         else if (a == "-t") p.threads = atoi(next());
+        else if (a == "-p") p.in_flight = std::max(1, std::min(3, atoi(next())));
         else if (a == "--options") p.options = next();
         else if (a == "--skip_encode") p.skip_encode = true;
         else if (a == "-v") p.verbose++;
@@ -159,6 +162,107 @@ int main(int argc, char** argv)
                                               : p.subsampling == "422" ? NVIMGCODEC_SAMPLING_422
                                               : p.subsampling == "gray" ? NVIMGCODEC_SAMPLING_GRAY
                                                                         : NVIMGCODEC_SAMPLING_420;
+
+    if (p.in_flight > 1 && p.skip_encode) {
+        // ---- decode only, several batches in flight: slot k holds the files, code streams, images, output buffers and future
+        // of one batch; a slot is reused after its future has been waited for
+        struct Slot {
+            std::vector<std::vector<unsigned char>> files;
+            std::vector<nvimgcodecCodeStream_t> streams;
+            std::vector<nvimgcodecImage_t> images;
+            std::vector<void*> buffers;
+            std::vector<size_t> bytes;
+            nvimgcodecFuture_t future = nullptr;
+            int n = 0;
+        };
+        std::vector<Slot> slots(p.in_flight);
+        for (auto& sl : slots) {
+            sl.buffers.assign(p.batch, nullptr);
+            sl.bytes.assign(p.batch, 0);
+        }
+        // the files are read once, before the clock starts: this mode measures the decode route, not the file system
+        std::vector<std::vector<unsigned char>> preloaded(names.size());
+        for (size_t i = 0; i < names.size(); i++)
+            if (!read_file(names[i], &preloaded[i])) {
+                fprintf(stderr, "cannot read %s\n", names[i].c_str());
+                return EXIT_FAILURE;
+            }
+        const size_t total = names.size() * (size_t)p.repeats, warm_images = (size_t)p.warmup * p.batch;
+        size_t submitted = 0, done = 0, failed = 0, cursor = 0;
+        int head = 0, tail = 0, pending = 0;
+        double t_begin = wtime();
+        bool timing = warm_images == 0;
+        auto retire = [&]() -> int {
+            Slot& sl = slots[tail];
+            CHECK_API(nvimgcodecFutureWaitForAll(sl.future));
+            size_t count = 0;
+            nvimgcodecFutureGetProcessingStatus(sl.future, nullptr, &count);
+            std::vector<nvimgcodecProcessingStatus_t> st(count);
+            nvimgcodecFutureGetProcessingStatus(sl.future, st.data(), &count);
+            for (auto v : st) failed += v != NVIMGCODEC_PROCESSING_STATUS_SUCCESS;
+            nvimgcodecFutureDestroy(sl.future);
+            for (auto cs : sl.streams) nvimgcodecCodeStreamDestroy(cs);
+            for (auto im : sl.images) nvimgcodecImageDestroy(im);
+            done += (size_t)sl.n;
+            tail = (tail + 1) % p.in_flight;
+            pending--;
+            return EXIT_SUCCESS;
+        };
+        while (submitted < total + warm_images) {
+            if (pending == p.in_flight && retire() != EXIT_SUCCESS) return EXIT_FAILURE;
+            if (!timing && done >= warm_images) {  // the warm-up batches are through: the clock starts here
+                timing = true;
+                t_begin = wtime();
+            }
+            Slot& sl = slots[head];
+            sl.n = (int)std::min<size_t>((size_t)p.batch, total + warm_images - submitted);
+            sl.streams.assign(sl.n, nullptr);
+            sl.images.assign(sl.n, nullptr);
+            for (int i = 0; i < sl.n; i++) {
+                const std::vector<unsigned char>& file = preloaded[(cursor + i) % names.size()];
+                CHECK_API(nvimgcodecCodeStreamCreateFromHostMem(instance, &sl.streams[i], file.data(), file.size()));
+                nvimgcodecImageInfo_t info{};
+                info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+                info.struct_size = sizeof info;
+                CHECK_API(nvimgcodecCodeStreamGetImageInfo(sl.streams[i], &info));
+                const uint32_t w = info.plane_info[0].width, h = info.plane_info[0].height;
+                info.sample_format = NVIMGCODEC_SAMPLEFORMAT_I_RGB;
+                info.color_spec = NVIMGCODEC_COLORSPEC_SRGB;
+                info.chroma_subsampling = NVIMGCODEC_SAMPLING_NONE;
+                info.num_planes = 1;
+                info.plane_info[0].num_channels = 3;
+                info.plane_info[0].row_stride = (size_t)w * 3;
+                info.plane_info[0].sample_type = NVIMGCODEC_SAMPLE_DATA_TYPE_UINT8;
+                info.buffer_size = (size_t)w * 3 * h;
+                info.buffer_kind = NVIMGCODEC_IMAGE_BUFFER_KIND_STRIDED_DEVICE;
+                if (sl.bytes[i] < info.buffer_size) {
+                    if (sl.buffers[i]) CHECK_HIP(hipFree(sl.buffers[i]));
+                    CHECK_HIP(hipMalloc(&sl.buffers[i], info.buffer_size));
+                    sl.bytes[i] = info.buffer_size;
+                }
+                info.buffer = sl.buffers[i];
+                CHECK_API(nvimgcodecImageCreate(instance, &sl.images[i], &info));
+            }
+            CHECK_API(nvimgcodecDecoderDecode(decoder, sl.streams.data(), sl.images.data(), sl.n, &dparams, &sl.future));
+            cursor += (size_t)sl.n;
+            submitted += (size_t)sl.n;
+            head = (head + 1) % p.in_flight;
+            pending++;
+        }
+        while (pending)
+            if (retire() != EXIT_SUCCESS) return EXIT_FAILURE;
+        CHECK_HIP(hipDeviceSynchronize());
+        const double t = wtime() - t_begin;
+        printf("\nTotal images: %zu (failed: %zu), batch size %d, %d batches in flight\n", total, failed, p.batch, p.in_flight);
+        printf("Total decoding time (parsing included, files preloaded): %f\n", t);
+        printf("Avg decoding speed  (in images per sec): %f\n", total / t);
+        for (auto& sl : slots)
+            for (void* b : sl.buffers)
+                if (b) (void)hipFree(b);
+        nvimgcodecDecoderDestroy(decoder);
+        nvimgcodecInstanceDestroy(instance);
+        return failed ? EXIT_FAILURE : EXIT_SUCCESS;
+    }
 
     const size_t total_images = names.size() * (size_t)p.repeats;
     std::vector<std::vector<unsigned char>> file_data(p.batch);
