@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhipjpeg_ext.so")
+LIB_PATH = os.environ.get("HIPJPEG_LIB_PATH") or os.path.join(_HERE, "libhipjpeg_ext.so")  # the override is a development aid (A/B builds)
 
 STATUS_NAMES = {0: "SUCCESS", 1: "INVALID_ARGUMENT", 2: "BAD_JPEG", 3: "UNSUPPORTED", 4: "TRUNCATED", 5: "CORRUPT", 6: "ALLOC_FAILED",
                 7: "HIP_ERROR", 8: "NO_DEVICE", 9: "BUFFER_TOO_SMALL", 10: "INTERNAL_ERROR"}

@@ -516,7 +516,7 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     work_changed_ = work_first_block_ + align_up(total_subseq_ * 4, 256);
     work_incoming_ = work_changed_ + 256;
     work_tail_ = align_up(work_incoming_ + max_huff_units_ * 8, 256);  // tail tasks (256 B per unit) + counts
-    work_dc_diff_ = align_up(work_tail_ + max_huff_units_ * 260, 256);
+    work_dc_diff_ = align_up(work_tail_ + max_huff_units_ * (kTailTaskBytes + 4), 256);
     work_block_pos_ = align_up(work_dc_diff_ + huff_blocks_total * 2, 256);
     work_drops_ = align_up(work_block_pos_ + huff_blockpos_total * 4, 256);
     work_prog_pos_ = align_up(work_drops_ + huff_chunks_total * 4, 256);
@@ -854,8 +854,8 @@ hipjpegStatus_t DecodeBatch::enqueue_gpu_entropy(void* stream)
         return HIPJPEG_STATUS_SUCCESS;
     }
     static const int tail_after = getenv("HIPJPEG_TAIL_AFTER") ? atoi(getenv("HIPJPEG_TAIL_AFTER")) : 2;  // tuning aid; 0 = no tail kernel
-    uint8_t* tail_tasks = work_.data() + work_tail_;
-    uint32_t* tail_count = reinterpret_cast<uint32_t*>(work_.data() + work_tail_ + (size_t)max_huff_units_ * 256);
+    uint16_t* tail_tasks = reinterpret_cast<uint16_t*>(work_.data() + work_tail_);
+    uint32_t* tail_count = reinterpret_cast<uint32_t*>(work_.data() + work_tail_ + (size_t)max_huff_units_ * kTailTaskBytes);
     if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 1, tail_after > 0 ? tail_after : 1 << 20,
                          tail_after > 0 ? tail_tasks : nullptr, tail_after > 0 ? tail_count : nullptr, L.pool_bytes, stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;

@@ -19,10 +19,10 @@ int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, 
 // pool_bytes = dynamic LDS for the lookup tables: 2 * the largest HuffImage::pool_words of the batch
 // units[i].first = first owned subsequence of workgroup i, a multiple of kHuffOwn; incoming = one uint64 per unit
 // max_rounds / tail_tasks / tail_count: after max_rounds correction rounds the workgroup hands what is left (tail_tasks:
-// 256 bytes per unit, tail_count: one uint32 per unit) to the tail kernel, launched right behind it; tail_count == nullptr:
+// kTailTaskBytes per unit, tail_count: one uint32 per unit) to the tail kernel, launched right behind it; tail_count == nullptr:
 // the workgroup iterates to its fixpoint itself.
 int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
-                     unsigned int* changed, int first_pass, int max_rounds, uint8_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream);
+                     unsigned int* changed, int first_pass, int max_rounds, uint16_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream);
 int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages, const unsigned long long* states, uint32_t* first_block, void* stream);
 // Write pass: position kernel over the sync units, then the block kernel over block_units ({image, first MCU}, kHuffMcusPerWg
 // MCUs each).

@@ -31,6 +31,8 @@ namespace {
 constexpr int kThreads = 256;
 
 constexpr int kRowWords = kSubseqWords + 1;
+constexpr int kRowShift = kSubseqWords == 32 ? 5 : kSubseqWords == 16 ? 4 : kSubseqWords == 64 ? 6 : -1;  // log2(words per subsequence)
+static_assert(kRowShift > 0, "subsequences of 512, 1024 or 2048 bits");
 
 #define HJ_LDS __attribute__((address_space(3)))
 #define HJ_GLOBAL __attribute__((address_space(1)))
@@ -41,18 +43,18 @@ struct KSlot {
     uint32_t stride_y, stride_x;
 };
 
-// Stream words in LDS: word d of the staged range sits at index d + (d >> 5) -- 33 words per 32-word subsequence, so that
+// Stream words in LDS: word d of the staged range sits at index d + d / kSubseqWords -- one spare word per subsequence, so that
 // lanes at the same column of their rows hit different banks.  kStagedExtra words behind the last row cover the bit
 // reader's look-ahead.
 constexpr int kStagedExtra = 4;
 __host__ __device__ constexpr int staged_lds_words(int rows) { return rows * kRowWords + kStagedExtra; }
 
 struct WgShared {
-    uint32_t stream[staged_lds_words(kThreads)];
-    unsigned long long end[kThreads];  // end state of lane t's subsequence ([0] = halo = state entering the workgroup)
+    uint32_t stream[staged_lds_words(kSyncThreads)];
+    unsigned long long end[kSyncThreads];  // end state of lane t's subsequence ([0] = halo = state entering the workgroup)
     uint32_t tsel[10];
-    uint32_t queue[kThreads];
-    uint32_t wave_count[4];
+    uint32_t queue[kSyncThreads];
+    uint32_t wave_count[kSyncThreads / 64];
 };
 
 // restart boundaries live in global memory (a handful of reads per decode; the destuffed positions come from the host's
@@ -73,7 +75,7 @@ struct DevEnv {
     __device__ __forceinline__ uint32_t word(uint32_t i) const
     {
         const uint32_t local = i - word0;
-        return *(const HJ_LDS uint32_t*)(uintptr_t)(stream_base + ((local + (local >> 5)) << 2));
+        return *(const HJ_LDS uint32_t*)(uintptr_t)(stream_base + ((local + (local >> kRowShift)) << 2));
     }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
     __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
@@ -128,7 +130,7 @@ __device__ __forceinline__ void stage_rows(uint32_t* lds_stream, const HuffImage
     for (int i = 0; i < kIters; i++) {
         if (i * THREADS + t < kGroups) {
             const uint32_t d = (uint32_t)(i * THREADS + t) * 4;  // the four words share a row: 32 % 4 == 0
-            HJ_LDS uint32_t* dst = (HJ_LDS uint32_t*)&lds_stream[d + (d >> 5)];
+            HJ_LDS uint32_t* dst = (HJ_LDS uint32_t*)&lds_stream[d + (d >> kRowShift)];
             dst[0] = __builtin_bswap32(v[i].x);
             dst[1] = __builtin_bswap32(v[i].y);
             dst[2] = __builtin_bswap32(v[i].z);
@@ -198,7 +200,7 @@ __device__ __forceinline__ int compact_tasks(WgShared& sh, bool has, int value, 
     __syncthreads();
     int base = 0, n = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < kSyncThreads / 64; w++) {
         const int c = (int)sh.wave_count[w];
         if (w < (t >> 6)) base += c;
         n += c;
@@ -392,10 +394,10 @@ __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __
 // long tail of rounds with a handful of corrections occupies one wave instead of four.
 // later passes: a workgroup whose incoming state still equals its guess has nothing to do and leaves before staging
 // anything; otherwise the ripple starts from its first subsequence.
-__global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+__global__ __launch_bounds__(kSyncThreads) void huff_sync_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
                                                              unsigned long long* __restrict__ states, unsigned long long* __restrict__ incoming,
                                                              unsigned int* __restrict__ counters, int first_pass, int max_rounds,
-                                                             uint8_t* __restrict__ tail_tasks, uint32_t* __restrict__ tail_count)
+                                                             uint16_t* __restrict__ tail_tasks, uint32_t* __restrict__ tail_count)
 {
     __shared__ WgShared sh;
     extern __shared__ uint16_t dyn_pool[];
@@ -409,14 +411,14 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
     const int t = threadIdx.x;
     const uint32_t j = u.first - 1 + t;  // subsequence of lane t (lane 0: the halo; none for the first workgroup of an image)
     const bool owner = t >= 1 && j < nsub;
-    const int n_rows = (int)min((uint32_t)kThreads, nsub - u.first + 1);  // rows 1 .. n_rows-1 are owned
+    const int n_rows = (int)min((uint32_t)kSyncThreads, nsub - u.first + 1);  // rows 1 .. n_rows-1 are owned
     unsigned long long in_state = 0;
     if (!first_pass) {
         in_state = u.first ? __hip_atomic_load(&gstate[u.first - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kSyncMask : 0ull;
         if (in_state == incoming[blockIdx.x]) return;  // uniform
     }
-    stage_rows<kThreads, kThreads>(sh.stream, im, (int)u.first - 1);
-    stage_pool<kThreads>(pool, im);
+    stage_rows<kSyncThreads, kSyncThreads>(sh.stream, im, (int)u.first - 1);
+    stage_pool<kSyncThreads>(pool, im);
     stage_constants(sh.tsel, nullptr, nullptr, im, false);
     __syncthreads();
 
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
         if (t == 1) task = 1;
     }
     int rounds = 0;
-    for (int round = 0; round < kThreads + 2; round++) {
+    for (int round = 0; round < kSyncThreads + 2; round++) {
         __syncthreads();
         rounds++;
         unsigned long long now = 0;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(kThreads) void huff_sync_kernel(const HuffImage* __
             // what is left goes to the tail kernel: few subsequences per round, one lane busy per chain -- not worth holding
             // 47 KB of LDS for
             if (tail_count) {
-                if (t < pending) tail_tasks[(size_t)blockIdx.x * kThreads + t] = (uint8_t)task;
+                if (t < pending) tail_tasks[(size_t)blockIdx.x * kSyncThreads + t] = (uint16_t)task;
                 if (t == 0) tail_count[blockIdx.x] = (uint32_t)pending;
             }
             break;
@@ -489,10 +491,10 @@ constexpr int kTailThreads = 64;
 constexpr int kTailRowWords = kSubseqWords + kStagedExtra;
 
 struct TailShared {
-    unsigned long long end[kThreads];  // end states of the group's rows ([0] = state entering the group)
+    unsigned long long end[kSyncThreads];  // end states of the group's rows ([0] = state entering the group)
     uint32_t rows[kTailThreads * kTailRowWords];
     uint32_t tsel[10];
-    uint8_t list[2][kThreads];         // subsequences to decode this round / next round
+    uint16_t list[2][kSyncThreads];         // subsequences to decode this round / next round
     uint32_t count[2];
 };
 
@@ -522,7 +524,7 @@ struct TailEnv {
 
 __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
                                                                  unsigned long long* __restrict__ states, const unsigned long long* __restrict__ incoming,
-                                                                 unsigned int* __restrict__ counters, const uint8_t* __restrict__ tail_tasks,
+                                                                 unsigned int* __restrict__ counters, const uint16_t* __restrict__ tail_tasks,
                                                                  const uint32_t* __restrict__ tail_count)
 {
     __shared__ TailShared sh;
@@ -537,11 +539,11 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
     if (u.first >= nsub) return;
     unsigned long long* gstate = states + im.first_subseq;
     const int t = threadIdx.x;
-    const int n_rows = (int)min((uint32_t)kThreads, nsub - u.first + 1);
+    const int n_rows = (int)min((uint32_t)kSyncThreads, nsub - u.first + 1);
     stage_pool<kTailThreads>(pool, im);
     stage_constants(sh.tsel, nullptr, nullptr, im, false);
     for (int r = t; r < n_rows; r += kTailThreads) sh.end[r] = r == 0 ? incoming[blockIdx.x] : gstate[u.first - 1 + r];
-    for (uint32_t i = t; i < pending; i += kTailThreads) sh.list[0][i] = tail_tasks[(size_t)blockIdx.x * kThreads + i];
+    for (uint32_t i = t; i < pending; i += kTailThreads) sh.list[0][i] = tail_tasks[(size_t)blockIdx.x * kSyncThreads + i];
     if (t == 0) sh.count[0] = pending;
     __syncthreads();
 
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
     const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
     const uint32_t gwords = im.stream_words;
     int rounds = 0, cur = 0;
-    for (int round = 0; round < kThreads + 2; round++) {
+    for (int round = 0; round < kSyncThreads + 2; round++) {
         const uint32_t n = sh.count[cur];
         if (n == 0) break;
         rounds++;
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
             if (busy) sh.end[task] = now;
             const bool more = busy && moved && task + 1 < n_rows;
             const unsigned long long mask = __ballot(more);
-            if (more) sh.list[cur ^ 1][sh.count[cur ^ 1] + __popcll(mask & ((1ull << t) - 1))] = (uint8_t)(task + 1);
+            if (more) sh.list[cur ^ 1][sh.count[cur ^ 1] + __popcll(mask & ((1ull << t) - 1))] = (uint16_t)(task + 1);
             __syncthreads();
             if (t == 0) sh.count[cur ^ 1] += (uint32_t)__popcll(mask);
             __syncthreads();
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(kThreads) void huff_scan_kernel(HuffImage* __restri
 // ---- write pass, step 1: where the blocks start -----------------------------------------------------------------------------
 // Same workgroup shape as the sync kernel (lane 0 idles): every lane walks its subsequence from the converged start state
 // and records the bit position of each block that starts inside it.
-__global__ __launch_bounds__(kThreads) void huff_pos_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+__global__ __launch_bounds__(kSyncThreads) void huff_pos_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
                                                             const unsigned long long* __restrict__ states, const uint32_t* __restrict__ first_block)
 {
     __shared__ WgShared sh;
@@ -657,8 +659,8 @@ __global__ __launch_bounds__(kThreads) void huff_pos_kernel(HuffImage* __restric
     const HuffGeom geom = make_geom(im);
     const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
     if (u.first >= nsub) return;
-    stage_rows<kThreads, kThreads>(sh.stream, im, (int)u.first - 1);
-    stage_pool<kThreads>(pool, im);
+    stage_rows<kSyncThreads, kSyncThreads>(sh.stream, im, (int)u.first - 1);
+    stage_pool<kSyncThreads>(pool, im);
     stage_constants(sh.tsel, nullptr, nullptr, im, false);
     __syncthreads();
     const int t = threadIdx.x;
@@ -931,10 +933,10 @@ int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, 
 }
 
 int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
-                     unsigned int* changed, int first_pass, int max_rounds, uint8_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream)
+                     unsigned int* changed, int first_pass, int max_rounds, uint16_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream)
 {
     if (nunits <= 0) return 0;
-    hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
+    hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kSyncThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
                        first_pass, max_rounds, tail_tasks, tail_count);
     if (tail_count)
         hipLaunchKernelGGL(huff_tail_kernel, dim3(nunits), dim3(kTailThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
@@ -953,7 +955,7 @@ int launch_huff_write(HuffImage* images, const HuffUnit* sync_units, int nsync_u
                       const unsigned long long* states, const uint32_t* first_block, unsigned pool_bytes, void* stream)
 {
     if (nsync_units <= 0) return 0;
-    hipLaunchKernelGGL(huff_pos_kernel, dim3(nsync_units), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, sync_units, states, first_block);
+    hipLaunchKernelGGL(huff_pos_kernel, dim3(nsync_units), dim3(kSyncThreads), pool_bytes, (hipStream_t)stream, images, sync_units, states, first_block);
     if (nblock_units > 0) hipLaunchKernelGGL(huff_blocks_kernel, dim3(nblock_units), dim3(kBThreads), pool_bytes, (hipStream_t)stream, images, block_units);
     return (int)hipGetLastError();
 }

@@ -33,12 +33,20 @@
 
 namespace hipjpeg {
 
-constexpr int kSubseqBits = 1024;      // bits per subsequence (128 bytes)
+#ifndef HJ_SUBSEQ_BITS
+#define HJ_SUBSEQ_BITS 1024
+#endif
+#ifndef HJ_SYNC_THREADS
+#define HJ_SYNC_THREADS 256
+#endif
+constexpr int kSubseqBits = HJ_SUBSEQ_BITS;  // bits per subsequence (one lane's share of the stream; its LDS footprint)
 constexpr int kSubseqWords = kSubseqBits / 32;
 constexpr int kHuffFastBits = 10;      // first-level lookup width
 constexpr int kHuffSubBits = 16 - kHuffFastBits;
 constexpr int kStreamSlackBytes = 32;  // readable bytes after the last real byte of a destuffed stream
-constexpr int kHuffOwn = 255;          // subsequences per workgroup of the sync/write kernels (256 lanes, one is the halo)
+constexpr int kSyncThreads = HJ_SYNC_THREADS;  // lanes of a workgroup of the sync / position kernels
+constexpr int kHuffOwn = kSyncThreads - 1;     // subsequences such a workgroup owns (one lane is the halo)
+constexpr int kTailTaskBytes = 2 * kSyncThreads;  // per workgroup: the subsequences (uint16) it hands to the tail kernel
 constexpr int kHuffBlocksPerWg = 256;   // lanes per workgroup of the block pass (one block per lane per round)
 constexpr int kHuffMcusPerWg = 128;     // MCUs a workgroup of the block pass covers
 constexpr int kDestuffChunk = 16384;   // raw bytes one workgroup of the destuff kernels handles
