@@ -184,7 +184,8 @@ typedef struct {
 typedef struct {
     int32_t quality;           /* 1..100, libjpeg quality scaling of the Annex-K tables */
     int32_t subsampling;       /* hipjpegChromaSubsampling_t of the OUTPUT stream (GRAY = single component) */
-    int32_t input_format;      /* HIPJPEG_OUTPUT_RGBI / BGRI / RGB_PLANAR / BGR_PLANAR / Y (gray plane) */
+    int32_t input_format;      /* HIPJPEG_OUTPUT_RGBI / BGRI / RGB_PLANAR / BGR_PLANAR / Y (gray plane) / YUV_PLANAR (Y, Cb, Cr planes
+                                  already in the stream's sampling: plane c holds ceil(width / hs_c) x ceil(height / vs_c) samples) */
     int32_t restart_interval;  /* MCUs per restart interval, 0 = none */
     int32_t optimized_huffman; /* 0 = Annex-K tables, 1 = per-image optimal tables (two-pass) */
 } hipjpegEncodeParams_t;

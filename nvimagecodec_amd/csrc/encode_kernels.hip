@@ -609,10 +609,55 @@ __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forwa
 
 }  // namespace
 
+// Pre-subsampled planar YCbCr input (NVIMGCODEC_SAMPLEFORMAT_P_YUV; the reference hands such images to nvjpegEncodeYUV,
+// extensions/nvjpeg/cuda_encoder.cpp:362-368): no colour conversion, no downsampling -- every plane is a component as it goes
+// into the stream.  One lane per block of the component's real block grid (unit: pad = component, tile_bx = first block);
+// samples past the plane's edge replicate the last column / row, as libjpeg pads (jcprepct.c, jcsample.c expand_right_edge).
+__global__ __launch_bounds__(kThreads) void forward_planes_kernel(const EncodeImage* __restrict__ images, const EncodeUnit* __restrict__ units)
+{
+    const EncodeUnit u = units[blockIdx.x];
+    const EncodeImage& im = images[u.image];
+    const int c = (int)u.pad;  // 0, 1, 2 (uniform)
+    const unsigned char* plane = c == 0 ? im.in[0] : c == 1 ? im.in[1] : im.in[2];
+    const unsigned pitch = c == 0 ? im.in_pitch[0] : c == 1 ? im.in_pitch[1] : im.in_pitch[2];
+    const int real_w = (int)(c == 0 ? im.real_w[0] : c == 1 ? im.real_w[1] : im.real_w[2]);
+    const int real_h = (int)(c == 0 ? im.real_h[0] : c == 1 ? im.real_h[1] : im.real_h[2]);
+    const int grid_w = (int)(c == 0 ? im.blocks_w[0] : c == 1 ? im.blocks_w[1] : im.blocks_w[2]);
+    int16_t* coef = c == 0 ? im.coef[0] : c == 1 ? im.coef[1] : im.coef[2];
+    // the plane's own size: luma = the picture, chroma = ceil(picture / sampling factor)
+    const int pw = c == 0 ? (int)im.width : ((int)im.width + (int)im.hs - 1) / (int)im.hs;
+    const int ph = c == 0 ? (int)im.height : ((int)im.height + (int)im.vs - 1) / (int)im.vs;
+    const int b = (int)u.tile_bx + (int)threadIdx.x;
+    if (b >= real_w * real_h) return;
+    const int by = b / real_w, bx = b - by * real_w;
+    int s[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const unsigned char* row = plane + (size_t)min(by * 8 + r, ph - 1) * pitch;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[r][k] = (int)row[min(bx * 8 + k, pw - 1)] - 128;
+    }
+    u32x4 packed[8];
+    if (c == 0)
+        fdct_quantize(s, im.quant[0], packed);
+    else
+        fdct_quantize(s, im.quant[1], packed);
+    u32x4* dst = reinterpret_cast<u32x4*>(coef + ((size_t)by * grid_w + bx) * 64);
+#pragma unroll
+    for (int j = 0; j < 8; j++) dst[j] = packed[j];
+}
+
 int launch_forward(const EncodeImage* images, const EncodeUnit* units, int nunits, void* stream)
 {
     if (nunits <= 0) return 0;
     hipLaunchKernelGGL(forward_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    return (int)hipGetLastError();
+}
+
+int launch_forward_planes(const EncodeImage* images, const EncodeUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    hipLaunchKernelGGL(forward_planes_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
     return (int)hipGetLastError();
 }
 

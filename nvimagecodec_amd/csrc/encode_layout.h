@@ -15,6 +15,7 @@ enum InFormat : uint32_t {
     kInPlanarRGB = 2,
     kInPlanarBGR = 3,
     kInGray = 4,
+    kInPlanarYUV = 5,  // Y, Cb, Cr planes as they go into the stream: luma at full size, chroma already downsampled
 };
 
 // Quantizer of one table, indexed by ZIGZAG position k: divisor = 8*q[k]; half = divisor/2; magic = floor(2^28/divisor)+1

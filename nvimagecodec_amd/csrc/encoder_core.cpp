@@ -75,10 +75,11 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
         if (im.status == HIPJPEG_STATUS_SUCCESS) {
             if (in.width < 1 || in.height < 1 || in.width > 65535 || in.height > 65535) im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
             if (fmt != HIPJPEG_OUTPUT_RGBI && fmt != HIPJPEG_OUTPUT_BGRI && fmt != HIPJPEG_OUTPUT_RGB_PLANAR && fmt != HIPJPEG_OUTPUT_BGR_PLANAR &&
-                fmt != HIPJPEG_OUTPUT_Y)
+                fmt != HIPJPEG_OUTPUT_Y && fmt != HIPJPEG_OUTPUT_YUV_PLANAR)
                 im.status = HIPJPEG_STATUS_UNSUPPORTED;
             if (fmt == HIPJPEG_OUTPUT_Y && g.ncomp != 1) im.status = HIPJPEG_STATUS_UNSUPPORTED;  // gray pixels carry no chroma
-            const int nplanes = (fmt == HIPJPEG_OUTPUT_RGB_PLANAR || fmt == HIPJPEG_OUTPUT_BGR_PLANAR) ? 3 : 1;
+            if (fmt == HIPJPEG_OUTPUT_YUV_PLANAR && g.ncomp != 3) im.status = HIPJPEG_STATUS_UNSUPPORTED;
+            const int nplanes = (fmt == HIPJPEG_OUTPUT_RGB_PLANAR || fmt == HIPJPEG_OUTPUT_BGR_PLANAR || fmt == HIPJPEG_OUTPUT_YUV_PLANAR) ? 3 : 1;
             for (int p = 0; p < nplanes; p++)
                 if (!in.plane[p]) im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
             if (params[i].restart_interval < 0 || params[i].restart_interval > 65535) im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
@@ -93,7 +94,7 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
         d.ncomp = (uint32_t)g.ncomp;
         d.hs = (uint32_t)g.hs;
         d.vs = (uint32_t)g.vs;
-        d.in_format = fmt == HIPJPEG_OUTPUT_Y ? (uint32_t)kInGray : (uint32_t)fmt;  // RGBI/BGRI/planar values coincide with InFormat
+        d.in_format = fmt == HIPJPEG_OUTPUT_Y ? (uint32_t)kInGray : (uint32_t)fmt;  // RGBI/BGRI/planar/YUV values coincide with InFormat
         for (int p = 0; p < 3; p++) {
             d.in[p] = static_cast<const uint8_t*>(in.plane[p]);
             d.in_pitch[p] = in.pitch[p];
@@ -123,12 +124,18 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
         int flavour = 0;
         if (g.ncomp == 3 && (fmt == HIPJPEG_OUTPUT_RGBI || fmt == HIPJPEG_OUTPUT_BGRI) && ((((uintptr_t)in.plane[0]) | in.pitch[0]) & 7) == 0)
             flavour = (g.hs == 2 && g.vs == 2) ? 1 : (g.hs == 2 && g.vs == 1) ? 2 : (g.hs == 1 && g.vs == 1) ? 3 : 0;
-        for (int ty = 0; ty < tiles_y; ty++)
-            for (int tx = 0; tx < tiles_x; tx++) unit_lists_[flavour].push_back(EncodeUnit{(uint32_t)i, (uint32_t)tx, (uint32_t)ty, 0u});
+        if (fmt == HIPJPEG_OUTPUT_YUV_PLANAR) {
+            // planes that are components already: one lane per real block of each component
+            for (int c = 0; c < 3; c++)
+                for (int b = 0; b < g.real_w[c] * g.real_h[c]; b += 256) unit_lists_[4].push_back(EncodeUnit{(uint32_t)i, (uint32_t)b, 0u, (uint32_t)c});
+        } else {
+            for (int ty = 0; ty < tiles_y; ty++)
+                for (int tx = 0; tx < tiles_x; tx++) unit_lists_[flavour].push_back(EncodeUnit{(uint32_t)i, (uint32_t)tx, (uint32_t)ty, 0u});
+        }
         pixel_bytes_ += (uint64_t)g.width * g.height * (g.ncomp == 1 ? 1 : 3);
         for (int c = 0; c < g.ncomp; c++) coef_bytes_ += (uint64_t)g.real_w[c] * g.real_h[c] * 128;
     }
-    for (int f = 0; f < 4; f++) {  // one table, the flavours back to back
+    for (int f = 0; f < 5; f++) {  // one table, the flavours back to back
         unit_first_[f] = units_.size();
         units_.insert(units_.end(), unit_lists_[f].begin(), unit_lists_[f].end());
     }
@@ -161,6 +168,7 @@ hipjpegStatus_t EncodeBatch::relaunch(void* stream)
     static const int pair_hs[4] = {0, 2, 2, 1}, pair_vs[4] = {0, 2, 1, 1};
     int rc = launch_forward(dimg, dunits + unit_first_[0], (int)unit_lists_[0].size(), stream);
     for (int f = 1; f < 4 && rc == 0; f++) rc = launch_forward_pair(pair_hs[f], pair_vs[f], dimg, dunits + unit_first_[f], (int)unit_lists_[f].size(), stream);
+    if (rc == 0) rc = launch_forward_planes(dimg, dunits + unit_first_[4], (int)unit_lists_[4].size(), stream);
     if (rc != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (!event_) {
         hipEvent_t ev;

@@ -54,8 +54,8 @@ private:
     std::vector<PlannedEncode> images_;
     std::vector<EncodeImage> desc_;
     std::vector<EncodeUnit> units_;            // every tile of the batch, grouped by kernel flavour
-    std::vector<EncodeUnit> unit_lists_[4];    // [0] one-lane-per-block kernel, [1..3] forward_pair_kernel 4:2:0 / 4:2:2 / 4:4:4
-    size_t unit_first_[4] = {0, 0, 0, 0};
+    std::vector<EncodeUnit> unit_lists_[5];    // [0] one-lane-per-block kernel, [1..3] forward_pair_kernel 4:2:0 / 4:2:2 / 4:4:4, [4] planar YCbCr
+    size_t unit_first_[5] = {0, 0, 0, 0, 0};
     size_t units_offset_ = 0, coef_offset_ = 0, desc_bytes_ = 0, coef_total_ = 0;
     uint64_t pixel_bytes_ = 0, coef_bytes_ = 0;
     void* stream_ = nullptr;

@@ -38,6 +38,7 @@ bool map_input_format(nvimgcodecSampleFormat_t f, int* fmt)
     case NVIMGCODEC_SAMPLEFORMAT_P_RGB: *fmt = HIPJPEG_OUTPUT_RGB_PLANAR; return true;
     case NVIMGCODEC_SAMPLEFORMAT_P_BGR: *fmt = HIPJPEG_OUTPUT_BGR_PLANAR; return true;
     case NVIMGCODEC_SAMPLEFORMAT_P_Y: *fmt = HIPJPEG_OUTPUT_Y; return true;
+    case NVIMGCODEC_SAMPLEFORMAT_P_YUV: *fmt = HIPJPEG_OUTPUT_YUV_PLANAR; return true;
     default: return false;
     }
 }
@@ -184,7 +185,14 @@ void HipJpegEncoder::single_can_encode(nvimgcodecProcessingStatus_t* st, nvimgco
     if (!map_css(info.chroma_subsampling, &css_in)) *st |= NVIMGCODEC_PROCESSING_STATUS_SAMPLING_UNSUPPORTED;
     if (!map_css(out_info.chroma_subsampling, &css_out)) *st |= NVIMGCODEC_PROCESSING_STATUS_SAMPLING_UNSUPPORTED;
     if (!map_input_format(info.sample_format, &fmt)) {
-        *st |= NVIMGCODEC_PROCESSING_STATUS_SAMPLE_FORMAT_UNSUPPORTED;  // incl. P_YUV (pre-subsampled planar YCbCr input)
+        *st |= NVIMGCODEC_PROCESSING_STATUS_SAMPLE_FORMAT_UNSUPPORTED;
+    } else if (info.sample_format == NVIMGCODEC_SAMPLEFORMAT_P_YUV) {
+        // pre-subsampled planar YCbCr goes into the stream as it is (the reference hands it to nvjpegEncodeYUV,
+        // cuda_encoder.cpp:362-368): three planes in the output's own sampling -- resampling between samplings is not offered
+        if (info.num_planes != 3) *st |= NVIMGCODEC_PROCESSING_STATUS_NUM_PLANES_UNSUPPORTED;
+        if (info.color_spec != NVIMGCODEC_COLORSPEC_SYCC) *st |= NVIMGCODEC_PROCESSING_STATUS_COLOR_SPEC_UNSUPPORTED;
+        if (info.chroma_subsampling != out_info.chroma_subsampling || out_info.chroma_subsampling == NVIMGCODEC_SAMPLING_GRAY)
+            *st |= NVIMGCODEC_PROCESSING_STATUS_SAMPLING_UNSUPPORTED;
     } else if (info.sample_format == NVIMGCODEC_SAMPLEFORMAT_P_Y) {
         // same cross-checks as cuda_encoder.cpp:118-128
         if (info.chroma_subsampling != NVIMGCODEC_SAMPLING_GRAY || out_info.chroma_subsampling != NVIMGCODEC_SAMPLING_GRAY)
@@ -217,6 +225,9 @@ void HipJpegEncoder::host_task(int /*tid*/, int idx, void* ctx)
     auto* self = static_cast<HipJpegEncoder*>(ctx);
     Sample& s = self->samples_[idx];
     nvimgcodecProcessingStatus_t ps = s.early;
+    // nothing may escape an executor task (the reference's pool swallows exceptions, src/thread_pool.cpp:175-185, and a sample
+    // that never reports deadlocks the caller's future): whatever is thrown becomes this sample's FAIL
+    try {
     if (ps == NVIMGCODEC_PROCESSING_STATUS_SUCCESS) {
         hipjpeg::PlannedEncode& im = self->batch_->image(idx);
         if (im.status != HIPJPEG_STATUS_SUCCESS) {
@@ -232,6 +243,9 @@ void HipJpegEncoder::host_task(int /*tid*/, int idx, void* ctx)
                 written != im.file_size() || io->flush(io->instance) != NVIMGCODEC_STATUS_SUCCESS)
                 ps = NVIMGCODEC_PROCESSING_STATUS_FAIL;
         }
+    }
+    } catch (...) {
+        ps = NVIMGCODEC_PROCESSING_STATUS_FAIL;
     }
     nvimgcodecImageDesc_t* image = s.image;
     self->sample_done();  // after this the encoder may start the next batch; `s` must not be touched any more
@@ -249,13 +263,16 @@ nvimgcodecStatus_t HipJpegEncoder::encode(nvimgcodecImageDesc_t** images, nvimgc
         cv_.wait(lk, [&] { return !busy_; });
         busy_ = true;
     }
+    bool gpu_ok = false;
+    int reported = 0;  // samples handed to host tasks (they report themselves)
+    try {
     samples_.assign(n, Sample());
     std::vector<hipjpegEncodeInput_t> inputs(n);
     std::vector<hipjpegEncodeParams_t> eparams(n);
     memset(inputs.data(), 0, sizeof(hipjpegEncodeInput_t) * n);
     memset(eparams.data(), 0, sizeof(hipjpegEncodeParams_t) * n);
     const auto* jp = find_in_chain<nvimgcodecJpegEncodeParams_t>(params->struct_next, NVIMGCODEC_STRUCTURE_TYPE_JPEG_ENCODE_PARAMS);
-    bool gpu_ok = hipSetDevice(device_) == hipSuccess;
+    gpu_ok = hipSetDevice(device_) == hipSuccess;
     for (int i = 0; i < n; i++) {
         Sample& s = samples_[i];
         s.image = images[i];
@@ -309,8 +326,17 @@ nvimgcodecStatus_t HipJpegEncoder::encode(nvimgcodecImageDesc_t** images, nvimgc
     for (int i = 0; i < n; i++) any_host = any_host || host_coder_[i];
     // the host coder needs the coefficients: blocks like cudaEventSynchronize in cuda_encoder.cpp:374-375
     if (gpu_ok && any_host) gpu_ok = batch_->fetch_coefficients() == HIPJPEG_STATUS_SUCCESS;
+    } catch (...) {
+        gpu_ok = false;  // an exception while marshalling or in the device stage: the whole batch is reported failed below
+    }
     if (!gpu_ok) {
-        for (int i = 0; i < n; i++) images[i]->imageReady(images[i]->instance, NVIMGCODEC_PROCESSING_STATUS_FAIL);
+        // batch-level failure: every sample FAIL, an error code back (reference cuda_encoder.cpp error path)
+        for (int i = 0; i < n; i++) {
+            try {
+                images[i]->imageReady(images[i]->instance, NVIMGCODEC_PROCESSING_STATUS_FAIL);
+            } catch (...) {
+            }
+        }
         {
             std::lock_guard<std::mutex> lk(m_);
             busy_ = false;
@@ -321,8 +347,16 @@ nvimgcodecStatus_t HipJpegEncoder::encode(nvimgcodecImageDesc_t** images, nvimgc
     }
     remaining_.store(n);
     nvimgcodecExecutorDesc_t* ex = ep_->executor;
-    for (int i = 0; i < n; i++) {
-        if (n == 1 || !ex || ex->launch(ex->instance, device_, i, this, &HipJpegEncoder::host_task) != NVIMGCODEC_STATUS_SUCCESS) host_task(0, i, this);
+    for (int i = 0; i < n; i++, reported++) {
+        bool handed = false;
+        if (n != 1 && ex) {
+            try {
+                handed = ex->launch(ex->instance, device_, i, this, &HipJpegEncoder::host_task) == NVIMGCODEC_STATUS_SUCCESS;
+            } catch (...) {
+                handed = false;
+            }
+        }
+        if (!handed) host_task(0, i, this);  // host_task lets nothing escape
     }
     return NVIMGCODEC_STATUS_SUCCESS;
 }

@@ -257,7 +257,8 @@ class BatchDecoder:
 # ---------------------------------------------------------------------------------------------- encode
 _ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42,
                     49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
-_IN_FORMATS = {"rgb": N.OUTPUT_RGBI, "bgr": N.OUTPUT_BGRI, "rgb_planar": N.OUTPUT_RGB_PLANAR, "bgr_planar": N.OUTPUT_BGR_PLANAR, "gray": N.OUTPUT_Y}
+_IN_FORMATS = {"rgb": N.OUTPUT_RGBI, "bgr": N.OUTPUT_BGRI, "rgb_planar": N.OUTPUT_RGB_PLANAR, "bgr_planar": N.OUTPUT_BGR_PLANAR, "gray": N.OUTPUT_Y,
+               "yuv_planar": N.OUTPUT_YUV_PLANAR}
 
 
 def _enc_params(subsampling, quality, input_format="rgb", restart_interval=0, optimized_huffman=False):
@@ -326,6 +327,11 @@ class BatchEncoder:
                 h, w = t.shape
                 I[i].plane[0] = t.data_ptr()
                 I[i].pitch[0] = t.stride(0)
+            elif fmt == "yuv_planar":  # t = [Y, Cb, Cr], the chroma planes already in the stream's sampling
+                h, w = t[0].shape
+                for p in range(3):
+                    I[i].plane[p] = t[p].data_ptr()
+                    I[i].pitch[p] = t[p].stride(0)
             else:
                 h, w = t.shape[1], t.shape[2]
                 for p in range(3):

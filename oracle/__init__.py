@@ -54,6 +54,8 @@ def lib():
         L.oj_enc_geometry.restype = None
         L.oj_forward.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p, u8p,
                                  u8p, u8p, u8p]
+        L.oj_forward_planes.argtypes = [u8p, ctypes.c_int, u8p, ctypes.c_int, u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        u8p, u8p, u8p, u8p, u8p]
         L.oj_encode.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_int, u8p, ctypes.c_size_t]
         L.oj_encode.restype = ctypes.c_long
@@ -162,6 +164,21 @@ def forward(rgb, subsampling="420", quality=90):
     rc = lib().oj_forward(rgb.ctypes.data, rgb.strides[0], w, h, ncomp, hs, vs, ql.ctypes.data, qc.ctypes.data, *ptrs)
     if rc:
         raise OracleError(rc, "forward")
+    return coefs, (ql, qc)
+
+
+def forward_planes(planes, width, height, subsampling="420", quality=90):
+    """Y, Cb, Cr planes that are the stream's components already (P_YUV input) -> quantized coefficient arrays per component
+    ([bh, bw, 64] int16 natural order) + quant tables.  Edge rule: replicate the plane's last column / row (parity unpinned)."""
+    ncomp, hs, vs, bw, bh = enc_geometry(width, height, subsampling)
+    assert ncomp == 3 and len(planes) == 3
+    pl = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+    ql, qc = quality_tables(quality)
+    coefs = [np.zeros((bh[c], bw[c], 64), dtype=np.int16) for c in range(3)]
+    rc = lib().oj_forward_planes(pl[0].ctypes.data, pl[0].strides[0], pl[1].ctypes.data, pl[1].strides[0], pl[2].ctypes.data, pl[2].strides[0],
+                                 width, height, hs, vs, ql.ctypes.data, qc.ctypes.data, *[c.ctypes.data for c in coefs])
+    if rc:
+        raise OracleError(rc, "forward_planes")
     return coefs, (ql, qc)
 
 

@@ -1337,6 +1337,72 @@ done:
     return rc;
 }
 
+/* Pre-subsampled planar YCbCr input (NVIMGCODEC_SAMPLEFORMAT_P_YUV, which the reference's GPU encoder hands to nvjpegEncodeYUV,
+ * extensions/nvjpeg/cuda_encoder.cpp:362-368): the planes ARE the components -- level shift, FDCT, quantize, nothing else.
+ * Plane c holds ceil(w / hs_c) x ceil(h / vs_c) samples; blocks that reach past a plane's edge replicate its last column /
+ * row (the rule libjpeg applies to what it downsamples; nvJPEG's own rule is not documented in the reference, so this
+ * function is "parity unpinned" beyond sizes where no padding occurs).  Output as oj_forward: natural-order blocks over the
+ * MCU-padded grid, dummy blocks filled the jccoefct.c way. */
+int oj_forward_planes(const uint8_t* p0, int s0, const uint8_t* p1, int s1, const uint8_t* p2, int s2, int w, int h, int hs, int vs,
+                      const uint16_t* qlum, const uint16_t* qchr, int16_t* coef0, int16_t* coef1, int16_t* coef2)
+{
+    int32_t bw[3], bh[3];
+    int16_t* coef[3];
+    const uint8_t* plane[3];
+    int stride[3], c, x, y, bx, by;
+    coef[0] = coef0; coef[1] = coef1; coef[2] = coef2;
+    plane[0] = p0; plane[1] = p1; plane[2] = p2;
+    stride[0] = s0; stride[1] = s1; stride[2] = s2;
+    oj_enc_geometry(w, h, 3, hs, vs, bw, bh);
+    for (c = 0; c < 3; c++) {
+        int dwc = c == 0 ? w : (w + hs - 1) / hs, dhc = c == 0 ? h : (h + vs - 1) / vs;
+        int wib = (dwc + 7) / 8, hib = (dhc + 7) / 8;
+        int mh = c == 0 ? hs : 1;
+        const uint16_t* q = c == 0 ? qlum : qchr;
+        for (by = 0; by < hib; by++)
+            for (bx = 0; bx < wib; bx++) {
+                int32_t blk[64];
+                int16_t* o = coef[c] + ((size_t)by * bw[c] + bx) * 64;
+                int i;
+                for (y = 0; y < 8; y++)
+                    for (x = 0; x < 8; x++) {
+                        int sy = by * 8 + y, sx = bx * 8 + x;
+                        if (sy > dhc - 1) sy = dhc - 1;
+                        if (sx > dwc - 1) sx = dwc - 1;
+                        blk[y * 8 + x] = (int32_t)plane[c][(size_t)sy * stride[c] + sx] - 128;
+                    }
+                oj_fdct(blk);
+                for (i = 0; i < 64; i++) {
+                    int32_t qv = (int32_t)q[i] * 8, v = blk[i];
+                    if (v < 0) {
+                        v = -v;
+                        v += qv >> 1;
+                        v = v >= qv ? v / qv : 0;
+                        v = -v;
+                    } else {
+                        v += qv >> 1;
+                        v = v >= qv ? v / qv : 0;
+                    }
+                    o[i] = (int16_t)v;
+                }
+            }
+        for (by = 0; by < hib; by++)
+            for (bx = wib; bx < bw[c]; bx++) {
+                int16_t* o = coef[c] + ((size_t)by * bw[c] + bx) * 64;
+                memset(o, 0, 64 * sizeof(int16_t));
+                o[0] = o[-64];
+            }
+        for (by = hib; by < bh[c]; by++)
+            for (bx = 0; bx < bw[c]; bx++) {
+                int16_t* o = coef[c] + ((size_t)by * bw[c] + bx) * 64;
+                int last_in_mcu = (bx / mh) * mh + mh - 1;
+                memset(o, 0, 64 * sizeof(int16_t));
+                o[0] = coef[c][((size_t)(by - 1) * bw[c] + last_in_mcu) * 64];
+            }
+    }
+    return OJ_OK;
+}
+
 /* ---------------------------------------------------------------- entropy encoder + JFIF writer */
 typedef struct {
     uint8_t* p;

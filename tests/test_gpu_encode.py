@@ -182,3 +182,52 @@ def test_pipelined_submit_wait(enc, torch_mod):
         assert statuses == [0] * 5
         for im, s in zip(batches[k], streams):
             assert s == oracle.encode(im, subs[k], 80 + k), k
+
+
+def _planes_like_libjpeg(rgb, hs, vs):
+    """Y / Cb / Cr planes at component size for dimensions that are multiples of the MCU (no edge padding involved):
+    jccolor.c fixed-point conversion, jcsample.c box filter with the alternating bias."""
+    r, g, b = [rgb[:, :, i].astype(np.int64) for i in range(3)]
+    y = (19595 * r + 38470 * g + 7471 * b + 32768) >> 16
+    cb = (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16
+    cr = (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16
+
+    def down(p):
+        h, w = p.shape
+        if hs == 1 and vs == 1:
+            return p
+        if hs == 2 and vs == 1:
+            bias = np.arange(w // 2) & 1
+            return (p[:, 0::2] + p[:, 1::2] + bias) >> 1
+        bias = 1 + (np.arange(w // 2) & 1)
+        return (p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2] + bias) >> 2
+    return [y.astype(np.uint8), down(cb).astype(np.uint8), down(cr).astype(np.uint8)]
+
+
+@pytest.mark.parametrize("sub,hs,vs", [("420", 2, 2), ("422", 2, 1), ("444", 1, 1)])
+def test_planar_ycbcr_input_goes_into_the_stream_as_it_is(sub, hs, vs):
+    """NVIMGCODEC_SAMPLEFORMAT_P_YUV (reference extensions/nvjpeg/cuda_encoder.cpp:109,362-368 -> nvjpegEncodeYUV): planes that
+    are the components already.  (i) MCU-multiple sizes: fed with the planes libjpeg itself would have made from an RGB picture,
+    the file must be libjpeg-turbo's file for that picture (oracle.encode, pinned by the encode goldens).  (ii) ragged sizes:
+    coefficients equal the oracle's restatement of the same rule (replicate the plane's last column / row) -- parity unpinned,
+    nvJPEG's padding rule is not in the reference."""
+    import torch
+    from nvimagecodec_amd.lowlevel import BatchEncoder
+    enc = BatchEncoder(device=0, num_threads=2)
+    for gpu_huffman in (False, True):
+        enc.gpu_huffman = gpu_huffman
+        rgb = synth_image(160, 96, seed=11)
+        planes = _planes_like_libjpeg(rgb, hs, vs)
+        out = enc.encode([[torch.from_numpy(p).cuda() for p in planes]], sub, 90, "yuv_planar")
+        assert out[0] == oracle.encode(rgb, sub, 90), (sub, gpu_huffman)
+    rng = np.random.default_rng(5)
+    for (w, h) in ((50, 37), (17, 13), (129, 71)):
+        planes = [rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, ((h + vs - 1) // vs, (w + hs - 1) // hs), dtype=np.uint8),
+                  rng.integers(0, 256, ((h + vs - 1) // vs, (w + hs - 1) // hs), dtype=np.uint8)]
+        enc.gpu_huffman = False
+        out = enc.encode([[torch.from_numpy(p).cuda() for p in planes]], sub, 75, "yuv_planar")
+        ref, _ = oracle.forward_planes(planes, w, h, sub, 75)
+        got, _ = oracle.decode_coefficients(out[0])
+        for c in range(3):
+            assert np.array_equal(got[c], ref[c]), (sub, w, h, c)
+    enc.close()
