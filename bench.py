@@ -215,7 +215,10 @@ def config3_sharded(dec, rank, world, dist, host_threads):
     order = [(7 * i + 3) % 10 for i in range(total)]  # fixed pseudo-random draw, identical on every rank
     costs = [sharding.image_cost(s) for s in srcs]
     mine = sharding.shard_indices([costs[k] for k in order], world)[rank]
-    pieces = [mine[i:i + BATCH] for i in range(0, len(mine), BATCH)]
+    # pieces of 256 with the same mix of sizes each (every npieces-th image of the size-sorted queue), so that the three
+    # staging pages of the decoder see similar batches and never have to grow in the middle of the run
+    npieces = max(1, (len(mine) + BATCH - 1) // BATCH)
+    pieces = [mine[k::npieces] for k in range(npieces)]
     batches = [[srcs[order[i]] for i in piece] for piece in pieces]
     ring = {}
 
