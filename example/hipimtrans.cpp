@@ -8,6 +8,7 @@
 //
 //   hipimtrans -i <file|dir> [-o <dir>] [-b batch] [-w warmup batches] [-r repeats] [-q quality] [-s 444|422|420|gray]
 //              [-d device] [-t cpu threads] [-p batches in flight (decode only)] [--skip_encode] [--options "<plugin options>"] [-v]
+//              [--jpeg_encoding baseline_dct|progressive_dct] [--optimized_huffman true|false]
 // -p N > 1 uses what the API offers for throughput: nvimgcodecDecoderDecode returns a future as soon as the batch is scheduled
 // (include/nvimgcodec_abi.h; reference nvimgcodec.h:1455-1459), so the caller submits batch n+1 before it waits for batch n.
 #include <dirent.h>
@@ -54,6 +55,7 @@ struct Params {
     std::string input, output, options;
     int batch = 16, warmup = 1, repeats = 1, quality = 90, device = 0, threads = 0, verbose = 0, in_flight = 1;
     std::string subsampling = "420";
+    bool progressive = false, optimized_huffman = false;  // nvimtrans --jpeg_encoding / --optimized_huffman (command_line_params.h:195-207)
     bool skip_encode = false;
 };
 
@@ -114,10 +116,13 @@ int main(int argc, char** argv)
         else if (a == "-p") p.in_flight = std::max(1, std::min(3, atoi(next())));
         else if (a == "--options") p.options = next();
         else if (a == "--skip_encode") p.skip_encode = true;
+        else if (a == "--jpeg_encoding") p.progressive = std::string(next()) == "progressive_dct";
+        else if (a == "--optimized_huffman") p.optimized_huffman = std::string(next()) == "true";
         else if (a == "-v") p.verbose++;
         else {
             fprintf(stderr, "usage: %s -i <file|dir> [-o dir] [-b batch] [-w warmup] [-r repeats] [-q quality] [-s 444|422|420|gray] [-d device] "
-                            "[-t threads] [--skip_encode] [--options str] [-v]\n", argv[0]);
+                            "[-t threads] [-p batches in flight] [--skip_encode] [--jpeg_encoding baseline_dct|progressive_dct] [--optimized_huffman true|false] "
+                            "[--options str] [-v]\n", argv[0]);
             return EXIT_FAILURE;
         }
     }
@@ -156,7 +161,9 @@ int main(int argc, char** argv)
     if (!p.skip_encode) CHECK_API(nvimgcodecEncoderCreate(instance, &encoder, &ep, p.options.c_str()));
 
     nvimgcodecDecodeParams_t dparams{NVIMGCODEC_STRUCTURE_TYPE_DECODE_PARAMS, sizeof(nvimgcodecDecodeParams_t), nullptr, 1, 0};
-    nvimgcodecJpegEncodeParams_t jparams{NVIMGCODEC_STRUCTURE_TYPE_JPEG_ENCODE_PARAMS, sizeof(nvimgcodecJpegEncodeParams_t), nullptr, 0};
+    nvimgcodecJpegEncodeParams_t jparams{NVIMGCODEC_STRUCTURE_TYPE_JPEG_ENCODE_PARAMS, sizeof(nvimgcodecJpegEncodeParams_t), nullptr, p.optimized_huffman ? 1 : 0};
+    nvimgcodecJpegImageInfo_t jinfo{NVIMGCODEC_STRUCTURE_TYPE_JPEG_IMAGE_INFO, sizeof(nvimgcodecJpegImageInfo_t), nullptr,
+                                    p.progressive ? NVIMGCODEC_JPEG_ENCODING_PROGRESSIVE_DCT_HUFFMAN : NVIMGCODEC_JPEG_ENCODING_BASELINE_DCT};
     nvimgcodecEncodeParams_t eparams{NVIMGCODEC_STRUCTURE_TYPE_ENCODE_PARAMS, sizeof(nvimgcodecEncodeParams_t), &jparams, (float)p.quality, 50.f};
     const nvimgcodecChromaSubsampling_t css = p.subsampling == "444"   ? NVIMGCODEC_SAMPLING_444
                                               : p.subsampling == "422" ? NVIMGCODEC_SAMPLING_422
@@ -349,6 +356,7 @@ int main(int argc, char** argv)
                 nvimgcodecImageInfo_t out_info = infos[i];
                 strcpy(out_info.codec_name, "jpeg");
                 out_info.chroma_subsampling = css;
+                out_info.struct_next = &jinfo;  // nvimtrans main.cpp:138
                 std::string base = current[i].substr(current[i].find_last_of('/') + 1);
                 std::string path = p.output + "/" + base;
                 nvimgcodecCodeStream_t cs = nullptr;

@@ -188,6 +188,9 @@ typedef struct {
                                   already in the stream's sampling: plane c holds ceil(width / hs_c) x ceil(height / vs_c) samples) */
     int32_t restart_interval;  /* MCUs per restart interval, 0 = none */
     int32_t optimized_huffman; /* 0 = Annex-K tables, 1 = per-image optimal tables (two-pass) */
+    int32_t progressive;       /* 0 = baseline sequential (SOF0); 1 = progressive (SOF2): libjpeg's jpeg_simple_progression scan script
+                                  with per-scan optimal tables, what nvimgcodecJpegImageInfo_t::encoding = PROGRESSIVE_DCT_HUFFMAN asks
+                                  for (reference extensions/nvjpeg/cuda_encoder.cpp:339-346) */
 } hipjpegEncodeParams_t;
 
 /* Device stage only: colour conversion + downsampling + FDCT + quantization for the whole batch (asynchronous). */

@@ -32,7 +32,7 @@ class EncodeInput(ctypes.Structure):
 
 
 class EncodeParams(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("quality", "subsampling", "input_format", "restart_interval", "optimized_huffman")]
+    _fields_ = [(n, ctypes.c_int32) for n in ("quality", "subsampling", "input_format", "restart_interval", "optimized_huffman", "progressive")]
 
 
 CSS = {"444": 0, "422": 1, "420": 2, "440": 3, "411": 4, "410": 5, "gray": 6}

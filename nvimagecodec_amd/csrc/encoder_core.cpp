@@ -212,10 +212,10 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
         im.gpu_bitstream = nullptr;
         im.gpu_bitstream_len = 0;
         if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
-        if (im.params.restart_interval == 0 && !im.params.optimized_huffman)
+        if (im.params.restart_interval == 0 && !im.params.optimized_huffman && !im.params.progressive)
             idx.push_back(i);
         else
-            (*todo)[i] = 1;  // restart markers / per-image tables: the host coder
+            (*todo)[i] = 1;  // restart markers / per-image tables / progressive scans: the host coder
     }
     const int ng = (int)idx.size();
     if (ng == 0) return HIPJPEG_STATUS_SUCCESS;
@@ -376,6 +376,7 @@ void EncodeBatch::entropy_stage(int i)
     EntropyEncodeOptions opt;
     opt.restart_interval = im.params.restart_interval;
     opt.optimized_huffman = im.params.optimized_huffman != 0;
+    opt.progressive = im.params.progressive != 0;
     im.bitstream.clear();
     im.gpu_bitstream = nullptr;
     im.gpu_bitstream_len = 0;

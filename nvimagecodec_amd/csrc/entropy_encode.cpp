@@ -333,11 +333,9 @@ void compute_geometry(EncodeGeometry* g)
     }
 }
 
-// Everything in front of the entropy-coded data: SOI .. SOS, in jcmarker.c's order.
-static void write_headers(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const HuffTable& dcl, const HuffTable& acl,
-                          const HuffTable& dcc, const HuffTable& acc, int restart_interval, std::vector<uint8_t>* o)
+// SOI, APP0, DQT.., SOFn (jcmarker.c write_file_header + write_frame_header)
+static void write_frame_header(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], int sof_marker, std::vector<uint8_t>* o)
 {
-    // marker order of jcmarker.c: SOI, APP0, DQT.., SOF0, DHT.., [DRI], SOS
     put16(o, 0xFFD8);
     put16(o, 0xFFE0);
     put16(o, 16);
@@ -349,7 +347,7 @@ static void write_headers(const EncodeGeometry& g, const uint16_t qlum[64], cons
         o->push_back((uint8_t)t);
         for (int i = 0; i < 64; i++) o->push_back((uint8_t)(t ? qchr : qlum)[kZigzagNatural[i]]);
     }
-    put16(o, 0xFFC0);
+    put16(o, sof_marker);
     put16(o, 8 + 3 * g.ncomp);
     o->push_back(8);
     put16(o, g.height);
@@ -360,6 +358,14 @@ static void write_headers(const EncodeGeometry& g, const uint16_t qlum[64], cons
         o->push_back((uint8_t)(c == 0 ? ((g.hs << 4) | g.vs) : 0x11));
         o->push_back((uint8_t)(c == 0 ? 0 : 1));
     }
+}
+
+// Everything in front of the entropy-coded data: SOI .. SOS, in jcmarker.c's order.
+static void write_headers(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const HuffTable& dcl, const HuffTable& acl,
+                          const HuffTable& dcc, const HuffTable& acc, int restart_interval, std::vector<uint8_t>* o)
+{
+    // marker order of jcmarker.c: SOI, APP0, DQT.., SOF0, DHT.., [DRI], SOS
+    write_frame_header(g, qlum, qchr, 0xFFC0, o);
     write_dht(o, 0x00, dcl);
     write_dht(o, 0x10, acl);
     if (g.ncomp == 3) {
@@ -382,6 +388,311 @@ static void write_headers(const EncodeGeometry& g, const uint16_t qlum[64], cons
     o->push_back(63);
     o->push_back(0);
 }
+
+namespace {
+
+// ---- progressive (SOF2) ------------------------------------------------------------------------------------------------
+// libjpeg's progressive Huffman coder (jcphuff.c) over the scan script of jcparam.c jpeg_simple_progression, with the
+// per-scan optimal tables libjpeg forces in progressive mode (jcmaster.c: optimize_coding = TRUE).
+
+struct ScanSpec {
+    int ncomp, comp[3];
+    int ss, se, ah, al;
+};
+
+// jcparam.c jpeg_simple_progression: the 10-scan script for YCbCr, the all-purpose 6-scan script for one component
+std::vector<ScanSpec> simple_progression(int ncomp)
+{
+    std::vector<ScanSpec> v;
+    auto dc = [&](int ah, int al) {
+        ScanSpec s{ncomp, {0, 1, 2}, 0, 0, ah, al};
+        v.push_back(s);
+    };
+    auto ac = [&](int c, int ss, int se, int ah, int al) {
+        ScanSpec s{1, {c, 0, 0}, ss, se, ah, al};
+        v.push_back(s);
+    };
+    if (ncomp == 3) {
+        dc(0, 1);
+        ac(0, 1, 5, 0, 2);
+        ac(2, 1, 63, 0, 1);
+        ac(1, 1, 63, 0, 1);
+        ac(0, 6, 63, 0, 2);
+        ac(0, 1, 63, 2, 1);
+        dc(1, 0);
+        ac(2, 1, 63, 1, 0);
+        ac(1, 1, 63, 1, 0);
+        ac(0, 1, 63, 1, 0);
+    } else {
+        dc(0, 1);
+        ac(0, 1, 5, 0, 2);
+        ac(0, 6, 63, 0, 2);
+        ac(0, 1, 63, 2, 1);
+        dc(1, 0);
+        ac(0, 1, 63, 1, 0);
+    }
+    return v;
+}
+
+// One scan, either counting symbols (bw == null) or emitting them.  State and routine names follow jcphuff.c.
+class ProgressiveScanCoder {
+public:
+    ProgressiveScanCoder(const EncodeGeometry& g, const BlockSource& src, const ScanSpec& sc, int restart_interval, BitWriter* bw,
+                         const HuffTable* tables, long (*counts)[257])
+        : g_(g), src_(src), sc_(sc), bw_(bw), tables_(tables), counts_(counts), interval_(restart_interval), left_(restart_interval)
+    {
+    }
+
+    void run()
+    {
+        if (sc_.ss == 0) {
+            if (sc_.ncomp > 1) {
+                for (int my = 0; my < g_.mcus_y; my++)
+                    for (int mx = 0; mx < g_.mcus_x; mx++) {
+                        next_mcu();
+                        for (int k = 0; k < sc_.ncomp; k++) {
+                            const int c = sc_.comp[k];
+                            const int mh = c == 0 ? g_.hs : 1, mv = c == 0 ? g_.vs : 1;
+                            for (int v = 0; v < mv; v++)
+                                for (int h = 0; h < mh; h++) dc_block(c, mx * mh + h, my * mv + v);
+                        }
+                    }
+            } else {
+                const int c = sc_.comp[0];
+                for (int by = 0; by < g_.real_h[c]; by++)
+                    for (int bx = 0; bx < g_.real_w[c]; bx++) {
+                        next_mcu();
+                        dc_block(c, bx, by);
+                    }
+            }
+        } else {
+            // AC scans hold one component: its real blocks in raster order (jcmaster.c per_scan_setup, non-interleaved)
+            const int c = sc_.comp[0];
+            table_ = c == 0 ? 0 : 1;
+            for (int by = 0; by < g_.real_h[c]; by++)
+                for (int bx = 0; bx < g_.real_w[c]; bx++) {
+                    next_mcu();
+                    const int16_t* zz = src_.block(c, bx, by);
+                    if (sc_.ah == 0)
+                        ac_first(zz);
+                    else
+                        ac_refine(zz);
+                }
+            emit_eobrun();  // finish_pass_phuff
+        }
+        if (bw_) bw_->align();
+    }
+
+private:
+    // jcphuff.c emit_restart, in front of the MCU that starts a new interval
+    void next_mcu()
+    {
+        if (!interval_) return;
+        if (left_ == 0) {
+            emit_eobrun();
+            if (bw_) {
+                bw_->align();
+                bw_->raw(0xFF);
+                bw_->raw((uint8_t)(0xD0 + rst_));
+            }
+            rst_ = (rst_ + 1) & 7;
+            pred_[0] = pred_[1] = pred_[2] = 0;
+            eobrun_ = 0;
+            be_ = 0;
+            left_ = interval_;
+        }
+        left_--;
+    }
+    void emit_symbol(int table, int sym)
+    {
+        if (bw_)
+            bw_->put(tables_[table].code[sym], tables_[table].size[sym]);
+        else
+            counts_[table][sym]++;
+    }
+    void emit_bits(uint32_t v, int n)
+    {
+        if (bw_ && n) bw_->put(v, n);
+    }
+    void emit_buffered_bits(const uint8_t* p, unsigned n)
+    {
+        if (!bw_) return;
+        for (unsigned i = 0; i < n; i++) bw_->put(p[i], 1);
+    }
+    void emit_eobrun()
+    {
+        if (eobrun_ > 0) {
+            int nbits = 0;
+            for (unsigned t = eobrun_; (t >>= 1) != 0;) nbits++;
+            emit_symbol(table_, nbits << 4);
+            if (nbits) emit_bits(eobrun_, nbits);
+            eobrun_ = 0;
+            emit_buffered_bits(corr_, be_);
+            be_ = 0;
+        }
+    }
+    void dc_block(int c, int bx, int by)
+    {
+        const int v = src_.dc_of(c, bx, by);
+        if (sc_.ah != 0) {  // encode_mcu_DC_refine: the next lower bit, no table
+            emit_bits((uint32_t)(v >> sc_.al) & 1u, 1);
+            return;
+        }
+        const int t2 = v >> sc_.al;  // arithmetic shift (IRIGHT_SHIFT)
+        int diff = t2 - pred_[c];
+        pred_[c] = t2;
+        const int a = diff < 0 ? -diff : diff;
+        const int nb = bit_length(a);
+        emit_symbol(c == 0 ? 0 : 1, nb);
+        if (nb) emit_bits((uint32_t)(diff < 0 ? diff - 1 : diff), nb);
+    }
+    void ac_first(const int16_t* zz)
+    {
+        int r = 0;
+        for (int k = sc_.ss; k <= sc_.se; k++) {
+            int t = zz[k], t2;
+            if (t == 0) {
+                r++;
+                continue;
+            }
+            if (t < 0) {
+                t = (-t) >> sc_.al;
+                t2 = ~t;
+            } else {
+                t >>= sc_.al;
+                t2 = t;
+            }
+            if (t == 0) {
+                r++;
+                continue;
+            }
+            if (eobrun_ > 0) emit_eobrun();
+            while (r > 15) {
+                emit_symbol(table_, 0xF0);
+                r -= 16;
+            }
+            const int nb = bit_length(t);
+            emit_symbol(table_, (r << 4) + nb);
+            emit_bits((uint32_t)t2, nb);
+            r = 0;
+        }
+        if (r > 0) {
+            eobrun_++;
+            if (eobrun_ == 0x7FFF) emit_eobrun();
+        }
+    }
+    void ac_refine(const int16_t* zz)
+    {
+        int absv[64], eob = 0;
+        for (int k = sc_.ss; k <= sc_.se; k++) {
+            int t = zz[k];
+            if (t < 0) t = -t;
+            t >>= sc_.al;
+            absv[k] = t;
+            if (t == 1) eob = k;
+        }
+        int r = 0;
+        unsigned br = 0;
+        uint8_t* br_buffer = corr_ + be_;
+        for (int k = sc_.ss; k <= sc_.se; k++) {
+            const int t = absv[k];
+            if (t == 0) {
+                r++;
+                continue;
+            }
+            while (r > 15 && k <= eob) {
+                emit_eobrun();
+                emit_symbol(table_, 0xF0);
+                r -= 16;
+                emit_buffered_bits(br_buffer, br);
+                br_buffer = corr_;
+                br = 0;
+            }
+            if (t > 1) {  // already nonzero: its next bit goes behind the coming symbol
+                br_buffer[br++] = (uint8_t)(t & 1);
+                continue;
+            }
+            emit_eobrun();
+            emit_symbol(table_, (r << 4) + 1);
+            emit_bits(zz[k] < 0 ? 0u : 1u, 1);
+            emit_buffered_bits(br_buffer, br);
+            br_buffer = corr_;
+            br = 0;
+            r = 0;
+        }
+        if (r > 0 || br > 0) {
+            eobrun_++;
+            be_ += br;
+            if (eobrun_ == 0x7FFF || be_ > (kMaxCorrBits - 64 + 1)) emit_eobrun();
+        }
+    }
+
+    static constexpr unsigned kMaxCorrBits = 1000;  // jcphuff.c MAX_CORR_BITS
+    const EncodeGeometry& g_;
+    const BlockSource& src_;
+    const ScanSpec& sc_;
+    BitWriter* bw_;
+    const HuffTable* tables_;
+    long (*counts_)[257];
+    int interval_, left_, rst_ = 0;
+    int pred_[3] = {0, 0, 0};
+    int table_ = 0;
+    unsigned eobrun_ = 0, be_ = 0;
+    uint8_t corr_[kMaxCorrBits];
+};
+
+void encode_progressive(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const int16_t* const coef[3],
+                        int restart_interval, std::vector<uint8_t>* o)
+{
+    bool dri_sent = false;
+    BlockSource src{g, coef};
+    write_frame_header(g, qlum, qchr, 0xFFC2, o);
+    for (const ScanSpec& sc : simple_progression(g.ncomp)) {
+        const bool dc_scan = sc.ss == 0;
+        const bool needs_table = !(dc_scan && sc.ah != 0);
+        HuffTable tables[2];
+        bool used[2] = {false, false};
+        if (needs_table) {
+            long counts[2][257];
+            memset(counts, 0, sizeof counts);
+            ProgressiveScanCoder(g, src, sc, restart_interval, nullptr, nullptr, counts).run();
+            for (int k = 0; k < sc.ncomp; k++) used[sc.comp[k] == 0 ? 0 : 1] = true;
+            for (int t = 0; t < 2; t++)
+                if (used[t]) gen_optimal_table(counts[t], &tables[t]);
+            // jcmarker.c write_scan_header: the tables this scan uses, in component order, each once
+            bool sent[2] = {false, false};
+            for (int k = 0; k < sc.ncomp; k++) {
+                const int t = sc.comp[k] == 0 ? 0 : 1;
+                if (sent[t]) continue;
+                sent[t] = true;
+                write_dht(o, (dc_scan ? 0x00 : 0x10) | t, tables[t]);
+            }
+        }
+        if (restart_interval && !dri_sent) {  // write_scan_header: DRI whenever the interval changes, i.e. once
+            put16(o, 0xFFDD);
+            put16(o, 4);
+            put16(o, restart_interval);
+            dri_sent = true;
+        }
+        put16(o, 0xFFDA);
+        put16(o, 6 + 2 * sc.ncomp);
+        o->push_back((uint8_t)sc.ncomp);
+        for (int k = 0; k < sc.ncomp; k++) {
+            const int c = sc.comp[k], t = c == 0 ? 0 : 1;
+            o->push_back((uint8_t)(c + 1));
+            // only the table a scan uses is named: DC first scans Td, AC scans Ta, DC refinement neither
+            o->push_back((uint8_t)(dc_scan ? (sc.ah == 0 ? t << 4 : 0) : t));
+        }
+        o->push_back((uint8_t)sc.ss);
+        o->push_back((uint8_t)sc.se);
+        o->push_back((uint8_t)((sc.ah << 4) | sc.al));
+        BitWriter bw(o);
+        ProgressiveScanCoder(g, src, sc, restart_interval, &bw, tables, nullptr).run();
+    }
+    put16(o, 0xFFD9);
+}
+
+}  // namespace
 
 void write_standard_headers(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], std::vector<uint8_t>* out)
 {
@@ -415,6 +726,11 @@ void standard_code_tables(StandardCodeTables* t)
 void encode_jfif(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const int16_t* const coef[3],
                  const EntropyEncodeOptions& opt, std::vector<uint8_t>* o)
 {
+    if (opt.progressive) {
+        o->reserve(o->size() + (size_t)g.width * g.height / 2 + 1024);
+        encode_progressive(g, qlum, qchr, coef, opt.restart_interval, o);
+        return;
+    }
     HuffTable dcl, dcc, acl, acc;
     dcl.set(kDcLumBits, kDcVals);
     dcc.set(kDcChrBits, kDcVals);

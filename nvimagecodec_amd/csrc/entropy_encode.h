@@ -1,4 +1,4 @@
-// entropy_encode.h -- host-side baseline Huffman coder + JFIF marker writer for the encode path
+// entropy_encode.h -- host-side baseline and progressive Huffman coder + JFIF marker writer for the encode path
 // (the part of nvjpegEncodeImage / nvjpegEncodeRetrieveBitstream that stays on the CPU; reference call sites
 // extensions/nvjpeg/cuda_encoder.cpp:336-381).  Bitstream conventions follow libjpeg (jcmarker.c / jchuff.c / jccoefct.c)
 // so that, with the Annex-K tables, the output is byte-identical to libjpeg-turbo's for the same coefficients.
@@ -25,6 +25,8 @@ void compute_geometry(EncodeGeometry* g);
 struct EntropyEncodeOptions {
     int restart_interval = 0;     // in MCUs, 0 = none
     bool optimized_huffman = false;  // two-pass optimal tables (jchuff.c jpeg_gen_optimal_table); default = Annex-K tables
+    bool progressive = false;        // SOF2: jcparam.c jpeg_simple_progression's scan script coded as jcphuff.c does, per-scan optimal
+                                     // tables (libjpeg forces them in progressive mode)
 };
 
 // coef[c]: zigzag-ordered int16[64] blocks over the MCU-padded grid; only the real_w x real_h area is read.

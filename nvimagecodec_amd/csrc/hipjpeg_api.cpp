@@ -576,6 +576,7 @@ hipjpegStatus_t hipjpegEncodeFromCoefficientsHost(int32_t width, int32_t height,
     EntropyEncodeOptions opt;
     opt.restart_interval = params->restart_interval;
     opt.optimized_huffman = params->optimized_huffman != 0;
+    opt.progressive = params->progressive != 0;
     std::vector<uint8_t> bytes;
     encode_jfif(g, ql, qc, coef, opt, &bytes);
     *length = bytes.size();

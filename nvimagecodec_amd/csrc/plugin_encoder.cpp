@@ -2,9 +2,9 @@
 //
 // Fills nvimgcodecEncoderDesc_t (ABI: include/nvimgcodec_abi.h; reference include/nvimgcodec.h:1087-1145) the way the
 // reference's nvJPEG CUDA encoder does (extensions/nvjpeg/cuda_encoder.cpp):
-//   * canEncode(): acceptance rules of cuda_encoder.cpp:49-140, minus what this encoder does not produce
-//     (progressive output, P_YUV input) -- those statuses send the sample down the chain
-//   * encode(): quality = int(params->quality) (:336), optimized_huffman from the chained nvimgcodecJpegEncodeParams_t (:348-357),
+//   * canEncode(): acceptance rules of cuda_encoder.cpp:49-140 (baseline and progressive Huffman output, :77-82)
+//   * encode(): quality = int(params->quality) (:336), encoding from the code stream's chained nvimgcodecJpegImageInfo_t (:339-346),
+//     optimized_huffman from the chained nvimgcodecJpegEncodeParams_t (:348-357),
 //     output subsampling from the code stream's image info (:358-361), bitstream delivered through
 //     io_stream->reserve/seek/write/flush (:383-388), exactly one imageReady per sample.
 // Device work for the whole batch is ONE launch (colour + downsample + FDCT + quantize); the Huffman stage runs per sample
@@ -163,8 +163,9 @@ void HipJpegEncoder::single_can_encode(nvimgcodecProcessingStatus_t* st, nvimgco
         *st = NVIMGCODEC_PROCESSING_STATUS_CODEC_UNSUPPORTED;
         return;
     }
-    // baseline sequential output only; progressive requests go to the next encoder in the chain
-    if (ji.encoding != NVIMGCODEC_JPEG_ENCODING_UNKNOWN && ji.encoding != NVIMGCODEC_JPEG_ENCODING_BASELINE_DCT) {
+    // baseline sequential and progressive Huffman output (cuda_encoder.cpp:77-82); anything else goes down the chain
+    if (ji.encoding != NVIMGCODEC_JPEG_ENCODING_UNKNOWN && ji.encoding != NVIMGCODEC_JPEG_ENCODING_BASELINE_DCT &&
+        ji.encoding != NVIMGCODEC_JPEG_ENCODING_PROGRESSIVE_DCT_HUFFMAN) {
         *st = NVIMGCODEC_PROCESSING_STATUS_ENCODING_UNSUPPORTED;
         return;
     }
@@ -277,9 +278,11 @@ nvimgcodecStatus_t HipJpegEncoder::encode(nvimgcodecImageDesc_t** images, nvimgc
         Sample& s = samples_[i];
         s.image = images[i];
         s.code_stream = code_streams[i];
+        nvimgcodecJpegImageInfo_t ji{NVIMGCODEC_STRUCTURE_TYPE_JPEG_IMAGE_INFO, sizeof(nvimgcodecJpegImageInfo_t), nullptr,
+                                     NVIMGCODEC_JPEG_ENCODING_UNKNOWN};
         nvimgcodecImageInfo_t info, out_info;
         init_info(&info);
-        init_info(&out_info);
+        init_info(&out_info, &ji);
         if (s.image->getImageInfo(s.image->instance, &info) != NVIMGCODEC_STATUS_SUCCESS ||
             s.code_stream->getImageInfo(s.code_stream->instance, &out_info) != NVIMGCODEC_STATUS_SUCCESS) {
             s.early = NVIMGCODEC_PROCESSING_STATUS_FAIL;
@@ -314,6 +317,7 @@ nvimgcodecStatus_t HipJpegEncoder::encode(nvimgcodecImageDesc_t** images, nvimgc
         eparams[i].subsampling = css;
         eparams[i].input_format = fmt;
         eparams[i].optimized_huffman = jp ? jp->optimized_huffman : 0;
+        eparams[i].progressive = ji.encoding == NVIMGCODEC_JPEG_ENCODING_PROGRESSIVE_DCT_HUFFMAN;  // cuda_encoder.cpp:339-346
         // our stream must see the producer's pixels (cuda_encoder.cpp:311-312)
         if (gpu_ok && (hipEventRecord(event_, (hipStream_t)info.cuda_stream) != hipSuccess || hipStreamWaitEvent(stream_, event_, 0) != hipSuccess))
             gpu_ok = false;

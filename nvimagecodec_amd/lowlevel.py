@@ -261,16 +261,18 @@ _IN_FORMATS = {"rgb": N.OUTPUT_RGBI, "bgr": N.OUTPUT_BGRI, "rgb_planar": N.OUTPU
                "yuv_planar": N.OUTPUT_YUV_PLANAR}
 
 
-def _enc_params(subsampling, quality, input_format="rgb", restart_interval=0, optimized_huffman=False):
-    return N.EncodeParams(int(quality), N.CSS[subsampling], _IN_FORMATS[input_format], int(restart_interval), int(bool(optimized_huffman)))
+def _enc_params(subsampling, quality, input_format="rgb", restart_interval=0, optimized_huffman=False, progressive=False):
+    return N.EncodeParams(int(quality), N.CSS[subsampling], _IN_FORMATS[input_format], int(restart_interval), int(bool(optimized_huffman)),
+                          int(bool(progressive)))
 
 
-def encode_from_coefficients_host(width, height, coefs_natural, subsampling="420", quality=90, restart_interval=0, optimized_huffman=False):
+def encode_from_coefficients_host(width, height, coefs_natural, subsampling="420", quality=90, restart_interval=0, optimized_huffman=False,
+                                  progressive=False):
     """Host-only entropy coding (no GPU).  coefs_natural: per component int16 [blocks_h, blocks_w, 64] in natural order over the
     MCU-padded grid (what oracle.forward returns); converted to the zigzag layout the C-ABI takes."""
     zz = [np.ascontiguousarray(c[:, :, _ZIGZAG]) for c in coefs_natural]
     ptrs = (ctypes.c_void_p * 3)(*([z.ctypes.data for z in zz] + [None] * (3 - len(zz))))
-    p = _enc_params(subsampling, quality, "rgb", restart_interval, optimized_huffman)
+    p = _enc_params(subsampling, quality, "rgb", restart_interval, optimized_huffman, progressive)
     cap = width * height * 3 + 65536
     out = np.zeros(cap, dtype=np.uint8)
     n = ctypes.c_size_t()
@@ -311,7 +313,7 @@ class BatchEncoder:
         s = stream if stream is not None else self._torch.cuda.current_stream(self.device)
         return ctypes.c_void_p(s.cuda_stream)
 
-    def _marshal(self, images, subsampling, quality, input_format, restart_interval, optimized_huffman):
+    def _marshal(self, images, subsampling, quality, input_format, restart_interval, optimized_huffman, progressive=False):
         n = len(images)
         I = (N.EncodeInput * n)()
         P = (N.EncodeParams * n)()
@@ -338,13 +340,14 @@ class BatchEncoder:
                     I[i].plane[p] = t[p].data_ptr()
                     I[i].pitch[p] = t.stride(1)
             I[i].width, I[i].height = w, h
-            P[i] = _enc_params(subs[i], quals[i], fmt, restart_interval, optimized_huffman)
+            P[i] = _enc_params(subs[i], quals[i], fmt, restart_interval, optimized_huffman, progressive)
         self._keep = (images, I, P)
         self._n = n
         return I, P
 
-    def device_stage(self, images, subsampling="420", quality=90, input_format="rgb", restart_interval=0, optimized_huffman=False, stream=None):
-        I, P = self._marshal(images, subsampling, quality, input_format, restart_interval, optimized_huffman)
+    def device_stage(self, images, subsampling="420", quality=90, input_format="rgb", restart_interval=0, optimized_huffman=False, stream=None,
+                     progressive=False):
+        I, P = self._marshal(images, subsampling, quality, input_format, restart_interval, optimized_huffman, progressive)
         st_arr = (ctypes.c_int * self._n)()
         st = N.load().hipjpegEncodeBatchDevice(self._h, I, P, self._n, st_arr, self._stream_ptr(stream))
         if st:
@@ -354,10 +357,10 @@ class BatchEncoder:
     # -- pipelined: submit() queues forward kernel + entropy stage + copy of the files and returns; wait() completes the
     #    oldest submitted batch and returns (statuses, bitstreams).  At most three batches in flight.
     def submit(self, images, subsampling="420", quality=90, input_format="rgb", restart_interval=0, optimized_huffman=False, stream=None,
-               gpu_huffman=None):
+               gpu_huffman=None, progressive=False):
         if gpu_huffman is None:
             gpu_huffman = self.gpu_huffman
-        I, P = self._marshal(images, subsampling, quality, input_format, restart_interval, optimized_huffman)
+        I, P = self._marshal(images, subsampling, quality, input_format, restart_interval, optimized_huffman, progressive)
         st = N.load().hipjpegEncodeBatchSubmit(self._h, I, P, self._n, N.FLAG_GPU_HUFFMAN if gpu_huffman else 0, self._stream_ptr(stream))
         if st:
             raise N.HipJpegError(st, "hipjpegEncodeBatchSubmit")
@@ -414,8 +417,9 @@ class BatchEncoder:
             c += 1
         return res
 
-    def encode(self, images, subsampling="420", quality=90, input_format="rgb", restart_interval=0, optimized_huffman=False, stream=None):
-        st = self.device_stage(images, subsampling, quality, input_format, restart_interval, optimized_huffman, stream)
+    def encode(self, images, subsampling="420", quality=90, input_format="rgb", restart_interval=0, optimized_huffman=False, stream=None,
+               progressive=False):
+        st = self.device_stage(images, subsampling, quality, input_format, restart_interval, optimized_huffman, stream, progressive)
         st = self.host_stage()
         for i, s in enumerate(st):
             if s:

@@ -166,6 +166,49 @@ def test_optimized_huffman_and_bad_params(enc, torch_mod):
     assert st == [3]  # UNSUPPORTED
 
 
+def test_progressive_output_equals_libjpeg_turbo_files(enc, torch_mod):
+    """progressive=1 (nvimgcodecJpegImageInfo_t::encoding = PROGRESSIVE_DCT_HUFFMAN through the plugin): device stage as ever, then
+    the host coder's SOF2 writer -- whole files byte-identical to libjpeg-turbo's progressive output (47 vectors, colour and
+    gray, restart intervals), mixed with baseline images in one batch; then a 1080p picture decoded again on the GPU."""
+    torch = torch_mod
+    with open(os.path.join(GOLDEN, "manifest_encode_prog.json")) as f:
+        entries = json.load(f)["encode_progressive"]
+
+    def load(e):
+        rgb = np.fromfile(os.path.join(GOLDEN, e["input"]), dtype=np.uint8).reshape(e["height"], e["width"], 3)
+        with open(os.path.join(GOLDEN, "encode_prog", e["name"] + ".jpg"), "rb") as f:
+            return rgb, f.read()
+
+    for rst in sorted({e["restart"] for e in entries}):
+        for gray in (False, True):
+            cases = [(e, *load(e)) for e in entries if e["restart"] == rst and (e["sub"] == "gray") == gray]
+            if not cases:
+                continue
+            feed = [torch.from_numpy(np.ascontiguousarray(c[1][:, :, 0] if gray else c[1])).cuda() for c in cases]
+            out = enc.encode(feed, subsampling=[c[0]["sub"] for c in cases], quality=[c[0]["quality"] for c in cases],
+                             input_format="gray" if gray else "rgb", restart_interval=rst, progressive=True)
+            for (e, rgb, jpeg), s in zip(cases, out):
+                assert s == jpeg, e["name"]
+    from nvimagecodec_amd.lowlevel import BatchDecoder
+    im = synth_image(1920, 1080, seed=77)
+    prog = enc.encode([torch.from_numpy(im).cuda()], "420", 90, progressive=True)[0]
+    base = oracle.encode(im, "420", 90)
+    assert b"\xff\xc2" in prog[:700] and len(prog) < len(base)
+    dec = BatchDecoder(0, 4)
+    outs, st = dec.decode([prog])
+    torch.cuda.synchronize()
+    assert list(st) == [0] and np.array_equal(outs[0].cpu().numpy(), oracle.decode(base))
+    dec.close()
+    try:
+        import io
+        from PIL import Image
+    except ImportError:
+        return
+    b = io.BytesIO()
+    Image.fromarray(im).save(b, "JPEG", quality=90, subsampling=2, progressive=True)
+    assert prog == b.getvalue()
+
+
 def test_pipelined_submit_wait(enc, torch_mod):
     """hipjpegEncodeBatchSubmit / Wait: two batches in flight, results identical to the one-shot call, in submission order."""
     torch = torch_mod

@@ -47,3 +47,23 @@ def test_decode_only_mode_and_a_bad_file(tmp_path):
     assert p.returncode != 0      # the parser refuses b.jpg: the tool stops like the reference's CHECK_NVIMGCODEC
     p = subprocess.run([TOOL, "-i", str(src / "a.jpg"), "-b", "4", "-r", "8", "-w", "1"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "Total images: 8 (failed: 0)" in p.stdout and "Avg decoding speed" in p.stdout
+
+
+def test_progressive_and_optimized_output(tmp_path):
+    """--jpeg_encoding progressive_dct / --optimized_huffman true (nvimtrans command_line_params.h:195-207): the files hold the
+    coefficients of the plain baseline transcode; the progressive one is an SOF2 file."""
+    src = tmp_path / "in"
+    src.mkdir()
+    j = oracle.encode(synth_image(400, 300, seed=9), "444", 92)
+    (src / "x.jpg").write_bytes(j)
+    want = oracle.decode_coefficients(oracle.encode(oracle.decode(j), "420", 80))[0]
+    for extra, marker in ((["--jpeg_encoding", "progressive_dct"], b"\xff\xc2"), (["--optimized_huffman", "true"], b"\xff\xc0")):
+        dst = tmp_path / ("out" + extra[1])
+        dst.mkdir()
+        p = subprocess.run([TOOL, "-i", str(src), "-o", str(dst), "-b", "1", "-w", "0", "-q", "80", "-s", "420"] + extra, capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        out = (dst / "x.jpg").read_bytes()
+        assert marker in out[:700]
+        got = oracle.decode_coefficients(out)[0]
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))

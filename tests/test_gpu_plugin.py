@@ -319,9 +319,13 @@ def test_python_encoder_mirror_through_plugin(torch_mod):
         ref = oracle.encode(imgs[2], "420", 90)
         assert len(bo) < len(ref)
         assert all(np.array_equal(a, c) for a, c in zip(oracle.decode_coefficients(bo)[0], oracle.decode_coefficients(ref)[0]))
-        # progressive output is not produced by this encoder: no other encoder registered -> None
-        bp = enc.encode(api.as_image(dev[0]), "jpeg", api.EncodeParams(quality=90, jpeg_encode_params=api.JpegEncodeParams(progressive=True)))
-        assert bp is None
+        # progressive output (nvimgcodecJpegImageInfo_t::encoding = PROGRESSIVE_DCT_HUFFMAN, cuda_encoder.cpp:339-346): an SOF2 file with
+        # the coefficients of the baseline one; byte parity with libjpeg-turbo is in test_gpu_encode.py
+        bp = enc.encode(api.as_image(dev[0]), "jpeg", api.EncodeParams(quality=90, chroma_subsampling=api.ChromaSubsampling.CSS_420,
+                                                                       jpeg_encode_params=api.JpegEncodeParams(progressive=True)))
+        assert bp is not None and b"\xff\xc2" in bp[:700] and b"\xff\xc0" not in bp[:700]
+        assert all(np.array_equal(a, c) for a, c in zip(oracle.decode_coefficients(bp)[0],
+                                                        oracle.decode_coefficients(oracle.encode(imgs[0], "420", 90))[0]))
 
 
 def test_transcode_roundtrip_through_both_plugins(torch_mod, tmp_path):
