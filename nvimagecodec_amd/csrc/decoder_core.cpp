@@ -520,7 +520,8 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     work_block_pos_ = align_up(work_dc_diff_ + huff_blocks_total * 2, 256);
     work_drops_ = align_up(work_block_pos_ + huff_blockpos_total * 4, 256);
     work_prog_pos_ = align_up(work_drops_ + huff_chunks_total * 4, 256);
-    work_streams_ = align_up(work_prog_pos_ + prog_pos_total * 4, 256);
+    work_group_sums_ = align_up(work_prog_pos_ + prog_pos_total * 4, 256);  // per block-pass workgroup: DC difference sums of its MCUs
+    work_streams_ = align_up(work_group_sums_ + max_huff_wunits_ * 16, 256);
     if ((ng || prog_scan_total_) && (st = work_.reserve(work_streams_ + huff_stream_total + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     huff_images_.assign(ng + prog_scan_total_, HuffImage());
     prog_images_.assign(prog_to_image_.size(), ProgImage());
@@ -751,7 +752,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         h.first_subseq = first_subseq;
         first_subseq += h.num_subseq;
         for (uint32_t j = 0; j < h.num_subseq; j += kHuffOwn) huff_units_.push_back(HuffUnit{(uint32_t)g, j});
-        for (int c = 0; c < im.frame.ncomp; c++) huff_dc_units_.push_back(HuffUnit{(uint32_t)g, (uint32_t)c});
+        if (h.restart_interval)  // the predictor starts over inside the image: the per-component scan (everything else: per MCU group)
+            for (int c = 0; c < im.frame.ncomp; c++) huff_dc_units_.push_back(HuffUnit{(uint32_t)g, (uint32_t)c});
         huff_list_.push_back((uint32_t)g);
         stream_bytes_total_ += im.stream_bytes;
     }
@@ -900,6 +902,7 @@ DecodeBatch::EntropyLaunch DecodeBatch::entropy_launch_args()
     L.dlist = reinterpret_cast<const uint32_t*>(device_.data() + huff_list_offset_);
     L.states = reinterpret_cast<unsigned long long*>(work_.data());
     L.first_block = reinterpret_cast<uint32_t*>(work_.data() + work_first_block_);
+    L.group_sums = reinterpret_cast<int32_t*>(work_.data() + work_group_sums_);
     L.changed = reinterpret_cast<unsigned int*>(work_.data() + work_changed_);
     L.incoming = reinterpret_cast<unsigned long long*>(work_.data() + work_incoming_);
     L.pool_bytes = (unsigned)align_up(max_pool_words_ * 2, 256);
@@ -912,8 +915,9 @@ DecodeBatch::EntropyLaunch DecodeBatch::entropy_launch_args()
 bool DecodeBatch::entropy_write_passes(const EntropyLaunch& L, void* stream)
 {
     return launch_huff_scan(L.dimg, L.dlist, (int)huff_list_.size(), L.states, L.first_block, stream) == 0 &&
-           launch_huff_write(L.dimg, L.dunits, L.nunits, L.dwunits, (int)huff_wunits_.size(), L.states, L.first_block, L.pool_bytes, stream) == 0 &&
-           launch_huff_dc(L.dimg, L.ddc, (int)huff_dc_units_.size(), stream) == 0;
+           launch_huff_write(L.dimg, L.dunits, L.nunits, L.dwunits, (int)huff_wunits_.size(), L.states, L.first_block, L.group_sums, L.pool_bytes,
+                             stream) == 0 &&
+           launch_huff_dc(L.dimg, L.ddc, (int)huff_dc_units_.size(), L.dwunits, (int)huff_wunits_.size(), L.group_sums, stream) == 0;
 }
 
 hipjpegStatus_t DecodeBatch::wait_done()

@@ -154,6 +154,7 @@ private:
         const uint32_t* dlist;
         unsigned long long *states, *incoming;
         uint32_t* first_block;
+        int32_t* group_sums;
         unsigned int *changed, *host_changed;
         HuffImage* himg;
         unsigned pool_bytes;
@@ -174,7 +175,7 @@ private:
     std::vector<int> huff_to_image_;
     size_t huff_desc_offset_ = 0, huff_units_offset_ = 0, huff_dc_units_offset_ = 0, huff_list_offset_ = 0, h2d_bytes_ = 0;
     size_t gpu_coef_begin_ = 0, gpu_coef_bytes_ = 0, total_subseq_ = 0, max_huff_units_ = 0, max_pool_words_ = 0;
-    size_t work_first_block_ = 0, work_changed_ = 0, work_incoming_ = 0, work_tail_ = 0, work_dc_diff_ = 0, work_block_pos_ = 0, work_drops_ = 0, work_streams_ = 0;
+    size_t work_first_block_ = 0, work_changed_ = 0, work_incoming_ = 0, work_tail_ = 0, work_dc_diff_ = 0, work_block_pos_ = 0, work_drops_ = 0, work_streams_ = 0, work_group_sums_ = 0;
     size_t huff_chunk_units_offset_ = 0, huff_wunits_offset_ = 0, max_huff_wunits_ = 0;
     std::vector<TransformImage> xform_desc_;
     std::vector<WorkUnit> xform_units_;

@@ -691,23 +691,31 @@ __global__ __launch_bounds__(kSyncThreads) void huff_pos_kernel(HuffImage* __res
 }
 
 // ---- write pass, step 2: one lane per block -----------------------------------------------------------------------------------
-// 256 consecutive blocks (scan order) of one image per workgroup.  The bitstream span they cover is staged in LDS (the
-// blocks of a 1080p q90 image average ~80 bits; a span that does not fit is read from memory instead), every lane decodes
+// kHuffMcusPerWg consecutive MCUs (scan order) of one image per workgroup, 256 blocks per round.  Every lane decodes
 // its block into a 128-byte LDS buffer, and the finished blocks leave as whole 128-byte lines, eight lanes per block --
 // each line written once, no memset, no partial-line traffic.  Lanes idle once their block is done: chroma blocks are
 // short, luma blocks long; the wave runs as long as its longest block.
 constexpr int kBThreads = kHuffBlocksPerWg;
-constexpr int kBStreamWords = 4096;
+// Words of the bitstream a workgroup may stage in LDS.  0 (shipped): the lanes read the stream through the vector cache instead
+// -- a workgroup's span is ~7 KB and every word is needed by one or two neighbouring lanes, the prefetch in the bit reader covers
+// the longer latency, and without the 16 KB stage three workgroups fit a CU instead of two (A/B on 256 x 1080p: 771 us against
+// 959 us with 4096 words staged, 971 us with 2048).
+#ifndef HJ_BLOCK_STREAM_WORDS
+#define HJ_BLOCK_STREAM_WORDS 0
+#endif
+constexpr int kBStreamWords = HJ_BLOCK_STREAM_WORDS;
 constexpr int kBlockBufBytes = 144;  // 128 + 16: 16-byte aligned buffers whose starts are spread over the banks
 
 struct BlockShared {
-    uint32_t stream[kBStreamWords];
+    uint32_t stream[kBStreamWords > 0 ? kBStreamWords : 1];
     __attribute__((aligned(16))) uint8_t blocks[kBThreads * kBlockBufBytes];
     int16_t* dst[kBThreads];
     KSlot kslot[10];
     uint32_t tsel[10];
     uint32_t zz[16];  // zigzag permutation, 4 entries per word
     uint32_t span[2]; // first staged word, number of staged words (0: the span does not fit, read from memory)
+    int32_t dc_sum[4];  // per component: sum of the DC differences of the workgroup's blocks
+    uint32_t kcomp[10]; // component of MCU position k
 };
 
 struct BlockEnv {
@@ -744,7 +752,8 @@ struct BlockEnv {
     __device__ __forceinline__ void put(int index, int value) const { *(HJ_LDS int16_t*)(uintptr_t)(buf + index * 2) = (int16_t)value; }
 };
 
-__global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units)
+__global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+                                                                int32_t* __restrict__ group_sums)
 {
     __shared__ BlockShared sh;
     extern __shared__ uint16_t dyn_pool[];
@@ -755,8 +764,13 @@ __global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __res
     const uint32_t bpm = geom.blocks_per_mcu;
     const uint32_t nblocks = min(im.total_blocks, im.decoded_blocks);  // a truncated stream: the scan kernel has flagged it
     const uint32_t b_first = u.first * bpm;
-    if (b_first >= nblocks) return;
     const int t = threadIdx.x;
+    if (b_first >= nblocks) {
+        if (t < 4) group_sums[(size_t)blockIdx.x * 4 + t] = 0;
+        return;
+    }
+    if (t < 4) sh.dc_sum[t] = 0;
+    if (t >= 32 && t < 42) sh.kcomp[t - 32] = im.k[t - 32].comp & 3;
     const uint32_t mcus = min((uint32_t)kHuffMcusPerWg, geom.mcus_x * geom.mcus_y - u.first);
     const uint32_t items = mcus * bpm;
     if (t == 0) {
@@ -765,7 +779,7 @@ __global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __res
         const uint32_t end_bit = b_end < nblocks ? im.block_pos[b_end] : geom.total_bits;
         const uint32_t w_lo = im.block_pos[b_first] >> 5, w_hi = (end_bit >> 5) + kStagedExtra;
         sh.span[0] = w_lo;
-        sh.span[1] = (w_hi - w_lo <= (uint32_t)kBStreamWords) ? w_hi - w_lo : 0u;
+        sh.span[1] = (kBStreamWords > 0 && w_hi - w_lo <= (uint32_t)kBStreamWords) ? w_hi - w_lo : 0u;
     }
     stage_pool<kBThreads>(pool, im);
     stage_constants(sh.tsel, sh.kslot, sh.zz, im, true);
@@ -812,6 +826,7 @@ __global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __res
                     err = 1;
                 const int dc = decode_block(geom, env, bpos, (int)k, &err);
                 ((HJ_GLOBAL int16_t*)geom.dc_diff)[b] = (int16_t)dc;
+                atomicAdd(&sh.dc_sum[sh.kcomp[k]], (int)(int16_t)dc);
             }
         }
         sh.dst[t] = dst;
@@ -833,9 +848,70 @@ __global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __res
         }
     }
     if (err) im.status = 1;  // benign race: every writer stores the same value
+    __syncthreads();
+    if (t < 4) group_sums[(size_t)blockIdx.x * 4 + t] = sh.dc_sum[t];
 }
 
-// One workgroup per (image, component): integrate the DC differences in MCU order; DC values go to the component's compact
+// ---- DC differences -> DC values ------------------------------------------------------------------------------------------
+// Images without restart intervals: one workgroup per block-pass unit (kHuffMcusPerWg MCUs).  The predictor value a group
+// starts from is the sum of the group sums in front of it (the block pass left them: a few dozen numbers), so every group
+// integrates its own MCUs without waiting for anybody; wave c takes component c and scans its entries 64 at a time.
+__global__ __launch_bounds__(kThreads) void huff_dc_group_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+                                                                 const int32_t* __restrict__ group_sums)
+{
+    __shared__ int16_t s_diff[kHuffMcusPerWg * 10];
+    __shared__ int s_base[4];
+    const HuffUnit u = units[blockIdx.x];  // first = first MCU of the group
+    const HuffImage& im = images[u.image];
+    if (im.restart_interval != 0) return;  // uniform: huff_dc_kernel takes those
+    const int t = threadIdx.x;
+    const uint32_t bpm = im.blocks_per_mcu;
+    const uint32_t total_mcus = im.mcus_x * im.mcus_y;
+    const uint32_t mcus = min((uint32_t)kHuffMcusPerWg, total_mcus - u.first);
+    const uint32_t n = mcus * bpm;
+    const uint32_t g = u.first / kHuffMcusPerWg;  // groups in front of this one: units blockIdx.x - g .. blockIdx.x - 1
+    if (t < 4) s_base[t] = 0;
+    {
+        const HJ_GLOBAL int16_t* diff = (const HJ_GLOBAL int16_t*)im.dc_diff + (size_t)u.first * bpm;
+        for (uint32_t i = t; i < n; i += kThreads) s_diff[i] = diff[i];
+    }
+    __syncthreads();
+    {
+        const HJ_GLOBAL int32_t* sums = (const HJ_GLOBAL int32_t*)group_sums + (size_t)(blockIdx.x - g) * 4;
+        int part = 0;
+        for (uint32_t i = t; i < g * 4; i += kThreads) part += sums[i];  // i & 3 = t & 3: a lane stays with one component
+        if (part != 0) atomicAdd(&s_base[t & 3], part);
+    }
+    __syncthreads();
+    const int c = t >> 6, lane = t & 63;
+    if (c >= (int)im.ncomp) return;
+    const uint32_t h = im.comp_h[c], v = im.comp_v[c], bpc = h * v, k0 = im.comp_k0[c];
+    const uint32_t bw = im.blocks_w[c], mcus_x = im.mcus_x;
+    HJ_GLOBAL int16_t* plane = (HJ_GLOBAL int16_t*)im.dc_plane[c];
+    int run = s_base[c];
+    const uint32_t nc = mcus * bpc;
+    for (uint32_t s0 = 0; s0 < nc; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const bool live = s < nc;
+        const uint32_t m = s / bpc, jj = s - m * bpc;
+        int x = live ? (int)s_diff[m * bpm + k0 + jj] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (live) {
+            const uint32_t mcu = u.first + m;
+            const uint32_t my = mcu / mcus_x, mx = mcu - my * mcus_x;
+            const uint32_t dy = jj / h, dx = jj - dy * h;
+            plane[(my * v + dy) * bw + (mx * h + dx)] = (int16_t)(run + x);
+        }
+        run += __shfl(x, 63, 64);
+    }
+}
+
+// Images with restart intervals (the predictor starts over inside the image): one workgroup per (image, component)
+// integrates the DC differences in MCU order; DC values go to the component's compact
 // DC plane (raster block order), which the IDCT kernels read beside the coefficient blocks.
 __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units)
 {
@@ -952,18 +1028,20 @@ int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages,
 }
 
 int launch_huff_write(HuffImage* images, const HuffUnit* sync_units, int nsync_units, const HuffUnit* block_units, int nblock_units,
-                      const unsigned long long* states, const uint32_t* first_block, unsigned pool_bytes, void* stream)
+                      const unsigned long long* states, const uint32_t* first_block, int32_t* group_sums, unsigned pool_bytes, void* stream)
 {
     if (nsync_units <= 0) return 0;
     hipLaunchKernelGGL(huff_pos_kernel, dim3(nsync_units), dim3(kSyncThreads), pool_bytes, (hipStream_t)stream, images, sync_units, states, first_block);
-    if (nblock_units > 0) hipLaunchKernelGGL(huff_blocks_kernel, dim3(nblock_units), dim3(kBThreads), pool_bytes, (hipStream_t)stream, images, block_units);
+    if (nblock_units > 0) hipLaunchKernelGGL(huff_blocks_kernel, dim3(nblock_units), dim3(kBThreads), pool_bytes, (hipStream_t)stream, images, block_units, group_sums);
     return (int)hipGetLastError();
 }
 
-int launch_huff_dc(const HuffImage* images, const HuffUnit* units, int nunits, void* stream)
+int launch_huff_dc(const HuffImage* images, const HuffUnit* rst_units, int nrst_units, const HuffUnit* block_units, int nblock_units,
+                   const int32_t* group_sums, void* stream)
 {
-    if (nunits <= 0) return 0;
-    hipLaunchKernelGGL(huff_dc_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    if (nblock_units > 0)
+        hipLaunchKernelGGL(huff_dc_group_kernel, dim3(nblock_units), dim3(kThreads), 0, (hipStream_t)stream, images, block_units, group_sums);
+    if (nrst_units > 0) hipLaunchKernelGGL(huff_dc_kernel, dim3(nrst_units), dim3(kThreads), 0, (hipStream_t)stream, images, rst_units);
     return (int)hipGetLastError();
 }
 

@@ -159,34 +159,45 @@ HJ_HD HuffGeom make_geom(const HuffImage& im)
     return g;
 }
 
-// MSB-first bit reader over 32-bit words fetched through Env::word(index): `hi` always holds the next 32 bits of the stream
-// (a symbol is at most 16 code + 15 value bits), `lo` the bits behind them.  The word that may be needed next is requested
-// at the top of every step, before the table lookup, so that its latency overlaps the lookup instead of preceding it.
+// MSB-first bit reader over 32-bit words fetched through Env::word(index).  The reader holds the 64 bits w0:w1 around the
+// current position and a shift s: `hi` -- the next 32 bits of the stream (a symbol is at most 16 code + 15 value bits) -- is
+// bits [s+31 : s] of w0:w1, one v_alignbit_b32.  Consuming c bits is s -= c; when s goes negative the pair moves on by one
+// word.  The word that may be needed next is requested at the top of every step, before the table lookup, so that its latency
+// overlaps the lookup instead of preceding it.
+HJ_HD uint32_t funnel_shift_right(uint32_t high, uint32_t low, uint32_t s)  // bits [s+31 : s] of high:low, 0 <= s <= 31
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(high, low, s);
+#else
+    return (uint32_t)((((uint64_t)high << 32) | low) >> (s & 31));
+#endif
+}
 struct BitReader {
-    uint32_t hi, lo;
-    uint32_t nbits;  // valid bits in hi:lo, 32 <= nbits <= 64 between steps
-    uint32_t next;   // index of the next word to fetch
+    uint32_t hi;      // the next 32 bits of the stream
+    uint32_t w0, w1;  // the words hi is cut from
+    uint32_t s;       // 0 <= s <= 31
+    uint32_t next;    // index of the word behind w1
     template <class Env>
     HJ_HD void start(const Env& env, uint32_t pos)
     {
-        const uint32_t i = pos >> 5, sh = pos & 31;
-        const uint32_t w0 = env.word(i), w1 = env.word(i + 1);
-        hi = (w0 << sh) | ((w1 >> 1) >> (sh ^ 31));
-        lo = w1 << sh;
-        nbits = 64 - sh;
-        next = i + 2;
+        const uint32_t i = pos >> 5, b = pos & 31;
+        const uint32_t i1 = i + (b != 0 ? 1u : 0u);  // on a word boundary the window is w1 alone (s = 0)
+        w0 = env.word(i);
+        w1 = env.word(i1);
+        s = (0u - b) & 31u;
+        next = i1 + 1;
+        hi = funnel_shift_right(w0, w1, s);
     }
-    // drops c (1..31) bits and, when fewer than 32 remain, appends `fetched` (= word `next`)
+    // drops c (1..31) bits; `fetched` = word `next`, taken when the position leaves w0
     HJ_HD void consume(uint32_t c, uint32_t fetched)
     {
-        hi = (hi << c) | (lo >> (32 - c));
-        lo <<= c;
-        nbits -= c;
-        const bool need = nbits < 32;  // then 1 <= nbits <= 31 and lo is empty
-        hi |= need ? fetched >> (nbits & 31) : 0u;
-        lo = need ? fetched << ((32 - nbits) & 31) : lo;
-        nbits += need ? 32u : 0u;
+        const uint32_t t = s - c;
+        const bool need = (int32_t)t < 0;
+        w0 = need ? w1 : w0;
+        w1 = need ? fetched : w1;
         next += need ? 1u : 0u;
+        s = t & 31u;
+        hi = funnel_shift_right(w0, w1, s);
     }
 };
 
@@ -337,11 +348,9 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
         }
         if (fault && rc.index != met && block != (met + 1) * im.interval_blocks) *fault = 1;
     }
+    // a block is recorded where its predecessor ends (inside the rare end-of-block branch), the one in progress at `begin` here
+    if (fresh && pos < end) rec(block, pos);
     while (pos < end) {
-        if (fresh) {
-            rec(block, pos);
-            fresh = false;
-        }
         const uint32_t fetched = env.word(br.next);
         uint32_t e = env.lookup1(tcur, br.hi);
         const uint32_t pr = env.lookup_pair(tcur, br.hi);
@@ -358,7 +367,6 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
             if (++k == bpm) k = 0;
             tsel = env.tables(k);
             tcur = tsel & 0xFFFFu;
-            fresh = true;
             if (RST && k == 0) {
                 const uint32_t met = rc.index;
                 if (rc.normalise(env, br.hi, &pos, &z, &k, fault)) {
@@ -368,6 +376,7 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
                 }
                 if (fault && rc.index != met && block != (met + 1) * im.interval_blocks) *fault = 1;
             }
+            if (pos < end) rec(block, pos);
         }
     }
 }

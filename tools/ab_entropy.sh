@@ -1,8 +1,9 @@
 #!/bin/bash
-# usage (on the GPU box): tools/ab_entropy.sh <other .so>   -- per-kernel times of the GPU entropy stage, shipped build vs another build
+# usage (on the GPU box): tools/ab_entropy.sh <other .so> ...   -- per-kernel times of the GPU entropy stage, shipped build vs other builds
+# (tools/build_variant.sh makes them)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for lib in "" "$1"; do
+for lib in "" "$@"; do
   export HIPJPEG_LIB_PATH=$lib
   [ -z "$lib" ] && unset HIPJPEG_LIB_PATH
   echo "== ${lib:-shipped build}"
