@@ -170,7 +170,7 @@ __device__ __forceinline__ void stage_constants(uint32_t* tsel, KSlot* kslot, ui
             kslot[t] = s;
         }
     }
-    if (t >= 64 && t < 80) {
+    if (zzw && t >= 64 && t < 80) {
         constexpr uint8_t zz[64] = HJ_ZIGZAG_DEVICE_TABLE;
         const int i = (t - 64) * 4;
         zzw[t - 64] = (uint32_t)zz[i] | ((uint32_t)zz[i + 1] << 8) | ((uint32_t)zz[i + 2] << 16) | ((uint32_t)zz[i + 3] << 24);
@@ -482,20 +482,30 @@ __global__ __launch_bounds__(kSyncThreads) void huff_sync_kernel(const HuffImage
 }
 
 // ---- tail corrections ---------------------------------------------------------------------------------------------------
-// After pass 0 and the first correction round most subsequences are settled; what remains are chains: a decoder that has
+// After pass 0 and the first correction rounds most subsequences are settled; what remains are chains: a decoder that has
 // not yet found the MCU phase hands a wrong end state to its successor, which must be decoded again, and so on for a few
-// thousand bits.  Each link is one full single-lane decode, strictly after the previous one.  This kernel walks those chains
-// with ONE wave per group of 255 subsequences and little LDS (each lane stages just the row it is decoding), so that seven
-// groups per CU make progress at once instead of three workgroups of the big kernel idling on their barriers.
-constexpr int kTailThreads = 64;
+// thousand bits (per round a third of the subsequences decoded still change their end state: 8-10 rounds for a 1080p picture).
+// Each link is one full single-lane decode, strictly after the previous one, so the kernel's time is the longest chain -- IF
+// every group is resident.  One WAVE per group of 255 subsequences; kTailWaves waves share a workgroup and with it the lookup
+// tables in LDS; a wave has kTailSlots row buffers (a lane stages the row it is about to decode: reading the stream through
+// the vector cache instead costs a lone lane a third more per round) and takes more tasks than that in several helpings -- only
+// the first tail round has that many; end states live in global memory.  So all groups of a 256 x 1080p batch are resident at
+// once.  (One wave per workgroup with its own 12 KB of tables and 64 rows: 7 per CU, the batch took 2.1 shifts -- 543 us
+// against 300 us for a batch that fits.)  The waves of a workgroup never synchronise with each other after the tables are in
+// place.
+constexpr int kTailWaves = 4;
+constexpr int kTailThreads = 64 * kTailWaves;
+constexpr int kTailSlots = 32;
 constexpr int kTailRowWords = kSubseqWords + kStagedExtra;
 
-struct TailShared {
-    unsigned long long end[kSyncThreads];  // end states of the group's rows ([0] = state entering the group)
-    uint32_t rows[kTailThreads * kTailRowWords];
-    uint32_t tsel[10];
-    uint16_t list[2][kSyncThreads];         // subsequences to decode this round / next round
+struct TailWave {
+    uint32_t rows[kTailSlots * kTailRowWords];
+    uint16_t list[2][kSyncThreads];  // subsequences to decode this round / next round
     uint32_t count[2];
+};
+struct TailShared {
+    TailWave wave[kTailWaves];
+    uint32_t tsel[10];
 };
 
 struct TailEnv {
@@ -522,53 +532,49 @@ struct TailEnv {
     }
 };
 
-__global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
-                                                                 unsigned long long* __restrict__ states, const unsigned long long* __restrict__ incoming,
-                                                                 unsigned int* __restrict__ counters, const uint16_t* __restrict__ tail_tasks,
-                                                                 const uint32_t* __restrict__ tail_count)
+// orders a wave's own LDS / global traffic between its lanes (the waves of the tail kernel run on their own)
+__device__ __forceinline__ void wave_sync()
 {
-    __shared__ TailShared sh;
-    extern __shared__ uint16_t dyn_pool[];
-    HJ_LDS uint16_t* pool = (HJ_LDS uint16_t*)dyn_pool;
-    const uint32_t pending = tail_count[blockIdx.x];
-    if (pending == 0) return;  // uniform
-    const HuffUnit u = units[blockIdx.x];
-    const HuffImage& im = images[u.image];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the chains of one group (sync unit `ui`), walked by one wave
+__device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const HuffImage& im, const HuffUnit u, uint32_t ui, int lane,
+                                           unsigned long long* __restrict__ states, const unsigned long long* __restrict__ incoming,
+                                           unsigned int* __restrict__ counters, const uint16_t* __restrict__ tail_tasks, uint32_t pending)
+{
     const HuffGeom geom = make_geom(im);
     const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
     if (u.first >= nsub) return;
     unsigned long long* gstate = states + im.first_subseq;
-    const int t = threadIdx.x;
     const int n_rows = (int)min((uint32_t)kSyncThreads, nsub - u.first + 1);
-    stage_pool<kTailThreads>(pool, im);
-    stage_constants(sh.tsel, nullptr, nullptr, im, false);
-    for (int r = t; r < n_rows; r += kTailThreads) sh.end[r] = r == 0 ? incoming[blockIdx.x] : gstate[u.first - 1 + r];
-    for (uint32_t i = t; i < pending; i += kTailThreads) sh.list[0][i] = tail_tasks[(size_t)blockIdx.x * kSyncThreads + i];
-    if (t == 0) sh.count[0] = pending;
-    __syncthreads();
-
-    TailEnv env;
-    env.row_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&sh.rows[t * kTailRowWords];
-    env.pool = (uint32_t)(uintptr_t)pool;
-    env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
-    env.boundaries = geom.boundaries;
-    env.num_boundaries = geom.num_boundaries;
+    for (uint32_t i = lane; i < pending; i += 64) ws.list[0][i] = tail_tasks[(size_t)ui * kSyncThreads + i];
+    if (lane == 0) ws.count[0] = pending;
+    wave_sync();
     const bool rst = im.restart_interval != 0;
+    const unsigned long long entering = incoming[ui];  // the state the group was entered with ([0] of its rows)
     const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
     const uint32_t gwords = im.stream_words;
+    env.row_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&ws.rows[(lane & (kTailSlots - 1)) * kTailRowWords];
     int rounds = 0, cur = 0;
     for (int round = 0; round < kSyncThreads + 2; round++) {
-        const uint32_t n = sh.count[cur];
+        const uint32_t n = ws.count[cur];
         if (n == 0) break;
         rounds++;
-        if (t == 0) sh.count[cur ^ 1] = 0;
-        __syncthreads();
-        for (uint32_t base = 0; base < n; base += kTailThreads) {
-            const bool busy = base + t < n;
-            const int task = busy ? (int)sh.list[cur][base + t] : 0;
+        wave_sync();  // every lane has read the count before it is reused
+        if (lane == 0) ws.count[cur ^ 1] = 0;
+        wave_sync();
+        for (uint32_t base = 0; base < n; base += kTailSlots) {
+            const bool busy = lane < kTailSlots && base + lane < n;
+            const int task = busy ? (int)ws.list[cur][base + lane] : 1;
             unsigned long long now = 0;
             bool moved = false;
             if (busy) {
+                // Jacobi: every lane of the iteration starts from the end state its predecessor had BEFORE this iteration
+                const unsigned long long before =
+                    task == 1 ? entering : __hip_atomic_load(&gstate[u.first - 2 + task], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long old = __hip_atomic_load(&gstate[u.first - 1 + task], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // stage the row: 32 words + the reader's look-ahead, straight from the destuffed stream
                 env.word0 = (u.first - 1 + task) * kSubseqWords;
                 HJ_LDS uint32_t* row = (HJ_LDS uint32_t*)(uintptr_t)env.row_base;
@@ -582,26 +588,67 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
                     row[4 * i + 2] = ok ? __builtin_bswap32(x.z) : ~0u;
                     row[4 * i + 3] = ok ? __builtin_bswap32(x.w) : ~0u;
                 }
-                const SubseqState p = unpack_state(sh.end[task - 1]);
+                const SubseqState p = unpack_state(before);
                 now = pack_state(walk_subsequence(rst, geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8, boundary0_of(im, u.first - 1 + task)));
-                moved = ((now ^ sh.end[task]) & kSyncMask) != 0;
+                moved = ((now ^ old) & kSyncMask) != 0;
             }
-            __syncthreads();  // one wave: orders the LDS traffic, costs next to nothing
-            if (busy) sh.end[task] = now;
+            wave_sync();  // all start states have been read
+            if (busy) __hip_atomic_store(&gstate[u.first - 1 + task], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool more = busy && moved && task + 1 < n_rows;
             const unsigned long long mask = __ballot(more);
-            if (more) sh.list[cur ^ 1][sh.count[cur ^ 1] + __popcll(mask & ((1ull << t) - 1))] = (uint16_t)(task + 1);
-            __syncthreads();
-            if (t == 0) sh.count[cur ^ 1] += (uint32_t)__popcll(mask);
-            __syncthreads();
+            const uint32_t have = ws.count[cur ^ 1];
+            if (more) ws.list[cur ^ 1][have + __popcll(mask & ((1ull << lane) - 1))] = (uint16_t)(task + 1);
+            wave_sync();
+            if (lane == 0) ws.count[cur ^ 1] = have + (uint32_t)__popcll(mask);
+            wave_sync();
         }
         cur ^= 1;
     }
-    __syncthreads();
-    for (int r = 1 + t; r < n_rows; r += kTailThreads) gstate[u.first - 1 + r] = sh.end[r];
-    if (t == 0) {
+    if (lane == 0) {
         atomicAdd(counters + 6, (unsigned)rounds);
         atomicMax(counters + 7, (unsigned)rounds);
+    }
+}
+
+__global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units, int nunits,
+                                                                 unsigned long long* __restrict__ states, const unsigned long long* __restrict__ incoming,
+                                                                 unsigned int* __restrict__ counters, const uint16_t* __restrict__ tail_tasks,
+                                                                 const uint32_t* __restrict__ tail_count)
+{
+    __shared__ TailShared sh;
+    extern __shared__ uint16_t dyn_pool[];
+    HJ_LDS uint16_t* pool = (HJ_LDS uint16_t*)dyn_pool;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t ui0 = blockIdx.x * kTailWaves, ui = ui0 + wave;
+    const bool valid = ui < (uint32_t)nunits;
+    const HuffUnit u = units[valid ? ui : ui0];
+    const uint32_t pending = valid ? tail_count[ui] : 0u;
+    // the groups of a workgroup usually belong to one image; where an image ends inside it, its tables are staged in turn
+#pragma unroll 1
+    for (int s = 0; s < kTailWaves; s++) {
+        if (ui0 + s >= (uint32_t)nunits) break;  // uniform
+        const uint32_t image = units[ui0 + s].image;
+        if (s > 0 && image == units[ui0 + s - 1].image) continue;  // uniform: staged with the slot before
+        uint32_t work = 0;
+#pragma unroll
+        for (int q = 0; q < kTailWaves; q++)
+            if (ui0 + q < (uint32_t)nunits && units[ui0 + q].image == image) work |= tail_count[ui0 + q];
+        if (work == 0) continue;  // uniform: nothing left in this image's groups
+        const HuffImage& im = images[image];
+        __syncthreads();  // the tables of the image before are no longer in use
+        stage_pool<kTailThreads>(pool, im);
+        stage_constants(sh.tsel, nullptr, nullptr, im, false);
+        __syncthreads();
+        if (valid && u.image == image && pending != 0) {
+            TailEnv env;
+            env.row_base = 0;
+            env.word0 = 0;
+            env.pool = (uint32_t)(uintptr_t)pool;
+            env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
+            env.boundaries = im.boundaries;
+            env.num_boundaries = im.num_boundaries;
+            tail_group(sh.wave[wave], env, im, u, ui, lane, states, incoming, counters, tail_tasks, pending);
+        }
     }
 }
 
@@ -1015,8 +1062,8 @@ int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits,
     hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kSyncThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
                        first_pass, max_rounds, tail_tasks, tail_count);
     if (tail_count)
-        hipLaunchKernelGGL(huff_tail_kernel, dim3(nunits), dim3(kTailThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
-                           tail_tasks, tail_count);
+        hipLaunchKernelGGL(huff_tail_kernel, dim3((nunits + kTailWaves - 1) / kTailWaves), dim3(kTailThreads), pool_bytes, (hipStream_t)stream, images, units,
+                           nunits, states, incoming, changed, tail_tasks, tail_count);
     return (int)hipGetLastError();
 }
 
