@@ -157,12 +157,17 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, voi
  * hipjpegDecodeBatchDevice == entropy (if any image uses it), then 0, 1, 2, 4. */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handle, int which, void* stream);
 /* Pipelined submission.  Submit = host stage + H2D copy (on an internal copy stream) + every kernel on `stream`, without
- * waiting for anything on the device; at most three batches may be in flight (the handle's three staging pages).  Wait = block
+ * waiting for anything on the device; at most three batches (hipjpegSetPipelineDepth: up to eight) may be in flight (the handle's staging pages).  Wait = block
  * until the OLDEST submitted batch has finished and return its final per-image statuses.  The host stage of batch n+1 and
  * its H2D copy overlap the kernels of batch n.  Outputs and `data` of a submitted batch must stay valid until its Wait. */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
                                                      const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags, void* stream);
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size);
+/* How many batches Submit may have in flight (staging pages in use): 1..8, default 3; only while nothing is in flight.
+ * Batches of progressive images keep a small part of the chip busy for a long time (one wave per scan), so their throughput
+ * grows with the depth; each page in flight runs its entropy stage on a stream of its own, and the HIP runtime must be
+ * allowed as many hardware queues (environment GPU_MAX_HW_QUEUES, default 4, read when the runtime starts). */
+HIPJPEG_API hipjpegStatus_t hipjpegSetPipelineDepth(hipjpegHandle_t handle, int depth);
 /* Final per-image statuses of the current batch (after the device stage they include what the GPU entropy stage found;
  * blocks until that stage has reported). */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchGetStatuses(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size);

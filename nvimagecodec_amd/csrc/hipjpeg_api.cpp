@@ -45,20 +45,22 @@ struct hipjpegHandle {
     // three batch pages, used in turn: the host stage and H2D copy of batches k+1 and k+2 proceed while the device is still
     // consuming batch k (same idea as the reference's two pinned pages per thread, cuda_decoder.h:50-53; the third page
     // keeps the copy engine a whole batch ahead of the kernels)
-    static constexpr int kPages = 3;
-    std::unique_ptr<DecodeBatch> batches[kPages];
+    // (hipjpegSetPipelineDepth: up to kMaxPages, for work whose batches leave most of the chip idle -- progressive scans)
+    static constexpr int kMaxPages = 8;
+    int pages = 3;
+    std::unique_ptr<DecodeBatch> batches[kMaxPages];
     int current = 0;
     DecodeBatch& cur() { return *batches[current]; }
     // pipelined submission (hipjpegDecodeBatchSubmit / Wait): pages in flight, oldest first, with the stream each runs on
     std::vector<hipjpegTransform_t> transforms;  // geometry for the next batch (hipjpegDecodeBatchSetTransforms)
-    int submitted[kPages] = {-1, -1, -1};
-    void* submitted_stream[kPages] = {nullptr, nullptr, nullptr};
+    int submitted[kMaxPages] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    void* submitted_stream[kMaxPages] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int num_submitted = 0;
     hipStream_t copy_stream = nullptr;  // H2D copies of submitted batches: they overlap the kernels of the batch before
     hipStream_t entropy_stream = nullptr;  // GPU entropy stage of submitted batches: beside the pixel kernels of the batch before
     // batches with progressive images: the walk of a progressive scan is one wave per scan and leaves most of the chip idle, so
     // the entropy stages of consecutive batches run beside EACH OTHER, one stream per page
-    hipStream_t page_entropy_stream[3] = {nullptr, nullptr, nullptr};
+    hipStream_t page_entropy_stream[kMaxPages] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::unique_ptr<EncodeBatch> encode;
     EncodeBatch* encode_view = nullptr;  // the batch hipjpegEncodeGetBitstream / GetCoefficients / Stats talk about
     // pipelined encoding (hipjpegEncodeBatchSubmit / Wait): three pages, each driven by its own host thread on its own
@@ -239,7 +241,7 @@ hipjpegStatus_t hipjpegDecodeBatchHost(hipjpegHandle_t handle, const uint8_t* co
 {
     return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    handle->current = (handle->current + 1) % hipjpegHandle::kPages;
+    handle->current = (handle->current + 1) % handle->pages;
     DecodeBatch& b = handle->cur();
     static const bool timing = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;  // debug aid: host-stage phase times on stderr
     const auto t0 = std::chrono::steady_clock::now();
@@ -334,7 +336,7 @@ hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* 
 {
     return guarded([&]() -> hipjpegStatus_t {
     if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
-    if (handle->num_submitted >= hipjpegHandle::kPages) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // every page in flight: Wait first
+    if (handle->num_submitted >= handle->pages) return HIPJPEG_STATUS_INVALID_ARGUMENT;  // every page in flight: Wait first
     if (hipSetDevice(handle->device_id) != hipSuccess) return HIPJPEG_STATUS_NO_DEVICE;
     if (!handle->copy_stream && hipStreamCreateWithFlags(&handle->copy_stream, hipStreamNonBlocking) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     static const bool two_streams = getenv("HIPJPEG_SINGLE_STREAM") == nullptr;  // HIPJPEG_SINGLE_STREAM=1: measurement aid
@@ -354,6 +356,16 @@ hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* 
     handle->submitted[handle->num_submitted] = handle->current;
     handle->submitted_stream[handle->num_submitted] = stream;
     handle->num_submitted++;
+    return HIPJPEG_STATUS_SUCCESS;
+    });
+}
+
+hipjpegStatus_t hipjpegSetPipelineDepth(hipjpegHandle_t handle, int depth)
+{
+    return guarded([&]() -> hipjpegStatus_t {
+    if (!handle || depth < 1 || depth > hipjpegHandle::kMaxPages || handle->num_submitted != 0) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    handle->pages = depth;
+    handle->current = 0;
     return HIPJPEG_STATUS_SUCCESS;
     });
 }

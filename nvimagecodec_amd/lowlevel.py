@@ -194,7 +194,13 @@ class BatchDecoder:
         return outs, statuses
 
     # -- pipelined: submit() returns once everything is queued; wait() returns the statuses of the oldest submitted batch.
-    #    At most two batches in flight.  The caller keeps jpegs and outs alive until the matching wait().
+    #    At most three batches in flight (set_pipeline_depth: up to eight).  The caller keeps jpegs and outs alive until the
+    #    matching wait().
+    def set_pipeline_depth(self, depth):
+        st = N.load().hipjpegSetPipelineDepth(self._h, int(depth))
+        if st:
+            raise N.HipJpegError(st, "hipjpegSetPipelineDepth")
+
     def submit(self, jpegs, outs, fmt="rgb", fancy=True, stream=None, gpu_huffman=True):
         ptrs, lens, O, statuses = self._marshal(jpegs, outs, fmt)
         flags = (N.FLAG_FANCY_UPSAMPLING if fancy else 0) | (N.FLAG_GPU_HUFFMAN if gpu_huffman else 0)

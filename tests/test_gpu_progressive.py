@@ -146,3 +146,34 @@ def test_progressive_through_the_pipelined_entry_points(dec):
     for outs in ring:
         for r, o in zip(refs, outs):
             assert np.array_equal(o.cpu().numpy(), r)
+
+
+def test_deeper_pipeline_for_progressive_batches(dec):
+    """hipjpegSetPipelineDepth: six batches of progressive and baseline images in flight (each page its own entropy stream),
+    different content per batch, every output checked; the depth cannot change while batches are in flight and is bounded."""
+    import torch
+    from nvimagecodec_amd import _native as N
+    prog = [load_decode_case(e)[0] for e in _PROG if "_rst" not in e["name"]][:12]
+    base = [load_decode_case(e)[0] for e in _M["decode"] if not e["progressive"] and e["sub"] != "gray" and e["pixels"]][:12]
+    depth = 6
+    dec.set_pipeline_depth(depth)
+    batches = [(prog + base)[k:] + (prog + base)[:k] for k in range(depth)]
+    refs = [[oracle.decode(j) for j in b] for b in batches]
+    ring = [dec.allocate_outputs(b, "rgb") for b in batches]
+    for rep in range(2):
+        for k in range(depth):
+            dec.submit(batches[k], ring[k], gpu_huffman=True)
+        with pytest.raises(N.HipJpegError):
+            dec.set_pipeline_depth(3)  # batches in flight
+        with pytest.raises(N.HipJpegError):
+            dec.submit(batches[0], ring[0], gpu_huffman=True)  # every page is taken
+        for k in range(depth):
+            assert all(s == 0 for s in dec.wait())
+        torch.cuda.synchronize()
+        for rb, outs in zip(refs, ring):
+            for r, o in zip(rb, outs):
+                assert np.array_equal(o.cpu().numpy(), r)
+                o.zero_()
+    with pytest.raises(N.HipJpegError):
+        dec.set_pipeline_depth(9)
+    dec.set_pipeline_depth(3)
