@@ -10,20 +10,25 @@ from nvimagecodec_amd.lowlevel import BatchDecoder
 from nvimagecodec_amd.synth import synth_image
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 prog = [bench._pil_encode(synth_image(bench.WIDTH, bench.HEIGHT, seed=900 + k), 90, "444", progressive=True) for k in range(4)]
 batch = [prog[i % 4] for i in range(128)]
 dec = BatchDecoder(0, bench.usable_cpus())
-ring = [dec.allocate_outputs(batch, "rgb_planar") for _ in range(3)]
+dec.set_pipeline_depth(depth)
+ring = [dec.allocate_outputs(batch, "rgb_planar") for _ in range(depth)]
 dec.submit(batch, ring[1], fmt="rgb_planar")
 dec.wait()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(nb):
-    dec.submit(batch, ring[i % 3], fmt="rgb_planar")
-    if i > 1:
+    ts = time.perf_counter()
+    dec.submit(batch, ring[i % depth], fmt="rgb_planar")
+    tm = time.perf_counter()
+    if i >= depth - 1:
         dec.wait()
-dec.wait()
-dec.wait()
+    print("batch %d: submit %.1f ms, wait %.1f ms" % (i, (tm - ts) * 1e3, (time.perf_counter() - tm) * 1e3))
+for _ in range(depth - 1):
+    dec.wait()
 torch.cuda.synchronize()
 t = (time.perf_counter() - t0) / nb
 print("pipelined: %.1f ms per batch, %.0f images/s" % (t * 1e3, 128 / t))

@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage (on the GPU box): tools/prog_pipe_trace.sh   -- kernel timeline of the pipelined progressive decode (who overlaps whom)
+# usage (on the GPU box): tools/prog_pipe_trace.sh [batches [depth]]   -- kernel timeline of the pipelined progressive decode (who overlaps whom)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_pp
-(cd /tmp && rocprofv3 --kernel-trace -d $R/gpurun_out/prof_pp -o pp --output-format csv -- python3 $R/tools/prof_prog_pipe.py 6 > $R/gpurun_out/prof_pp.log 2>&1) || { tail -5 $R/gpurun_out/prof_pp.log; exit 1; }
-tail -1 $R/gpurun_out/prof_pp.log
+(cd /tmp && rocprofv3 --kernel-trace -d $R/gpurun_out/prof_pp -o pp --output-format csv -- python3 $R/tools/prof_prog_pipe.py ${1:-6} ${2:-3} > $R/gpurun_out/prof_pp.log 2>&1) || { tail -5 $R/gpurun_out/prof_pp.log; exit 1; }
+grep -v rocprof $R/gpurun_out/prof_pp.log | tail -${1:-6} ; tail -2 $R/gpurun_out/prof_pp.log
 python3 - <<PY
 import csv
 rows = list(csv.DictReader(open("$R/gpurun_out/prof_pp/pp_kernel_trace.csv")))
