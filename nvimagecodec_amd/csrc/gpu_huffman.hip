@@ -30,7 +30,6 @@ namespace {
 
 constexpr int kThreads = 256;
 
-constexpr int kRowWords = kSubseqWords + 1;
 constexpr int kRowShift = kSubseqWords == 32 ? 5 : kSubseqWords == 16 ? 4 : kSubseqWords == 64 ? 6 : -1;  // log2(words per subsequence)
 static_assert(kRowShift > 0, "subsequences of 512, 1024 or 2048 bits");
 
@@ -43,11 +42,15 @@ struct KSlot {
     uint32_t stride_y, stride_x;
 };
 
-// Stream words in LDS: word d of the staged range sits at index d + d / kSubseqWords -- one spare word per subsequence, so that
-// lanes at the same column of their rows hit different banks.  kStagedExtra words behind the last row cover the bit
-// reader's look-ahead.
-constexpr int kStagedExtra = 4;
-__host__ __device__ constexpr int staged_lds_words(int rows) { return rows * kRowWords + kStagedExtra; }
+// Stream words in LDS: every subsequence ("row") is staged together with the kStagedExtra words behind it, which cover the bit
+// reader's look-ahead (the last symbol of a walk starts before the row's end: its window reaches into word 32, the word
+// requested ahead is word 33) -- a walk never leaves its row -- and the rows are TRANSPOSED: word k of row r sits at index
+// k * rows + r.  The bank of an access is then r mod 32 whatever k is: lanes that walk their own rows never collide, however
+// far apart their positions are, and stepping to the next word is adding a constant to an address (BitReader's cursor).
+constexpr int kStagedExtra = 2;
+constexpr int kRowWords = kSubseqWords + kStagedExtra;
+static_assert(kSubseqWords % 4 == 0 && kStagedExtra == 2, "stage_rows: 16-byte groups and one 8-byte group per row");
+__host__ __device__ constexpr int staged_lds_words(int rows) { return rows * kRowWords; }
 
 struct WgShared {
     uint32_t stream[staged_lds_words(kSyncThreads)];
@@ -66,17 +69,22 @@ __device__ __forceinline__ uint32_t load_boundary(const uint32_t* boundaries, ui
 // LDS accessors for decode_subsequence.
 struct DevEnv {
     uint32_t stream_base;  // LDS byte address of the staged words
-    uint32_t word0;        // image word index of the first staged word
+    uint32_t word0;        // image word index of the first word of staged row 0
+    uint32_t row_addr;     // this lane's walk: LDS byte address of word 0 of its row ...
+    uint32_t row_word0;    // ... and the image word index of that word (set_row)
     uint32_t pool;         // LDS byte address of the lookup tables
     const HJ_LDS uint32_t* tsel;  // per MCU position: BYTE offsets of the DC / AC first-level tables, packed lo/hi
     const uint32_t* boundaries;
     uint32_t num_boundaries;
     __device__ __forceinline__ uint32_t boundary(uint32_t i) const { return load_boundary(boundaries, num_boundaries, i); }
-    __device__ __forceinline__ uint32_t word(uint32_t i) const
+    static constexpr uint32_t kCursorStep = (uint32_t)kSyncThreads * 4u;  // consecutive words of a row, in bytes
+    __device__ __forceinline__ void set_row(int row)
     {
-        const uint32_t local = i - word0;
-        return *(const HJ_LDS uint32_t*)(uintptr_t)(stream_base + ((local + (local >> kRowShift)) << 2));
+        row_addr = stream_base + ((uint32_t)row << 2);
+        row_word0 = word0 + ((uint32_t)row << kRowShift);
     }
+    __device__ __forceinline__ uint32_t cursor(uint32_t i) const { return row_addr + (i - row_word0) * kCursorStep; }
+    __device__ __forceinline__ uint32_t fetch(uint32_t c) const { return *(const HJ_LDS uint32_t*)(uintptr_t)c; }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
     __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
     {
@@ -104,39 +112,45 @@ __device__ __forceinline__ SubseqState walk_subsequence(bool rst, const HuffGeom
     return rst ? decode_subsequence<true>(geom, env, begin, limit, z, k, boundary0) : decode_subsequence<false>(geom, env, begin, limit, z, k);
 }
 
-// Cooperative staging of stream words: ROWS subsequences starting with subsequence first_row of the image (first_row may
-// be -1: that row is filled with ones) plus kStagedExtra words.  16-byte global loads, all of a lane's loads in flight
-// together.
-template <int THREADS, int ROWS>
+// Cooperative staging of stream words: lane t brings in row t = subsequence first_row + t of the image (first_row may be -1:
+// that row is filled with ones) and the kStagedExtra words behind it, transposed (see WgShared).  16-byte global loads, all of
+// a lane's loads in flight together; words behind the end of the stream read as ones.
+template <int ROWS>
 __device__ __forceinline__ void stage_rows(uint32_t* lds_stream, const HuffImage& im, int first_row)
 {
     const int t = threadIdx.x;
     const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
     const int nwords = (int)im.stream_words;
-    const int w0 = first_row * kSubseqWords;
-    constexpr int kGroups = (ROWS * kSubseqWords + kStagedExtra) / 4;  // 16-byte groups
-    constexpr int kIters = (kGroups + THREADS - 1) / THREADS;
-    u32x4 v[kIters];
+    const int w0 = (first_row + t) * kSubseqWords;
+    constexpr int kGroups = kSubseqWords / 4;  // 16-byte groups per row; the look-ahead words are one 8-byte group more
+    u32x4 v[kGroups];
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 tail;
+    {
+        const int gd = w0 + kSubseqWords;
+        const int gc = min(max(gd, 0), (nwords - 1) & ~1);
+        const u32x2 x = *(const HJ_GLOBAL u32x2*)(g + gc);
+        tail = (gd >= 0 && gd < nwords) ? x : u32x2{~0u, ~0u};
+    }
 #pragma unroll
-    for (int i = 0; i < kIters; i++) {
-        const int gd = w0 + (i * THREADS + t) * 4;
+    for (int i = 0; i < kGroups; i++) {
+        const int gd = w0 + i * 4;
         // streams are allocated in whole 64-byte units: a 16-byte group that starts inside the stream is readable.  The
         // load itself is unconditional (clamped address) so that all of them are in flight together.
         const int gc = min(max(gd, 0), (nwords - 1) & ~3);
         const u32x4 x = *(const HJ_GLOBAL u32x4*)(g + gc);
         v[i] = (gd >= 0 && gd < nwords) ? x : u32x4{~0u, ~0u, ~0u, ~0u};
     }
+    HJ_LDS uint32_t* dst = (HJ_LDS uint32_t*)lds_stream + t;
 #pragma unroll
-    for (int i = 0; i < kIters; i++) {
-        if (i * THREADS + t < kGroups) {
-            const uint32_t d = (uint32_t)(i * THREADS + t) * 4;  // the four words share a row: 32 % 4 == 0
-            HJ_LDS uint32_t* dst = (HJ_LDS uint32_t*)&lds_stream[d + (d >> kRowShift)];
-            dst[0] = __builtin_bswap32(v[i].x);
-            dst[1] = __builtin_bswap32(v[i].y);
-            dst[2] = __builtin_bswap32(v[i].z);
-            dst[3] = __builtin_bswap32(v[i].w);
-        }
+    for (int i = 0; i < kGroups; i++) {
+        dst[(4 * i + 0) * ROWS] = __builtin_bswap32(v[i].x);
+        dst[(4 * i + 1) * ROWS] = __builtin_bswap32(v[i].y);
+        dst[(4 * i + 2) * ROWS] = __builtin_bswap32(v[i].z);
+        dst[(4 * i + 3) * ROWS] = __builtin_bswap32(v[i].w);
     }
+    dst[(kSubseqWords + 0) * ROWS] = __builtin_bswap32(tail.x);
+    dst[(kSubseqWords + 1) * ROWS] = __builtin_bswap32(tail.y);
 }
 
 // lookup tables -> LDS
@@ -182,6 +196,8 @@ __device__ __forceinline__ DevEnv make_env(WgShared& sh, HJ_LDS uint16_t* pool, 
     DevEnv env;
     env.stream_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)sh.stream;
     env.word0 = (first - 1) * kSubseqWords;  // row 0 = the halo (wraps for the first workgroup of an image; so do the indices)
+    env.row_addr = env.stream_base;
+    env.row_word0 = env.word0;
     env.pool = (uint32_t)(uintptr_t)pool;
     env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
     env.boundaries = geom.boundaries;
@@ -417,12 +433,12 @@ __global__ __launch_bounds__(kSyncThreads) void huff_sync_kernel(const HuffImage
         in_state = u.first ? __hip_atomic_load(&gstate[u.first - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kSyncMask : 0ull;
         if (in_state == incoming[blockIdx.x]) return;  // uniform
     }
-    stage_rows<kSyncThreads, kSyncThreads>(sh.stream, im, (int)u.first - 1);
+    stage_rows<kSyncThreads>(sh.stream, im, (int)u.first - 1);
     stage_pool<kSyncThreads>(pool, im);
     stage_constants(sh.tsel, nullptr, nullptr, im, false);
     __syncthreads();
 
-    const DevEnv env = make_env(sh, pool, u.first, geom);
+    DevEnv env = make_env(sh, pool, u.first, geom);
     const bool rst = im.restart_interval != 0;
     unsigned long long old_global = ~0ull;
     int task = -1;
@@ -431,6 +447,7 @@ __global__ __launch_bounds__(kSyncThreads) void huff_sync_kernel(const HuffImage
         unsigned long long mine = 0;  // first workgroup of an image, lane 0: the exact initial state (bit 0, z 0, k 0)
         if (owner || (t == 0 && u.first > 0)) {
             const uint32_t bidx0 = boundary0_of(im, j);
+            env.set_row(t);
             mine = pack_state(walk_subsequence(rst, geom, env, j * kSubseqBits, (j + 1) * kSubseqBits, 0, 0, bidx0));
         }
         sh.end[t] = mine;
@@ -449,6 +466,7 @@ __global__ __launch_bounds__(kSyncThreads) void huff_sync_kernel(const HuffImage
         bool moved = false;
         if (task >= 0) {
             const SubseqState p = unpack_state(sh.end[task - 1]);
+            env.set_row(task);  // the predecessor's walk ended on a symbol that starts in this row
             now = pack_state(walk_subsequence(rst, geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8, boundary0_of(im, u.first - 1 + task)));
             moved = ((now ^ sh.end[task]) & kSyncMask) != 0;
         }
@@ -496,7 +514,7 @@ __global__ __launch_bounds__(kSyncThreads) void huff_sync_kernel(const HuffImage
 constexpr int kTailWaves = 4;
 constexpr int kTailThreads = 64 * kTailWaves;
 constexpr int kTailSlots = 32;
-constexpr int kTailRowWords = kSubseqWords + kStagedExtra;
+constexpr int kTailRowWords = kSubseqWords + 4;  // whole 16-byte groups
 
 struct TailWave {
     uint32_t rows[kTailSlots * kTailRowWords];
@@ -516,7 +534,9 @@ struct TailEnv {
     const uint32_t* boundaries;
     uint32_t num_boundaries;
     __device__ __forceinline__ uint32_t boundary(uint32_t i) const { return load_boundary(boundaries, num_boundaries, i); }
-    __device__ __forceinline__ uint32_t word(uint32_t i) const { return *(const HJ_LDS uint32_t*)(uintptr_t)(row_base + ((i - word0) << 2)); }
+    static constexpr uint32_t kCursorStep = (uint32_t)kTailSlots * 4u;  // the slots are transposed like the rows of the sync kernel
+    __device__ __forceinline__ uint32_t cursor(uint32_t i) const { return row_base + (i - word0) * kCursorStep; }
+    __device__ __forceinline__ uint32_t fetch(uint32_t c) const { return *(const HJ_LDS uint32_t*)(uintptr_t)c; }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
     __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
     {
@@ -556,7 +576,7 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const Huff
     const unsigned long long entering = incoming[ui];  // the state the group was entered with ([0] of its rows)
     const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
     const uint32_t gwords = im.stream_words;
-    env.row_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&ws.rows[(lane & (kTailSlots - 1)) * kTailRowWords];
+    env.row_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&ws.rows[lane & (kTailSlots - 1)];  // word k of slot s at index k * kTailSlots + s
     int rounds = 0, cur = 0;
     for (int round = 0; round < kSyncThreads + 2; round++) {
         const uint32_t n = ws.count[cur];
@@ -583,10 +603,10 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const Huff
                     const uint32_t d = env.word0 + 4 * i;
                     const u32x4 x = *(const HJ_GLOBAL u32x4*)(g + min(d, (gwords - 1) & ~3u));
                     const bool ok = d < gwords;
-                    row[4 * i + 0] = ok ? __builtin_bswap32(x.x) : ~0u;
-                    row[4 * i + 1] = ok ? __builtin_bswap32(x.y) : ~0u;
-                    row[4 * i + 2] = ok ? __builtin_bswap32(x.z) : ~0u;
-                    row[4 * i + 3] = ok ? __builtin_bswap32(x.w) : ~0u;
+                    row[(4 * i + 0) * kTailSlots] = ok ? __builtin_bswap32(x.x) : ~0u;
+                    row[(4 * i + 1) * kTailSlots] = ok ? __builtin_bswap32(x.y) : ~0u;
+                    row[(4 * i + 2) * kTailSlots] = ok ? __builtin_bswap32(x.z) : ~0u;
+                    row[(4 * i + 3) * kTailSlots] = ok ? __builtin_bswap32(x.w) : ~0u;
                 }
                 const SubseqState p = unpack_state(before);
                 now = pack_state(walk_subsequence(rst, geom, env, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255, p.zk >> 8, boundary0_of(im, u.first - 1 + task)));
@@ -706,14 +726,15 @@ __global__ __launch_bounds__(kSyncThreads) void huff_pos_kernel(HuffImage* __res
     const HuffGeom geom = make_geom(im);
     const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
     if (u.first >= nsub) return;
-    stage_rows<kSyncThreads, kSyncThreads>(sh.stream, im, (int)u.first - 1);
+    stage_rows<kSyncThreads>(sh.stream, im, (int)u.first - 1);
     stage_pool<kSyncThreads>(pool, im);
     stage_constants(sh.tsel, nullptr, nullptr, im, false);
     __syncthreads();
     const int t = threadIdx.x;
     const uint32_t j = u.first - 1 + t;
     if (t == 0 || j >= nsub) return;
-    const DevEnv env = make_env(sh, pool, u.first, geom);
+    DevEnv env = make_env(sh, pool, u.first, geom);
+    env.set_row(t);
     const bool rst = im.restart_interval != 0;
     const unsigned long long* st = states + im.first_subseq;
     uint32_t begin = 0;
@@ -773,6 +794,9 @@ struct BlockEnv {
     const HJ_LDS uint32_t* tsel;
     const HJ_LDS KSlot* kslot;
     const HJ_LDS uint8_t* zz;
+    static constexpr uint32_t kCursorStep = 1;  // the cursor is the word index
+    __device__ __forceinline__ uint32_t cursor(uint32_t i) const { return i; }
+    __device__ __forceinline__ uint32_t fetch(uint32_t i) const { return word(i); }
     __device__ __forceinline__ uint32_t word(uint32_t i) const
     {
         const uint32_t local = i - word0;
@@ -824,7 +848,7 @@ __global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __res
         // the span of the stream these blocks cover: from the first block's word to the start of the block behind the last
         const uint32_t b_end = b_first + items;
         const uint32_t end_bit = b_end < nblocks ? im.block_pos[b_end] : geom.total_bits;
-        const uint32_t w_lo = im.block_pos[b_first] >> 5, w_hi = (end_bit >> 5) + kStagedExtra;
+        const uint32_t w_lo = im.block_pos[b_first] >> 5, w_hi = (end_bit >> 5) + 4;
         sh.span[0] = w_lo;
         sh.span[1] = (kBStreamWords > 0 && w_hi - w_lo <= (uint32_t)kBStreamWords) ? w_hi - w_lo : 0u;
     }

@@ -226,6 +226,9 @@ namespace {
 // plain-memory accessors for decode_subsequence
 struct HostEnv {
     const HuffImage* im;
+    static constexpr uint32_t kCursorStep = 1;  // the cursor is the word index
+    uint32_t cursor(uint32_t i) const { return i; }
+    uint32_t fetch(uint32_t i) const { return word(i); }
     uint32_t word(uint32_t i) const
     {
         const uint8_t* p = im->stream + (size_t)i * 4;  // the slack behind the stream covers the reader's look-ahead

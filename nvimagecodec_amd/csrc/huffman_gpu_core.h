@@ -172,30 +172,36 @@ HJ_HD uint32_t funnel_shift_right(uint32_t high, uint32_t low, uint32_t s)  // b
     return (uint32_t)((((uint64_t)high << 32) | low) >> (s & 31));
 #endif
 }
+// Words are addressed through a CURSOR the environment defines (Env::cursor(word index), Env::fetch(cursor), consecutive words
+// Env::kCursorStep apart): a plain index on the host, an LDS byte address in the kernels whose lanes keep their stretch of the
+// stream in LDS -- moving on by a word is then one add, not an index-to-address computation per symbol.
 struct BitReader {
     uint32_t hi;      // the next 32 bits of the stream
     uint32_t w0, w1;  // the words hi is cut from
     uint32_t s;       // 0 <= s <= 31
-    uint32_t next;    // index of the word behind w1
+    uint32_t next;    // cursor of the word behind w1
+    uint32_t step;    // Env::kCursorStep
     template <class Env>
     HJ_HD void start(const Env& env, uint32_t pos)
     {
         const uint32_t i = pos >> 5, b = pos & 31;
-        const uint32_t i1 = i + (b != 0 ? 1u : 0u);  // on a word boundary the window is w1 alone (s = 0)
-        w0 = env.word(i);
-        w1 = env.word(i1);
+        const uint32_t c0 = env.cursor(i);
+        const uint32_t c1 = c0 + (b != 0 ? Env::kCursorStep : 0u);  // on a word boundary the window is w1 alone (s = 0)
+        w0 = env.fetch(c0);
+        w1 = env.fetch(c1);
         s = (0u - b) & 31u;
-        next = i1 + 1;
+        step = Env::kCursorStep;
+        next = c1 + Env::kCursorStep;
         hi = funnel_shift_right(w0, w1, s);
     }
-    // drops c (1..31) bits; `fetched` = word `next`, taken when the position leaves w0
+    // drops c (1..31) bits; `fetched` = the word at `next`, taken when the position leaves w0
     HJ_HD void consume(uint32_t c, uint32_t fetched)
     {
         const uint32_t t = s - c;
         const bool need = (int32_t)t < 0;
         w0 = need ? w1 : w0;
         w1 = need ? fetched : w1;
-        next += need ? 1u : 0u;
+        next += need ? step : 0u;
         s = t & 31u;
         hi = funnel_shift_right(w0, w1, s);
     }
@@ -248,7 +254,8 @@ struct RestartCursor {
 // Synchronisation decode: the symbols that START in [begin, limit) (and before total_bits), beginning in state (z, k).
 // Tracks the decoder state and counts the blocks completed; nothing is stored.
 // Env supplies the memory accessors:
-//   uint32_t word(uint32_t i)            32-bit word i of the stream, first byte in the most significant position
+//   uint32_t cursor(uint32_t i), fetch(cursor), kCursorStep   32-bit word i of the stream, first byte in the most significant
+//                                        position, through a cursor (see BitReader)
 //   uint32_t tables(int k)               tdc | tac << 16 for block position k: where the first-level tables are, in whatever
 //                                        unit lookup1 wants
 //   uint32_t lookup1(uint32_t t, w)      first-level entry of table t for window w (index = top kHuffFastBits bits)
@@ -278,7 +285,7 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
         }
     }
     while (pos < end) {
-        const uint32_t fetched = env.word(br.next);
+        const uint32_t fetched = env.fetch(br.next);
         uint32_t e = env.lookup1(tcur, br.hi);
         const uint32_t pr = env.lookup_pair(tcur, br.hi);  // means something behind an AC table only (z != 0)
         const bool two = z != 0 && (uint32_t)z < (pr >> 10) && pos < pair_end;
@@ -351,7 +358,7 @@ HJ_HD void position_subsequence(const HuffGeom& im, const Env& env, uint32_t beg
     // a block is recorded where its predecessor ends (inside the rare end-of-block branch), the one in progress at `begin` here
     if (fresh && pos < end) rec(block, pos);
     while (pos < end) {
-        const uint32_t fetched = env.word(br.next);
+        const uint32_t fetched = env.fetch(br.next);
         uint32_t e = env.lookup1(tcur, br.hi);
         const uint32_t pr = env.lookup_pair(tcur, br.hi);
         const bool two = z != 0 && (uint32_t)z < (pr >> 10) && pos < pair_end;
@@ -396,7 +403,7 @@ HJ_HD int decode_block(const HuffGeom& im, const Env& env, uint32_t pos, int k, 
     BitReader br;
     br.start(env, pos);
     while (pos < im.total_bits && z < 64) {
-        const uint32_t fetched = env.word(br.next);
+        const uint32_t fetched = env.fetch(br.next);
         const uint32_t w = br.hi;
         uint32_t e = env.lookup1(tcur, w);
         if ((e >> 9) == kZadvLong) e = env.lookup2(e, w);
