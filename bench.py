@@ -309,6 +309,38 @@ def config4_progressive(dec, host_threads):
     return res
 
 
+def device_stage_flavours(dec, jpegs):
+    """The pixel kernels' other flavours on the same batch (configs[1] times the everyday one: interleaved RGB, fancy upsampling):
+    K1 + K2 per step by HIP events, coefficients resident in HBM.  The generic flavour of K2 runs at the same five-waves bound with
+    24-40 bytes of scratch per lane -- measured faster than four waves without."""
+    import torch
+    res = {}
+    for label, fmt, fancy in (("rgb_planar", "rgb_planar", True), ("bgr_interleaved", "bgr", True), ("rgb_plain_upsampling", "rgb", False),
+                              ("gray", "y", True)):
+        outs = dec.allocate_outputs(jpegs, fmt)
+        dec.host_stage(jpegs, outs, fmt, fancy=fancy, gpu_huffman=True)
+        dec.transfer()
+        dec.device_stage(which=3)
+        for _ in range(10):
+            dec.device_stage(which=0)
+            dec.device_stage(which=1)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            dec.device_stage(which=0)
+            dec.device_stage(which=1)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        px = 1 if fmt == "y" else 3
+        res[label] = {"k1_k2_ms": round(ms, 4), "images_per_s": round(BATCH / ms * 1e3, 1),
+                      "GBps_algorithmic": round((COEF_BYTES_PER_IMAGE + WIDTH * HEIGHT * px) * BATCH / (ms * 1e-3) / 1e9, 1)}
+        del outs
+    return res
+
+
 def encode_figures(outs, local_rank, host_threads):
     import torch
     from nvimagecodec_amd.lowlevel import BatchEncoder
@@ -507,6 +539,11 @@ def main():
             "host_threads_per_gpu": host_threads}
         extras["host_stage"] = {"huffman_images_per_s": round(BATCH / t_host, 1), "threads": host_threads,
                                 "h2d_GBps": round(hst["coef_bytes"] / t_h2d / 1e9, 1)}
+        if rank == 0:
+            try:
+                extras["device_stage_flavours"] = device_stage_flavours(dec, jpegs)
+            except Exception as e:
+                extras["device_stage_flavours"] = {"error": repr(e)}
         try:
             extras["encode"] = encode_figures(outs, local_rank, host_threads)
         except Exception as e:  # the decode line must not be lost because an extra failed
