@@ -1,5 +1,6 @@
 // decoder_core.cpp -- see decoder_core.h
 #include "decoder_core.h"
+#include "host_copy.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -572,7 +573,7 @@ void DecodeBatch::entropy_stage(int i)
             const ScanHeader& sc = f.scans[sidx];
             const size_t len = sc.data_end - sc.data_begin;
             uint8_t* raw = pinned_.data() + im.prog_raw_offset[sidx];
-            memcpy(raw, im.data + sc.data_begin, len);
+            copy_to_staging(raw, im.data + sc.data_begin, len);
             memset(raw + len, 0x01, align_up(len, 16) + 16 - len);  // neither FF nor 00
             HuffImage& h = huff_images_[huff_to_image_.size() + im.prog_huff_first + sidx];
             memset(&h, 0, sizeof h);
@@ -590,7 +591,7 @@ void DecodeBatch::entropy_stage(int i)
         const ScanHeader& sc = im.frame.scans[0];
         im.stream_bytes = (uint32_t)(sc.data_end - sc.data_begin);
         uint8_t* raw = pinned_.data() + im.raw_offset;
-        memcpy(raw, im.data + sc.data_begin, im.stream_bytes);
+        copy_to_staging(raw, im.data + sc.data_begin, im.stream_bytes);
         memset(raw + im.stream_bytes, 0x01, align_up((size_t)im.stream_bytes, 16) + 16 - im.stream_bytes);  // neither FF nor 00
         HuffImage& h = huff_images_[im.huff_index];
         fill_huff_image(im.frame, im.stream_bytes, &h);
