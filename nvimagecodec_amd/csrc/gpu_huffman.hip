@@ -799,9 +799,14 @@ struct BlockEnv {
     __device__ __forceinline__ uint32_t fetch(uint32_t i) const { return word(i); }
     __device__ __forceinline__ uint32_t word(uint32_t i) const
     {
-        const uint32_t local = i - word0;
-        if (local < staged) return *(const HJ_LDS uint32_t*)(uintptr_t)(stream_base + (local << 2));
-        return i < gwords ? __builtin_bswap32(((const HJ_GLOBAL uint32_t*)gstream)[i]) : ~0u;
+        if (kBStreamWords > 0) {
+            const uint32_t local = i - word0;
+            if (local < staged) return *(const HJ_LDS uint32_t*)(uintptr_t)(stream_base + (local << 2));
+        }
+        // unconditional load from a clamped index, selection afterwards: the request leaves at the top of the decode step and
+        // nothing waits for it before the value is consumed at the bottom
+        const uint32_t x = ((const HJ_GLOBAL uint32_t*)gstream)[min(i, gwords - 1)];
+        return i < gwords ? __builtin_bswap32(x) : ~0u;
     }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
     __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const

@@ -175,6 +175,14 @@ HJ_HD uint32_t funnel_shift_right(uint32_t high, uint32_t low, uint32_t s)  // b
 // Words are addressed through a CURSOR the environment defines (Env::cursor(word index), Env::fetch(cursor), consecutive words
 // Env::kCursorStep apart): a plain index on the host, an LDS byte address in the kernels whose lanes keep their stretch of the
 // stream in LDS -- moving on by a word is then one add, not an index-to-address computation per symbol.
+HJ_HD uint32_t extract_bits(uint32_t w, uint32_t offset, uint32_t width)  // bits [offset + width - 1 : offset] of w; offset <= 31, width <= 16
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(w, offset, width);
+#else
+    return (w >> offset) & ((1u << width) - 1u);
+#endif
+}
 struct BitReader {
     uint32_t hi;      // the next 32 bits of the stream
     uint32_t w0, w1;  // the words hi is cut from
@@ -397,33 +405,53 @@ template <class Env>
 HJ_HD int decode_block(const HuffGeom& im, const Env& env, uint32_t pos, int k, uint32_t* error)
 {
     const uint32_t tsel = env.tables(k);
-    uint32_t tcur = tsel & 0xFFFFu;
     int z = 0, dc = 0;
     uint32_t err = 0;
     BitReader br;
     br.start(env, pos);
+    // one symbol: its table entry (through the second level if the code is long), the value its nb extra bits stand for
+    // (values below 2^(nb-1) are the negative half, JPEG "EXTEND": with m = 2^nb - 1, v is in the lower half exactly when
+    // 2v <= m, and the value is then v - m), and "no such code"
+    struct Symbol {
+        uint32_t total, zadv, nb;
+        int val;
+        bool bad;
+    };
+    auto read = [&](uint32_t table, uint32_t w) {
+        uint32_t e = env.lookup1(table, w);
+        if ((e >> 9) == kZadvLong) e = env.lookup2(e, w);
+        Symbol s;
+        s.total = e & 31u;
+        s.zadv = e >> 9;
+        const uint32_t nb_raw = (e >> 5) & 15u;
+        s.bad = nb_raw >= s.total;
+        s.nb = s.bad ? 0u : nb_raw;
+        const uint32_t v = extract_bits(w, 32u - s.total, s.nb);
+        const uint32_t m = (1u << s.nb) - 1u;
+        s.val = (v << 1) <= m ? (int)v - (int)m : (int)v;
+        return s;
+    };
+    // the block's first symbol is its DC difference -- taken out of the loop, which then knows it codes coefficients
+    if (pos < im.total_bits) {
+        const uint32_t fetched = env.fetch(br.next);
+        const Symbol s = read(tsel & 0xFFFFu, br.hi);
+        err |= (uint32_t)s.bad;
+        dc = s.val;
+        pos += s.total;
+        br.consume(s.total, fetched);
+        z = (int)s.zadv;
+    }
+    const uint32_t tac = tsel >> 16;
     while (pos < im.total_bits && z < 64) {
         const uint32_t fetched = env.fetch(br.next);
-        const uint32_t w = br.hi;
-        uint32_t e = env.lookup1(tcur, w);
-        if ((e >> 9) == kZadvLong) e = env.lookup2(e, w);
-        const uint32_t total = e & 31u, zadv = e >> 9;
-        const uint32_t nb_raw = (e >> 5) & 15u;
-        const bool bad_code = nb_raw >= total;  // "no such code"
-        const uint32_t nb = bad_code ? 0u : nb_raw;
-        // nb value bits follow the code; values below 2^(nb-1) are the negative half (JPEG "EXTEND")
-        const uint32_t v = ((w << (total - nb)) >> 1) >> (31 - nb);
-        const int val = v < ((1u << nb) >> 1) ? (int)v - (int)(1u << nb) + 1 : (int)v;
-        const uint32_t zpos = (uint32_t)z + zadv - 1;
-        const bool is_dc = z == 0;
-        const bool ac = !is_dc && nb != 0;
-        err |= (uint32_t)(bad_code | (ac & (zpos > 63)));
-        dc = is_dc ? val : dc;
-        if (ac & (zpos <= 63)) env.put(env.zigzag((int)(zpos & 63)), val);
-        pos += total;
-        br.consume(total, fetched);
-        z += (int)zadv;
-        tcur = tsel >> 16;
+        const Symbol s = read(tac, br.hi);
+        const uint32_t zpos = (uint32_t)z + s.zadv - 1;
+        const bool coefficient = s.nb != 0;  // ZRL and EOB carry no value
+        err |= (uint32_t)(s.bad | (coefficient & (zpos > 63)));
+        if (coefficient & (zpos <= 63)) env.put(env.zigzag((int)(zpos & 63)), s.val);
+        pos += s.total;
+        br.consume(s.total, fetched);
+        z += (int)s.zadv;
     }
     // the stream ended inside the block, or its last symbol reaches into the slack behind the data (the host decoder calls
     // that TRUNCATED, BitReader::overran in entropy_decode.cpp)
