@@ -805,7 +805,8 @@ struct BlockEnv {
         }
         // unconditional load from a clamped index, selection afterwards: the request leaves at the top of the decode step and
         // nothing waits for it before the value is consumed at the bottom
-        const uint32_t x = ((const HJ_GLOBAL uint32_t*)gstream)[min(i, gwords - 1)];
+        // (byte offset in 32 bits -- a stream is far below 4 GB: SGPR base + VGPR offset addressing)
+        const uint32_t x = *(const HJ_GLOBAL uint32_t*)((const HJ_GLOBAL char*)gstream + (min(i, gwords - 1) << 2));
         return i < gwords ? __builtin_bswap32(x) : ~0u;
     }
     __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
