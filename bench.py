@@ -46,7 +46,7 @@ PROGRESSIVE_DEPTH = 6             # batches in flight for configs[4] (hipjpegSet
 # every batch in flight runs its entropy stage on a stream of its own; the HIP runtime multiplexes streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue run one after the other.  Read by
 # the runtime when it starts, so it is set before anything touches the GPU (a value already in the environment wins).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 
 def make_inputs():

@@ -877,13 +877,15 @@ hipjpegStatus_t DecodeBatch::enqueue_progressive(void* stream)
     ProgImage* dprog = reinterpret_cast<ProgImage*>(device_.data() + prog_desc_offset_);
     const HuffImage* dimg = reinterpret_cast<const HuffImage*>(device_.data() + huff_desc_offset_);
     const unsigned slot = (unsigned)align_up(std::max<unsigned>(prog_slot_words_, 256u), 64);
-    unsigned slots = 1;
+    unsigned slots = 1, waves = 1;  // table slots in LDS / waves per workgroup: the longest chain of the batch (one wave per scan)
     for (const ProgImage& pi : prog_images_) {
         for (int c = 0; c < 4; c++) slots = std::max<unsigned>(slots, pi.chain_len[c]);
+        for (int c = 0; c < 4; c++) waves = std::max<unsigned>(waves, pi.chain_len[c]);
         for (uint32_t k = 0; k < pi.num_scans; k++)
             if (pi.scan[k].ss == 0 && pi.scan[k].ah == 0) slots = std::max<unsigned>(slots, pi.scan[k].ncomp);
     }
-    if (launch_prog_walk(dprog, dimg, (int)prog_images_.size(), slot, std::min<unsigned>(slots, kProgMaxStages), stream) != 0)
+    if (launch_prog_walk(dprog, dimg, (int)prog_images_.size(), slot, std::min<unsigned>(slots, kProgMaxStages), std::min<unsigned>(waves, kProgMaxStages),
+                         stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_prog_replay(dprog, dimg, reinterpret_cast<const HuffUnit*>(device_.data() + prog_units_offset_), (int)prog_units_.size(), slot, stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;

@@ -489,12 +489,12 @@ __global__ __launch_bounds__(kRThreads) void prog_replay_kernel(ProgImage* __res
 
 }  // namespace
 
-int launch_prog_walk(ProgImage* images, const HuffImage* himgs, int nimages, unsigned slot_words, unsigned slots, void* stream)
+int launch_prog_walk(ProgImage* images, const HuffImage* himgs, int nimages, unsigned slot_words, unsigned slots, unsigned waves, void* stream)
 {
     if (nimages <= 0) return 0;
     // LDS decides how many walks are resident at once (a walk is one wave per scan: the chip is full of them long before it is
     // busy), so only as many table slots as the longest chain of the batch needs are reserved
-    hipLaunchKernelGGL(prog_walk_kernel, dim3(nimages * kProgChains), dim3(kWalkThreads), slot_words * 2u * slots, (hipStream_t)stream, images, himgs,
+    hipLaunchKernelGGL(prog_walk_kernel, dim3(nimages * kProgChains), dim3(64u * (waves < 1 ? 1u : waves)), slot_words * 2u * slots, (hipStream_t)stream, images, himgs,
                        slot_words);
     return (int)hipGetLastError();
 }
