@@ -559,9 +559,20 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// RIPPLE mode (the launches behind the first): nothing is handed over by the sync kernel; a group whose predecessor's last end state
+// is no longer the state it was entered with starts over at its first subsequence, and the correction runs as far as it changes
+// anything.  counters[0] counts the groups whose own last end state moved -- zero: the batch has converged.
+
+// the state in front of group `u` as it is now (0 for the first group of an image)
+__device__ __forceinline__ unsigned long long state_in_front(const unsigned long long* states, const HuffImage& im, const HuffUnit u)
+{
+    return u.first ? __hip_atomic_load(&states[im.first_subseq + u.first - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kSyncMask : 0ull;
+}
+
 // the chains of one group (sync unit `ui`), walked by one wave
+template <bool RIPPLE>
 __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const HuffImage& im, const HuffUnit u, uint32_t ui, int lane,
-                                           unsigned long long* __restrict__ states, const unsigned long long* __restrict__ incoming,
+                                           unsigned long long* __restrict__ states, unsigned long long* __restrict__ incoming,
                                            unsigned int* __restrict__ counters, const uint16_t* __restrict__ tail_tasks, uint32_t pending)
 {
     const HuffGeom geom = make_geom(im);
@@ -569,11 +580,21 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const Huff
     if (u.first >= nsub) return;
     unsigned long long* gstate = states + im.first_subseq;
     const int n_rows = (int)min((uint32_t)kSyncThreads, nsub - u.first + 1);
-    for (uint32_t i = lane; i < pending; i += 64) ws.list[0][i] = tail_tasks[(size_t)ui * kSyncThreads + i];
+    unsigned long long entering;  // the state the group is entered with ([0] of its rows)
+    if (RIPPLE) {
+        entering = state_in_front(states, im, u);
+        if (lane == 0) {
+            incoming[ui] = entering;
+            ws.list[0][0] = 1;
+        }
+    } else {
+        entering = incoming[ui];
+        for (uint32_t i = lane; i < pending; i += 64) ws.list[0][i] = tail_tasks[(size_t)ui * kSyncThreads + i];
+    }
     if (lane == 0) ws.count[0] = pending;
     wave_sync();
     const bool rst = im.restart_interval != 0;
-    const unsigned long long entering = incoming[ui];  // the state the group was entered with ([0] of its rows)
+    bool out_moved = false;  // the group's last end state changed
     const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
     const uint32_t gwords = im.stream_words;
     env.row_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&ws.rows[lane & (kTailSlots - 1)];  // word k of slot s at index k * kTailSlots + s
@@ -614,6 +635,7 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const Huff
             }
             wave_sync();  // all start states have been read
             if (busy) __hip_atomic_store(&gstate[u.first - 1 + task], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out_moved |= busy && moved && task + 1 == n_rows;
             const bool more = busy && moved && task + 1 < n_rows;
             const unsigned long long mask = __ballot(more);
             const uint32_t have = ws.count[cur ^ 1];
@@ -624,14 +646,17 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const Huff
         }
         cur ^= 1;
     }
+    const bool any_out = __ballot(out_moved) != 0;
     if (lane == 0) {
-        atomicAdd(counters + 6, (unsigned)rounds);
-        atomicMax(counters + 7, (unsigned)rounds);
+        atomicAdd(counters + (RIPPLE ? 4 : 6), (unsigned)rounds);
+        atomicMax(counters + (RIPPLE ? 5 : 7), (unsigned)rounds);
+        if (RIPPLE && any_out) atomicAdd(counters + 0, 1u);
     }
 }
 
+template <bool RIPPLE>
 __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units, int nunits,
-                                                                 unsigned long long* __restrict__ states, const unsigned long long* __restrict__ incoming,
+                                                                 unsigned long long* __restrict__ states, unsigned long long* __restrict__ incoming,
                                                                  unsigned int* __restrict__ counters, const uint16_t* __restrict__ tail_tasks,
                                                                  const uint32_t* __restrict__ tail_count)
 {
@@ -642,7 +667,25 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
     const uint32_t ui0 = blockIdx.x * kTailWaves, ui = ui0 + wave;
     const bool valid = ui < (uint32_t)nunits;
     const HuffUnit u = units[valid ? ui : ui0];
-    const uint32_t pending = valid ? tail_count[ui] : 0u;
+    // what every group of the workgroup has to do (uniform: every lane looks at all of them)
+    uint32_t todo[kTailWaves];
+#pragma unroll
+    for (int q = 0; q < kTailWaves; q++) {
+        todo[q] = 0;
+        if (ui0 + q < (uint32_t)nunits) {
+            if (RIPPLE) {
+                const HuffUnit uq = units[ui0 + q];
+                const HuffImage& iq = images[uq.image];
+                const uint32_t nsub = (iq.total_bits + kSubseqBits - 1) / kSubseqBits;
+                todo[q] = (uq.first < nsub && state_in_front(states, iq, uq) != incoming[ui0 + q]) ? 1u : 0u;
+            } else {
+                todo[q] = tail_count[ui0 + q];
+            }
+        }
+    }
+    uint32_t pending = 0;
+#pragma unroll
+    for (int q = 0; q < kTailWaves; q++) pending = q == wave ? todo[q] : pending;
     // the groups of a workgroup usually belong to one image; where an image ends inside it, its tables are staged in turn
 #pragma unroll 1
     for (int s = 0; s < kTailWaves; s++) {
@@ -652,7 +695,7 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
         uint32_t work = 0;
 #pragma unroll
         for (int q = 0; q < kTailWaves; q++)
-            if (ui0 + q < (uint32_t)nunits && units[ui0 + q].image == image) work |= tail_count[ui0 + q];
+            if (ui0 + q < (uint32_t)nunits && units[ui0 + q].image == image) work |= todo[q];
         if (work == 0) continue;  // uniform: nothing left in this image's groups
         const HuffImage& im = images[image];
         __syncthreads();  // the tables of the image before are no longer in use
@@ -667,7 +710,7 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
             env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
             env.boundaries = im.boundaries;
             env.num_boundaries = im.num_boundaries;
-            tail_group(sh.wave[wave], env, im, u, ui, lane, states, incoming, counters, tail_tasks, pending);
+            tail_group<RIPPLE>(sh.wave[wave], env, im, u, ui, lane, states, incoming, counters, tail_tasks, pending);
         }
     }
 }
@@ -1085,15 +1128,30 @@ int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, 
     return (int)hipGetLastError();
 }
 
+// HIPJPEG_RIPPLE_IN_SYNC=1: the second and later launches use the sync kernel's ripple branch as in round 1 (A/B aid)
+static bool ripple_in_tail_kernel()
+{
+    static const bool v = getenv("HIPJPEG_RIPPLE_IN_SYNC") == nullptr;
+    return v;
+}
+
 int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
                      unsigned int* changed, int first_pass, int max_rounds, uint16_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream)
 {
     if (nunits <= 0) return 0;
+    const dim3 tail_grid((nunits + kTailWaves - 1) / kTailWaves);
+    if (!first_pass && ripple_in_tail_kernel()) {
+        // corrections across group borders: the tail kernel's workgroups (little LDS, a row staged per decode) instead of the
+        // sync kernel's, which would stage 255 rows to decode one or two
+        hipLaunchKernelGGL(huff_tail_kernel<true>, tail_grid, dim3(kTailThreads), pool_bytes, (hipStream_t)stream, images, units, nunits, states, incoming,
+                           changed, nullptr, nullptr);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kSyncThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
                        first_pass, max_rounds, tail_tasks, tail_count);
     if (tail_count)
-        hipLaunchKernelGGL(huff_tail_kernel, dim3((nunits + kTailWaves - 1) / kTailWaves), dim3(kTailThreads), pool_bytes, (hipStream_t)stream, images, units,
-                           nunits, states, incoming, changed, tail_tasks, tail_count);
+        hipLaunchKernelGGL(huff_tail_kernel<false>, tail_grid, dim3(kTailThreads), pool_bytes, (hipStream_t)stream, images, units, nunits, states, incoming,
+                           changed, tail_tasks, tail_count);
     return (int)hipGetLastError();
 }
 
