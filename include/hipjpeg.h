@@ -111,6 +111,9 @@ HIPJPEG_API hipjpegStatus_t hipjpegTestSetFault(const char* site, int countdown)
 /* Test hook: how many times a plugin has reported a sample that had already been reported (must stay 0: exactly one
  * imageReady per sample, reference src/processing_results.cpp:104-115). Counted by this library's host harness. */
 HIPJPEG_API int hipjpegTestDoubleReports(void);
+/* Test hook: how many images of the handle's last settled batch the GPU entropy stage handed back to the host entropy decoder
+ * (damaged streams, and periodic streams whose corrections would have to travel through the image subsequence by subsequence). */
+HIPJPEG_API int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle);
 
 /* ---- host-only entry points (usable without a GPU) ---- */
 HIPJPEG_API hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t length, hipjpegImageInfo_t* info);

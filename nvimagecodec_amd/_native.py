@@ -79,6 +79,8 @@ def load():
     L.hipjpegDecodeBatchSubmit.argtypes = [vp, vp, vp, i32, vp, i32, ctypes.c_uint, vp]
     L.hipjpegDecodeBatchWait.argtypes = [vp, vp, i32]
     L.hipjpegSetPipelineDepth.argtypes = [vp, i32]
+    L.hipjpegTestHostFallbacks.argtypes = [vp]
+    L.hipjpegTestHostFallbacks.restype = i32
     L.hipjpegDecodeBatchEntropyStats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]
     L.hipjpegEncodeBatchDevice.argtypes = [vp, vp, vp, i32, vp, vp]
     L.hipjpegEncodeBatchRelaunch.argtypes = [vp, vp]

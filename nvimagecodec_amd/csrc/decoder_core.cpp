@@ -862,7 +862,7 @@ hipjpegStatus_t DecodeBatch::enqueue_gpu_entropy(void* stream)
     if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 1, tail_after > 0 ? tail_after : 1 << 20,
                          tail_after > 0 ? tail_tasks : nullptr, tail_after > 0 ? tail_count : nullptr, L.pool_bytes, stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
-    if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 0, 1 << 20, nullptr, nullptr, L.pool_bytes, stream) != 0)
+    if (launch_huff_sync(L.dimg, L.dunits, L.nunits, L.states, L.incoming, L.changed, 0, 1 << 20, nullptr, nullptr, L.pool_bytes, stream, 1) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
     if (!entropy_write_passes(L, stream)) return HIPJPEG_STATUS_HIP_ERROR;
     if (hipMemcpyAsync(L.host_changed, L.changed, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
@@ -963,26 +963,39 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
                 host_changed[5], host_changed[0]);
     const bool has_baseline = !huff_units_.empty();
     bool converged = has_baseline ? *host_changed == 0 : true;
+    // The ripple launch queued with the batch (pass 1) left groups whose last end state still moved: corrections that cross more
+    // than one group border.  A few more launches settle a photograph; a periodic stream (stripes, a test pattern) would need one
+    // launch per group, each a sequential walk through 255 subsequences -- those images go to the host decoder instead
+    // (HuffImage::gave_up / moved_pass say which), 25 times faster for them.
+    constexpr int kExtraRippleLaunches = 4;
+    uint32_t last_pass = 1;
+    std::vector<char> unsettled(huff_images_.size(), 0);
     if (!converged) {
-        for (int pass = 0; pass < 64 && !converged; pass++) {
+        for (int pass = 0; pass < kExtraRippleLaunches && !converged; pass++) {
             if (hipMemsetAsync(changed, 0, sizeof(unsigned int), s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-            if (launch_huff_sync(dimg, dunits, nunits, states, incoming, changed, 0, 1 << 20, nullptr, nullptr, pool_bytes, stream) != 0)
+            if (launch_huff_sync(dimg, dunits, nunits, states, incoming, changed, 0, 1 << 20, nullptr, nullptr, pool_bytes, stream, ++last_pass) != 0)
                 return HIPJPEG_STATUS_HIP_ERROR;
             if (hipMemcpyAsync(host_changed, changed, sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
             if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
             last_sync_launches_++;
             converged = *host_changed == 0;
         }
-        if (converged) {
-            // the first write passes ran on unsettled states: clear their verdicts and repeat them
-            for (size_t g = 0; g < huff_images_.size(); g++) himg[g].status = 0;
-            if (hipMemcpyAsync(dimg, himg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-            if (!write_passes()) return HIPJPEG_STATUS_HIP_ERROR;
-            if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-            if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-            redo_pixels = true;
+        // the write passes queued with the batch ran on unsettled states: fetch the flags, clear the verdicts, repeat them
+        if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        for (size_t g = 0; g < huff_to_image_.size(); g++) {
+            unsettled[g] = himg[g].gave_up != 0 || (!converged && himg[g].moved_pass == last_pass);
+            himg[g].status = 0;
         }
+        if (hipMemcpyAsync(dimg, himg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (!write_passes()) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        redo_pixels = true;
+    } else {
+        for (size_t g = 0; g < huff_to_image_.size(); g++) unsettled[g] = himg[g].gave_up != 0;  // a group ran out of rounds in the tail kernel
     }
+    host_fallback_images_ = 0;
     // The kernels could not vouch for a stream: the host entropy decoder produces either the coefficients or the precise
     // error.  (Rare path: corrupt / truncated data.)
     auto host_takes_over = [&](PlannedImage& im) -> hipjpegStatus_t {
@@ -1016,7 +1029,8 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
     for (size_t g = 0; g < huff_to_image_.size(); g++) {
         PlannedImage& im = images_[huff_to_image_[g]];
         if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
-        if (converged && himg[g].status == 0) continue;
+        if (himg[g].status == 0 && !unsettled[g]) continue;
+        host_fallback_images_++;
         const hipjpegStatus_t hs = host_takes_over(im);
         if (hs != HIPJPEG_STATUS_SUCCESS) return hs;
     }

@@ -126,6 +126,7 @@ public:
     void* last_stream() const { return last_stream_; }
     int gpu_entropy_images() const { return (int)(huff_to_image_.size() + prog_to_image_.size()); }
     int last_sync_launches() const { return last_sync_launches_; }
+    int host_fallback_images() const { return host_fallback_images_; }  // GPU-entropy images the host decoder took over in resolve()
     bool has_progressive() const { return !prog_to_image_.empty(); }
     uint64_t stream_bytes() const { return stream_bytes_total_; }
 
@@ -190,7 +191,7 @@ private:
     unsigned prog_slot_words_ = 0;
     hipjpegStatus_t enqueue_progressive(void* stream);
     uint64_t stream_bytes_total_ = 0;
-    int last_sync_launches_ = 0;
+    int last_sync_launches_ = 0, host_fallback_images_ = 0;
     unsigned sync_rounds_total_ = 0, sync_rounds_max_ = 0;  // correction rounds of the first sync launch (sum over workgroups, maximum)
     bool entropy_done_ = false;
     void* done_event_ = nullptr;  // hipEvent_t recorded after the last launch that reads this batch's buffers

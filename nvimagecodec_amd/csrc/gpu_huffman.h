@@ -21,8 +21,12 @@ int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, 
 // max_rounds / tail_tasks / tail_count: after max_rounds correction rounds the workgroup hands what is left (tail_tasks:
 // kTailTaskBytes per unit, tail_count: one uint32 per unit) to the tail kernel, launched right behind it; tail_count == nullptr:
 // the workgroup iterates to its fixpoint itself.
-int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
-                     unsigned int* changed, int first_pass, int max_rounds, uint16_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream);
+// first_pass == 0: a ripple launch (corrections across group borders), pass_id = its number (1, 2, ...): HuffImage::moved_pass
+// receives it for every image in which a group's own last end state still changed.  HuffImage::gave_up is set for images with a
+// group that exceeded its round budget (periodic streams); such images are skipped by later ripple launches.
+int launch_huff_sync(HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
+                     unsigned int* changed, int first_pass, int max_rounds, uint16_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream,
+                     unsigned pass_id = 0);
 int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages, const unsigned long long* states, uint32_t* first_block, void* stream);
 // Write pass: position kernel over the sync units, then the block kernel over block_units ({image, first MCU}, kHuffMcusPerWg
 // MCUs each).

@@ -570,10 +570,15 @@ __device__ __forceinline__ unsigned long long state_in_front(const unsigned long
 }
 
 // the chains of one group (sync unit `ui`), walked by one wave
+// Round budgets: a 1080p photo needs 11 rounds in the tail and 3 in a ripple launch at most (HIPJPEG_DEBUG_TIMING prints them); a
+// group that is not done by then sits on a periodic stream and would go on for all of its 255 subsequences, 28 us each.
+constexpr int kTailRoundBudget = 48, kRippleRoundBudget = 24;
+
 template <bool RIPPLE>
-__device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const HuffImage& im, const HuffUnit u, uint32_t ui, int lane,
+__device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, HuffImage& im, const HuffUnit u, uint32_t ui, int lane,
                                            unsigned long long* __restrict__ states, unsigned long long* __restrict__ incoming,
-                                           unsigned int* __restrict__ counters, const uint16_t* __restrict__ tail_tasks, uint32_t pending)
+                                           unsigned int* __restrict__ counters, const uint16_t* __restrict__ tail_tasks, uint32_t pending,
+                                           uint32_t pass_id)
 {
     const HuffGeom geom = make_geom(im);
     const uint32_t nsub = (geom.total_bits + kSubseqBits - 1) / kSubseqBits;
@@ -599,9 +604,14 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const Huff
     const uint32_t gwords = im.stream_words;
     env.row_base = (uint32_t)(uintptr_t)(HJ_LDS uint32_t*)&ws.rows[lane & (kTailSlots - 1)];  // word k of slot s at index k * kTailSlots + s
     int rounds = 0, cur = 0;
-    for (int round = 0; round < kSyncThreads + 2; round++) {
+    bool unfinished = false;
+    for (int round = 0;; round++) {
         const uint32_t n = ws.count[cur];
         if (n == 0) break;
+        if (round >= (RIPPLE ? kRippleRoundBudget : kTailRoundBudget)) {
+            unfinished = true;
+            break;
+        }
         rounds++;
         wave_sync();  // every lane has read the count before it is reused
         if (lane == 0) ws.count[cur ^ 1] = 0;
@@ -650,15 +660,20 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, const Huff
     if (lane == 0) {
         atomicAdd(counters + (RIPPLE ? 4 : 6), (unsigned)rounds);
         atomicMax(counters + (RIPPLE ? 5 : 7), (unsigned)rounds);
-        if (RIPPLE && any_out) atomicAdd(counters + 0, 1u);
+        if (unfinished) {
+            im.gave_up = 1;  // benign race: every writer stores the same value
+        } else if (RIPPLE && any_out) {
+            atomicAdd(counters + 0, 1u);
+            im.moved_pass = pass_id;  // (same)
+        }
     }
 }
 
 template <bool RIPPLE>
-__global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units, int nunits,
+__global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units, int nunits,
                                                                  unsigned long long* __restrict__ states, unsigned long long* __restrict__ incoming,
                                                                  unsigned int* __restrict__ counters, const uint16_t* __restrict__ tail_tasks,
-                                                                 const uint32_t* __restrict__ tail_count)
+                                                                 const uint32_t* __restrict__ tail_count, uint32_t pass_id)
 {
     __shared__ TailShared sh;
     extern __shared__ uint16_t dyn_pool[];
@@ -677,7 +692,7 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
                 const HuffUnit uq = units[ui0 + q];
                 const HuffImage& iq = images[uq.image];
                 const uint32_t nsub = (iq.total_bits + kSubseqBits - 1) / kSubseqBits;
-                todo[q] = (uq.first < nsub && state_in_front(states, iq, uq) != incoming[ui0 + q]) ? 1u : 0u;
+                todo[q] = (uq.first < nsub && iq.gave_up == 0 && state_in_front(states, iq, uq) != incoming[ui0 + q]) ? 1u : 0u;
             } else {
                 todo[q] = tail_count[ui0 + q];
             }
@@ -697,7 +712,7 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
         for (int q = 0; q < kTailWaves; q++)
             if (ui0 + q < (uint32_t)nunits && units[ui0 + q].image == image) work |= todo[q];
         if (work == 0) continue;  // uniform: nothing left in this image's groups
-        const HuffImage& im = images[image];
+        HuffImage& im = images[image];
         __syncthreads();  // the tables of the image before are no longer in use
         stage_pool<kTailThreads>(pool, im);
         stage_constants(sh.tsel, nullptr, nullptr, im, false);
@@ -710,7 +725,7 @@ __global__ __launch_bounds__(kTailThreads) void huff_tail_kernel(const HuffImage
             env.tsel = (const HJ_LDS uint32_t*)sh.tsel;
             env.boundaries = im.boundaries;
             env.num_boundaries = im.num_boundaries;
-            tail_group<RIPPLE>(sh.wave[wave], env, im, u, ui, lane, states, incoming, counters, tail_tasks, pending);
+            tail_group<RIPPLE>(sh.wave[wave], env, im, u, ui, lane, states, incoming, counters, tail_tasks, pending, pass_id);
         }
     }
 }
@@ -1135,8 +1150,9 @@ static bool ripple_in_tail_kernel()
     return v;
 }
 
-int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
-                     unsigned int* changed, int first_pass, int max_rounds, uint16_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream)
+int launch_huff_sync(HuffImage* images, const HuffUnit* units, int nunits, unsigned long long* states, unsigned long long* incoming,
+                     unsigned int* changed, int first_pass, int max_rounds, uint16_t* tail_tasks, uint32_t* tail_count, unsigned pool_bytes, void* stream,
+                     unsigned pass_id)
 {
     if (nunits <= 0) return 0;
     const dim3 tail_grid((nunits + kTailWaves - 1) / kTailWaves);
@@ -1144,14 +1160,14 @@ int launch_huff_sync(const HuffImage* images, const HuffUnit* units, int nunits,
         // corrections across group borders: the tail kernel's workgroups (little LDS, a row staged per decode) instead of the
         // sync kernel's, which would stage 255 rows to decode one or two
         hipLaunchKernelGGL(huff_tail_kernel<true>, tail_grid, dim3(kTailThreads), pool_bytes, (hipStream_t)stream, images, units, nunits, states, incoming,
-                           changed, nullptr, nullptr);
+                           changed, nullptr, nullptr, pass_id);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(huff_sync_kernel, dim3(nunits), dim3(kSyncThreads), pool_bytes, (hipStream_t)stream, images, units, states, incoming, changed,
                        first_pass, max_rounds, tail_tasks, tail_count);
     if (tail_count)
         hipLaunchKernelGGL(huff_tail_kernel<false>, tail_grid, dim3(kTailThreads), pool_bytes, (hipStream_t)stream, images, units, nunits, states, incoming,
-                           changed, tail_tasks, tail_count);
+                           changed, tail_tasks, tail_count, 0u);
     return (int)hipGetLastError();
 }
 

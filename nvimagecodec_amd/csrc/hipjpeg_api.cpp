@@ -413,6 +413,11 @@ hipjpegStatus_t hipjpegDecodeBatchEntropyStats(hipjpegHandle_t handle, int32_t* 
     });
 }
 
+int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle)
+{
+    return handle ? handle->cur().host_fallback_images() : -1;
+}
+
 // ---------------------------------------------------------------- encode
 hipjpegStatus_t hipjpegEncodeBatchDevice(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
                                          int batch_size, hipjpegStatus_t* statuses, void* stream)

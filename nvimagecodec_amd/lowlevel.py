@@ -196,6 +196,10 @@ class BatchDecoder:
     # -- pipelined: submit() returns once everything is queued; wait() returns the statuses of the oldest submitted batch.
     #    At most three batches in flight (set_pipeline_depth: up to eight).  The caller keeps jpegs and outs alive until the
     #    matching wait().
+    def host_fallbacks(self):
+        """Images of the last settled batch that the GPU entropy stage handed back to the host entropy decoder."""
+        return int(N.load().hipjpegTestHostFallbacks(self._h))
+
     def set_pipeline_depth(self, depth):
         st = N.load().hipjpegSetPipelineDepth(self._h, int(depth))
         if st:
