@@ -180,6 +180,7 @@ hipjpegStatus_t DecodeBatch::plan(const uint8_t* const* data, const size_t* leng
     // An allocation that fails costs only the images that made the arenas grow: the biggest remaining image is given up
     // (ALLOC_FAILED) and the layout is computed again without it.
     std::vector<char> give_up((size_t)std::max(n, 0), 0);
+    pool_ = pool;
     for (int attempt = 0;; attempt++) {
         const hipjpegStatus_t st = plan_once(data, lengths, n, outputs, format, flags, statuses, formats, pool, transforms, give_up);
         if (st != HIPJPEG_STATUS_ALLOC_FAILED || attempt >= 16) return st;
@@ -995,45 +996,17 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
     } else {
         for (size_t g = 0; g < huff_to_image_.size(); g++) unsettled[g] = himg[g].gave_up != 0;  // a group ran out of rounds in the tail kernel
     }
-    host_fallback_images_ = 0;
-    // The kernels could not vouch for a stream: the host entropy decoder produces either the coefficients or the precise
-    // error.  (Rare path: corrupt / truncated data.)
-    auto host_takes_over = [&](PlannedImage& im) -> hipjpegStatus_t {
-        const FrameInfo& f = im.frame;
-        std::vector<int16_t> tmp(f.total_blocks() * 64);
-        int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
-        size_t off = 0;
-        for (int c = 0; c < f.ncomp; c++) {
-            coef[c] = tmp.data() + off;
-            off += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 64;
-        }
-        EntropyStatus es = decode_coefficients(im.data, im.size, f, coef, nullptr);
-        if (es != kEntropyOk) {
-            im.status = es == kEntropyTruncated ? HIPJPEG_STATUS_TRUNCATED : HIPJPEG_STATUS_CORRUPT;
-            return HIPJPEG_STATUS_SUCCESS;
-        }
-        for (int c = 0; c < f.ncomp; c++) {
-            const size_t nblk = (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
-            std::vector<int16_t> dc(nblk);  // the kernels take this image's DC values from its compact DC plane
-            for (size_t b = 0; b < nblk; b++) {
-                dc[b] = coef[c][b * 64];
-                coef[c][b * 64] = 0;
-            }
-            if (hipMemcpy(device_.data() + im.coef_offset[c], coef[c], nblk * 128, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(work_.data() + work_dc_diff_ + im.dc_plane_offset[c], dc.data(), nblk * 2, hipMemcpyHostToDevice) != hipSuccess)
-                return HIPJPEG_STATUS_HIP_ERROR;
-        }
-        redo_pixels = true;
-        return HIPJPEG_STATUS_SUCCESS;
-    };
+    // The kernels could not vouch for a stream (corrupt / truncated data, a periodic stream): the host entropy decoder produces
+    // either the coefficients or the precise error.  Decoding runs on the batch's thread pool when there is one -- a batch of
+    // test patterns hands over every image -- a helping of images at a time; the uploads follow on this thread.
+    std::vector<int> takeover;
     for (size_t g = 0; g < huff_to_image_.size(); g++) {
-        PlannedImage& im = images_[huff_to_image_[g]];
+        const PlannedImage& im = images_[huff_to_image_[g]];
         if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
         if (himg[g].status == 0 && !unsettled[g]) continue;
-        host_fallback_images_++;
-        const hipjpegStatus_t hs = host_takes_over(im);
-        if (hs != HIPJPEG_STATUS_SUCCESS) return hs;
+        takeover.push_back(huff_to_image_[g]);
     }
+    host_fallback_images_ = (int)takeover.size();
     const ProgImage* hprog = reinterpret_cast<const ProgImage*>(pinned_.data() + prog_desc_offset_);
     if (debug_stats && !prog_to_image_.empty()) {
         const ProgImage& q0 = hprog[0];
@@ -1042,10 +1015,54 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
                     q0.scan[k].al, q0.scan[k].walk_ticks * 1e-5);
     }
     for (size_t q = 0; q < prog_to_image_.size(); q++) {
-        PlannedImage& im = images_[prog_to_image_[q]];
+        const PlannedImage& im = images_[prog_to_image_[q]];
         if (im.status != HIPJPEG_STATUS_SUCCESS || hprog[q].status == 0) continue;
-        const hipjpegStatus_t hs = host_takes_over(im);
-        if (hs != HIPJPEG_STATUS_SUCCESS) return hs;
+        takeover.push_back(prog_to_image_[q]);
+    }
+    constexpr size_t kHelping = 32;
+    for (size_t first = 0; first < takeover.size(); first += kHelping) {
+        const size_t count = std::min(kHelping, takeover.size() - first);
+        std::vector<std::vector<int16_t>> coefs(count);
+        std::vector<EntropyStatus> verdict(count, kEntropyOk);
+        auto decode_one = [&](int j) {
+            const PlannedImage& im = images_[takeover[first + j]];
+            const FrameInfo& f = im.frame;
+            coefs[j].assign(f.total_blocks() * 64, 0);
+            int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
+            size_t off = 0;
+            for (int c = 0; c < f.ncomp; c++) {
+                coef[c] = coefs[j].data() + off;
+                off += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h * 64;
+            }
+            verdict[j] = decode_coefficients(im.data, im.size, f, coef, nullptr);
+        };
+        if (pool_ && count > 1)
+            pool_->parallel_for((int)count, [&](int j, int) { decode_one(j); });
+        else
+            for (size_t j = 0; j < count; j++) decode_one((int)j);
+        for (size_t j = 0; j < count; j++) {
+            PlannedImage& im = images_[takeover[first + j]];
+            if (verdict[j] != kEntropyOk) {
+                im.status = verdict[j] == kEntropyTruncated ? HIPJPEG_STATUS_TRUNCATED : HIPJPEG_STATUS_CORRUPT;
+                continue;
+            }
+            const FrameInfo& f = im.frame;
+            size_t off = 0;
+            for (int c = 0; c < f.ncomp; c++) {
+                const size_t nblk = (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+                int16_t* coef = coefs[j].data() + off;
+                off += nblk * 64;
+                std::vector<int16_t> dc(nblk);  // the kernels take this image's DC values from its compact DC plane
+                for (size_t b = 0; b < nblk; b++) {
+                    dc[b] = coef[b * 64];
+                    coef[b * 64] = 0;
+                }
+                if (hipMemcpy(device_.data() + im.coef_offset[c], coef, nblk * 128, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(work_.data() + work_dc_diff_ + im.dc_plane_offset[c], dc.data(), nblk * 2, hipMemcpyHostToDevice) != hipSuccess)
+                    return HIPJPEG_STATUS_HIP_ERROR;
+            }
+            redo_pixels = true;
+        }
     }
     if (redo_pixels && pixels_launched_) {
         // the pixel kernels already ran on coefficients that have just been replaced

@@ -192,6 +192,7 @@ private:
     hipjpegStatus_t enqueue_progressive(void* stream);
     uint64_t stream_bytes_total_ = 0;
     int last_sync_launches_ = 0, host_fallback_images_ = 0;
+    ForkJoinPool* pool_ = nullptr;  // the pool plan() was given (resolve() decodes handed-over images on it)
     unsigned sync_rounds_total_ = 0, sync_rounds_max_ = 0;  // correction rounds of the first sync launch (sum over workgroups, maximum)
     bool entropy_done_ = false;
     void* done_event_ = nullptr;  // hipEvent_t recorded after the last launch that reads this batch's buffers
