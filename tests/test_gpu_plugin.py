@@ -340,3 +340,79 @@ def test_transcode_roundtrip_through_both_plugins(torch_mod, tmp_path):
         torch_mod.cuda.synchronize()
         ref_rgb = oracle.decode(jpeg)
         assert np.array_equal(again.cpu()._array, oracle.decode(oracle.encode(ref_rgb, "420", 95)))
+
+
+def test_planar_ycbcr_image_through_the_encoder_plugin(torch_mod):
+    """NVIMGCODEC_SAMPLEFORMAT_P_YUV + SYCC through nvimgcodecEncoderEncode (reference extensions/nvjpeg/cuda_encoder.cpp:104-115,
+    362-368): three planes at component size in one strided device buffer.  Same subsampling in and out -> the planes go into the
+    stream as they are and the file equals libjpeg-turbo's for the RGB picture the planes were made from; a different output
+    subsampling, or planes with an RGB colour spec, is refused by canEncode (no other encoder registered -> no file)."""
+    from nvimagecodec_amd import api
+    from nvimagecodec_amd.api import _api, _check, _fill_image_info
+    from nvimagecodec_amd.synth import synth_image
+    from test_gpu_encode import _planes_like_libjpeg
+    torch = torch_mod
+    lib, inst = _api()
+    rgb = synth_image(160, 96, seed=11)
+    h, w = rgb.shape[:2]
+
+    def encode(planes, in_css, out_css, color_spec, progressive=False):
+        # one device buffer, planes back to back, each with its own pitch = its width
+        flat = torch.cat([torch.from_numpy(np.ascontiguousarray(p)).reshape(-1) for p in planes]).cuda()
+        info = A.ImageInfo()
+        _fill_image_info(info, h, w, 3, A.SAMPLEFORMAT_P_YUV, color_spec, flat.data_ptr(), w, A.BUFFER_KIND_STRIDED_DEVICE,
+                         torch.cuda.current_stream().cuda_stream, planar=True, subsampling=in_css)
+        for p, plane in enumerate(planes):
+            info.plane_info[p].height, info.plane_info[p].width = plane.shape
+            info.plane_info[p].row_stride = plane.shape[1]
+        info.buffer_size = flat.numel()
+        image = C.c_void_p()
+        _check(lib.nvimgcodecImageCreate(inst, C.byref(image), C.byref(info)), "nvimgcodecImageCreate")
+        out_info = A.ImageInfo()
+        _fill_image_info(out_info, h, w, 3, A.SAMPLEFORMAT_P_YUV, color_spec, None, 0, A.BUFFER_KIND_STRIDED_HOST, None, subsampling=out_css)
+        out_info.codec_name = b"jpeg"
+        ji = A.init(A.JpegImageInfo, A.ST_JPEG_IMAGE_INFO,
+                    encoding=A.JPEG_ENCODING_PROGRESSIVE_DCT_HUFFMAN if progressive else A.JPEG_ENCODING_BASELINE_DCT)
+        out_info.struct_next = C.addressof(ji)
+        sink = {"buf": None, "size": 0}
+
+        def resize(ctx, size):
+            if sink["buf"] is None or size > len(sink["buf"]):
+                nb = C.create_string_buffer(size)
+                if sink["buf"] is not None:
+                    C.memmove(nb, sink["buf"], len(sink["buf"]))
+                sink["buf"] = nb
+            sink["size"] = size
+            return C.addressof(sink["buf"])
+
+        cb = A.ResizeBufferFn(resize)
+        cs = C.c_void_p()
+        _check(lib.nvimgcodecCodeStreamCreateToHostMem(inst, C.byref(cs), None, cb, C.byref(out_info)), "nvimgcodecCodeStreamCreateToHostMem")
+        ep = A.init(A.EncodeParams, A.ST_ENCODE_PARAMS, quality=90.0, target_psnr=50.0)
+        fut = C.c_void_p()
+        with api.Encoder(max_num_cpu_threads=2) as enc:
+            _check(lib.nvimgcodecEncoderEncode(enc._h, (C.c_void_p * 1)(image), (C.c_void_p * 1)(cs), 1, C.byref(ep), C.byref(fut)),
+                   "nvimgcodecEncoderEncode")
+            _check(lib.nvimgcodecFutureWaitForAll(fut), "nvimgcodecFutureWaitForAll")
+            st = (C.c_uint32 * 1)()
+            size = C.c_size_t()
+            lib.nvimgcodecFutureGetProcessingStatus(fut, st, C.byref(size))
+            lib.nvimgcodecFutureDestroy(fut)
+        data = C.string_at(sink["buf"], sink["size"]) if st[0] == A.PS_SUCCESS and sink["buf"] is not None else None
+        lib.nvimgcodecImageDestroy(image)
+        lib.nvimgcodecCodeStreamDestroy(cs)
+        return st[0], data
+
+    for sub, hs, vs, css in (("420", 2, 2, A.SAMPLING_420), ("422", 2, 1, A.SAMPLING_422), ("444", 1, 1, A.SAMPLING_444)):
+        planes = _planes_like_libjpeg(rgb, hs, vs)
+        st, data = encode(planes, css, css, A.COLORSPEC_SYCC)
+        assert st == A.PS_SUCCESS and data == oracle.encode(rgb, sub, 90), sub
+    planes = _planes_like_libjpeg(rgb, 2, 2)
+    st, data = encode(planes, A.SAMPLING_420, A.SAMPLING_420, A.COLORSPEC_SYCC, progressive=True)
+    assert st == A.PS_SUCCESS and b"\xff\xc2" in data[:700]
+    assert all(np.array_equal(a, b) for a, b in zip(oracle.decode_coefficients(data)[0], oracle.decode_coefficients(oracle.encode(rgb, "420", 90))[0]))
+    # resampling planar YCbCr is not offered (nor by the reference's encoder): 4:2:0 planes cannot become a 4:4:4 stream
+    st, data = encode(planes, A.SAMPLING_420, A.SAMPLING_444, A.COLORSPEC_SYCC)
+    assert st != A.PS_SUCCESS and data is None
+    st, data = encode(planes, A.SAMPLING_420, A.SAMPLING_420, A.COLORSPEC_SRGB)
+    assert st != A.PS_SUCCESS and data is None
