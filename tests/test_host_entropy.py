@@ -78,3 +78,34 @@ def test_arithmetic_and_12bit_are_unsupported():
     with pytest.raises(N.HipJpegError) as ei:
         lowlevel.get_image_info(bytes(b))
     assert ei.value.status == 3
+
+
+def test_marker_walk_at_every_alignment_with_restart_markers_fill_bytes_and_trailing_data():
+    """The parser's walk through the entropy-coded data takes 32 bytes at a time where the CPU has AVX2 (jpeg_syntax.cpp
+    find_scan_end): FFs at the last byte of a chunk, RSTn markers straddling chunks, fill bytes (FF FF) in front of a marker, a
+    file that ends inside a chunk, bytes behind EOI -- the scan's start is moved through 70 alignments by a comment segment of
+    growing length, and what comes out must be the oracle's coefficients every time (and the GPU-algorithm emulation's, which
+    uses the walk's restart positions)."""
+    from nvimagecodec_amd.synth import synth_image
+    img = synth_image(72, 40, seed=21)
+    for sub, rst in (("420", 1), ("444", 3), ("420", 0)):
+        base = oracle.encode(img, sub, 92, restart_interval=rst)
+        want, _ = oracle.decode_coefficients(base)
+        sos = base.index(b"\xff\xda")
+        for shift in range(70):
+            com = b"\xff\xfe" + (2 + shift).to_bytes(2, "big") + bytes([0x41] * shift)
+            variants = [base[:sos] + com + base[sos:]]
+            variants.append(variants[0] + b"\x00" * (shift % 37))                      # bytes behind EOI
+            if rst:
+                j = variants[0]
+                k = j.index(b"\xff\xd0", sos)                                             # fill bytes in front of the first RST0
+                variants.append(j[:k] + b"\xff\xff" + j[k:])
+            for v in variants:
+                got, _ = lowlevel.entropy_decode_host(v)
+                assert all(np.array_equal(a, b) for a, b in zip(got, want)), (sub, rst, shift)
+            emu, _ = lowlevel.entropy_decode_gpu_algorithm_host(variants[0])
+            assert all(np.array_equal(a, b[: a.shape[0], : a.shape[1]]) for a, b in zip(emu, want)), (sub, rst, shift)
+        # the file cut inside the scan: the walk ends at the end of the input, the decoder reports a truncated stream
+        for cut in range(len(base) - 40, len(base) - 2, 3):
+            with pytest.raises(N.HipJpegError):
+                lowlevel.entropy_decode_host(base[:cut])
