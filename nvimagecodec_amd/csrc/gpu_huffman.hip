@@ -570,9 +570,11 @@ __device__ __forceinline__ unsigned long long state_in_front(const unsigned long
 }
 
 // the chains of one group (sync unit `ui`), walked by one wave
-// Round budgets: a 1080p photo needs 11 rounds in the tail and 3 in a ripple launch at most (HIPJPEG_DEBUG_TIMING prints them); a
-// group that is not done by then sits on a periodic stream and would go on for all of its 255 subsequences, 28 us each.
-constexpr int kTailRoundBudget = 48, kRippleRoundBudget = 24;
+// Round budget.  A 1080p photograph at q90 needs 11 rounds in the tail and 3 in a ripple launch; noise at q98 -- long codes, few
+// symbols per subsequence, slow to fall into step -- 125 and 40 (tests/devtools/rounds_by_quality.py).  A chain that is still
+// going after 192 subsequences (a fifth of a megabit without meeting the true trajectory) sits on a periodic stream and would
+// walk through the rest of the image, 28 us per subsequence: the image is given up (the host decoder takes it).
+constexpr int kTailRoundBudget = 192, kRippleRoundBudget = 192;
 
 template <bool RIPPLE>
 __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, HuffImage& im, const HuffUnit u, uint32_t ui, int lane,

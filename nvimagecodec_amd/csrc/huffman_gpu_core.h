@@ -110,7 +110,7 @@ struct alignas(16) HuffImage {
     uint32_t restart_interval, num_boundaries;
     // Written by the tail / ripple kernels.  A periodic stream (stripes, a test pattern) can keep a decoder that started in the
     // wrong state on a stable wrong trajectory: corrections then travel through the image one subsequence at a time, strictly in
-    // sequence -- the self-synchronising scheme has nothing to offer and the host decoder is far faster.  gave_up = 1: a group of
+    // sequence -- the self-synchronising scheme has nothing to offer and the host decoder is far faster.  gave_up = 1: a chain of
     // the image exceeded its round budget; moved_pass = number of the last ripple launch in which a group's own last end state
     // still changed.  The host hands such images to the host entropy decoder instead of launching on (decoder_core.cpp resolve).
     uint32_t gave_up, moved_pass;

@@ -217,7 +217,7 @@ def test_periodic_streams_are_handed_to_the_host_decoder_not_walked_group_by_gro
     """Stripes / test patterns: every MCU codes the same bits, the stream is periodic, and a decoder that started in the wrong state can
     stay on a stable wrong trajectory -- corrections then travel through the image one subsequence after the other (one launch per
     group of 255: 33 launches and 157 ms for a 4096 x 2048 picture when this was found).  The tail / ripple kernels have a round
-    budget and resolve() a launch budget; images that exhaust them go to the host entropy decoder.  Pixels are exact either way; a
+    budget (192: noise at q98 needs 125) and resolve() a launch budget; images that exhaust them go to the host entropy decoder.  Pixels are exact either way; a
     photograph in the same batch stays on the GPU path."""
     import time
     import torch
@@ -241,4 +241,4 @@ def test_periodic_streams_are_handed_to_the_host_decoder_not_walked_group_by_gro
     s = dec.stats()
     assert s["gpu_entropy_images"] == 4 and s["sync_launches"] <= 6
     assert 1 <= dec.host_fallbacks() <= 2      # the striped pictures; never the flat one or the photograph
-    assert elapsed < 0.1, elapsed              # generous: ~20 ms with the host decoder taking the stripes
+    assert elapsed < 0.1, elapsed              # generous: ~25 ms with the host decoder taking the stripes
