@@ -582,8 +582,16 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
 // row: the wave's row buffer (word j of the subsequence at row[j * kTailSlots], kTailRowWords of them), staged by the caller
-__device__ __forceinline__ SubseqState coop_decode(const HuffGeom& geom, uint32_t pool, const HJ_LDS uint32_t* tsel, const HJ_LDS uint32_t* row,
-                                                   uint32_t row_bit0, uint32_t begin, uint32_t limit, uint32_t z, uint32_t k, uint32_t lane)
+__device__ __forceinline__ uint32_t table_changes(const HJ_LDS uint32_t* tsel, uint32_t bpm)
+{
+    uint32_t changes = 0;
+    for (uint32_t q = 0; q < bpm; q++) changes |= (uni(tsel[q]) != uni(tsel[q + 1 == bpm ? 0 : q + 1]) ? 1u : 0u) << q;
+    return changes;
+}
+
+__device__ __forceinline__ SubseqState coop_decode(const HuffGeom& geom, uint32_t pool, const HJ_LDS uint32_t* tsel, uint32_t changes,
+                                                   const HJ_LDS uint32_t* row, uint32_t row_bit0, uint32_t begin, uint32_t limit, uint32_t z, uint32_t k,
+                                                   uint32_t lane)
 {
     const uint32_t end = uni(limit < geom.total_bits ? limit : geom.total_bits);
     const uint32_t bpm = uni(geom.blocks_per_mcu);
@@ -595,8 +603,10 @@ __device__ __forceinline__ SubseqState coop_decode(const HuffGeom& geom, uint32_
         if ((e >> 9) == kZadvLong) e = *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0x1FFu) << 7) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
         return e;
     };
+    // `changes`: which MCU positions are followed by one with other tables (bit k: position k -> k + 1; table_changes()), so that
+    // the end of a block costs a bit test, not an LDS round trip; the tables in use are read again only where they change
+    uint32_t ts = uni(tsel[k]);
     while (pos < end) {
-        const uint32_t ts = uni(tsel[k]);
         // the 32 bits from bit pos + lane on
         const uint32_t b = pos + lane - row_bit0, bit = b & 31u;
         const uint32_t w0 = row[(b >> 5) * kTailSlots], w1 = row[((b >> 5) + 1) * kTailSlots];
@@ -618,9 +628,11 @@ __device__ __forceinline__ SubseqState coop_decode(const HuffGeom& geom, uint32_
             if (z >= 64) {
                 z = 0;
                 nblocks++;
+                const bool other_tables = (changes >> k) & 1u;
                 k = k + 1 == bpm ? 0 : k + 1;
-                if (uni(tsel[k]) != ts) {
+                if (other_tables) {
                     limit = 0;  // the next block uses other tables: the window's entries no longer apply
+                    ts = uni(tsel[k]);
                 } else if (rel < limit) {
                     const uint32_t d = lane_read(edc, rel);
                     rel += d & 31u;
@@ -692,6 +704,7 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, HuffImage&
         if (kCoopChains > 0 && n <= (uint32_t)kCoopChains && !rst) {
             // the few chains that are left, one after the other, each followed to its end by the whole wave (see coop_decode)
             const HJ_LDS uint32_t* row0 = (const HJ_LDS uint32_t*)&ws.rows[0];
+            const uint32_t changes = table_changes(env.tsel, uni(geom.blocks_per_mcu));
             for (uint32_t q = 0; q < n && !unfinished; q++) {
                 for (int task = (int)uni(ws.list[cur][q]);; task++) {
                     if (rounds++ >= (RIPPLE ? kRippleRoundBudget : kTailRoundBudget)) {
@@ -710,7 +723,7 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, HuffImage&
                     wave_sync();
                     const SubseqState p = unpack_state(before);
                     const unsigned long long now = pack_state(
-                        coop_decode(geom, env.pool, env.tsel, row0, word0 * 32u, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255u, p.zk >> 8, lane));
+                        coop_decode(geom, env.pool, env.tsel, changes, row0, word0 * 32u, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255u, p.zk >> 8, lane));
                     const bool moved = ((now ^ old) & kSyncMask) != 0;
                     if (lane == 0) __hip_atomic_store(&gstate[u.first - 1 + task], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     wave_sync();
