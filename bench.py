@@ -42,6 +42,10 @@ COEF_BYTES_PER_IMAGE = 6_266_880  # 48,960 blocks * 128 B
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 NUM_SOURCES = 8                   # distinct synthetic images cycled through the batch
 STEADY_PREWARM_STEPS = 40
+# BENCH_REHEARSE_ON_ONE_GPU=1: every rank on GPU 0 with a gloo process group -- a rehearsal of the N > 1 code path (spawning, sharding
+# of configs[3], NUMA split, max over ranks, the JSON line) on a box with one card.  Its figures mean nothing and the line says so.
+REHEARSAL = os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1"
+REDUCE_DEVICE = "cpu" if REHEARSAL else "cuda"  # where the max-over-ranks tensor lives (gloo reduces host tensors)
 PROGRESSIVE_DEPTH = 6             # batches in flight for configs[4] (hipjpegSetPipelineDepth): a progressive batch is one wave per scan
 # every batch in flight runs its entropy stage on a stream of its own; the HIP runtime multiplexes streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue run one after the other.  Read by
@@ -122,7 +126,7 @@ def spawn_ranks(args):
     """`python bench.py --gpus N` on its own: start N ranks, one per GPU, before any GPU call is made in this process."""
     import torch  # device_count() does not initialise the GPU
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not REHEARSAL:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node -- refusing to measure fewer than asked for")
     port = 29000 + os.getpid() % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -251,7 +255,7 @@ def config3_sharded(dec, rank, world, dist, host_threads):
         dist.barrier()
     t0 = time.perf_counter()
     one_pass()
-    t = sharding.max_over_ranks(time.perf_counter() - t0, dist, "cuda")
+    t = sharding.max_over_ranks(time.perf_counter() - t0, dist, REDUCE_DEVICE)
     mp = sum(shapes[k % 5][0] * shapes[k % 5][1] for k in order) / 1e6
     return {"workload": "configs[3]: batch=2048 mixed 480p-4K, 4:2:0/4:2:2 -> I_RGB, sharded over %d GPU(s) by sharding.shard_batch" % world,
             "images_per_s": round(total / t, 1), "mp_per_s": round(mp / t, 1), "images_this_rank": len(mine),
@@ -407,7 +411,7 @@ def main():
         spawn_ranks(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if REHEARSAL else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
@@ -425,7 +429,10 @@ def main():
     dist = None
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if REHEARSAL:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from nvimagecodec_amd.lowlevel import BatchDecoder
     from nvimagecodec_amd.sharding import max_over_ranks
@@ -467,7 +474,7 @@ def main():
         for k in range(steps):
             step(ev[k])
         barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0, dist, "cuda")
+        elapsed = max_over_ranks(time.perf_counter() - t0, dist, REDUCE_DEVICE)
         ms = [sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(steps)) / steps for i in range(3)]
         return elapsed, ms
 
@@ -510,7 +517,7 @@ def main():
         dec.wait()
         dec.wait()
         torch.cuda.synchronize()
-        t_e2e_gpu = max_over_ranks((time.perf_counter() - t0) / pipe_batches, dist, "cuda")
+        t_e2e_gpu = max_over_ranks((time.perf_counter() - t0) / pipe_batches, dist, REDUCE_DEVICE)
         del ring
         # (b) the north-star split: Huffman on the host cores, coefficients over PCIe, device stage; one batch at a time
         dec.decode(jpegs, fmt="rgb", outs=outs)
@@ -519,7 +526,7 @@ def main():
         for _ in range(2):
             dec.decode(jpegs, fmt="rgb", outs=outs)
         torch.cuda.synchronize()
-        t_e2e_cpu = max_over_ranks((time.perf_counter() - t0) / 2, dist, "cuda")
+        t_e2e_cpu = max_over_ranks((time.perf_counter() - t0) / 2, dist, REDUCE_DEVICE)
         # host entropy stage and H2D alone
         t0 = time.perf_counter()
         dec.host_stage(jpegs, outs, "rgb", fancy=True)
@@ -581,7 +588,9 @@ def main():
             "timed_region": "full decode, bitstreams resident in HBM -> RGB in HBM: GPU entropy stage (byte-stuffing removal + Huffman decode) "
                             "+ device stage (dequantize, IDCT, upsample, colour, store); host bytes -> HBM is reported under end_to_end",
             "config": {"workload": "configs[1]: batch=256 1920x1080 4:2:0 baseline JPEG -> I_RGB u8, fancy upsampling, ISLOW IDCT",
-                       "batch_per_gpu": BATCH, "parallelism": f"{world} independent per-GPU replicas, no collective",
+                       "batch_per_gpu": BATCH,
+                       "parallelism": f"{world} independent per-GPU replicas, no collective" +
+                                      (" -- REHEARSAL: all ranks share GPU 0 (BENCH_REHEARSE_ON_ONE_GPU), figures are not measurements" if REHEARSAL else ""),
                        "host_threads_per_gpu": host_threads, "numa": numa},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac, "traffic": measured_traffic(),
                          "scope": "device stage (SURVEY 8d): idct_plane_kernel + luma_color_kernel, HIP events inside the timed steps",
