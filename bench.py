@@ -39,7 +39,8 @@ BATCH = 256
 WIDTH, HEIGHT = 1920, 1080
 ALG_BYTES_PER_IMAGE = 12_487_680  # 48,960 blocks * 128 B + 1920*1080*3 B
 COEF_BYTES_PER_IMAGE = 6_266_880  # 48,960 blocks * 128 B
-HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0             # ... and what a float4 device-to-device copy reaches there ("report fraction of both")
 NUM_SOURCES = 8                   # distinct synthetic images cycled through the batch
 STEADY_PREWARM_STEPS = 40
 # BENCH_REHEARSE_ON_ONE_GPU=1: every rank on GPU 0 with a gloo process group -- a rehearsal of the N > 1 code path (spawning, sharding
@@ -595,6 +596,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac, "traffic": measured_traffic(),
                          "scope": "device stage (SURVEY 8d): idct_plane_kernel + luma_color_kernel, HIP events inside the timed steps",
                          "algorithmic_bytes_per_step": alg_bytes,
+                         "copy_rate": HBM_COPY_GBS, "frac_of_copy_rate": round(ach / HBM_COPY_GBS, 4),
                          "kernels": [{"name": "idct_plane_kernel<false>", "avg_ms": round(k1_ms, 4), "workgroups": gst["units"][0]},
                                      {"name": "luma_color_kernel<false,2,2,true>", "avg_ms": round(k2_ms, 4), "workgroups": gst["units"][1]}]},
             "entropy_stage": {"avg_ms": round(ent_ms, 4), "algorithmic_bytes_per_step": ent_bytes, "achieved_GBps": each, "frac_of_hbm_peak": efrac,
