@@ -878,16 +878,23 @@ hipjpegStatus_t DecodeBatch::enqueue_progressive(void* stream)
     ProgImage* dprog = reinterpret_cast<ProgImage*>(device_.data() + prog_desc_offset_);
     const HuffImage* dimg = reinterpret_cast<const HuffImage*>(device_.data() + huff_desc_offset_);
     const unsigned slot = (unsigned)align_up(std::max<unsigned>(prog_slot_words_, 256u), 64);
-    unsigned slots = 1, waves = 1;  // table slots in LDS / waves per workgroup: the longest chain of the batch (one wave per scan)
+    unsigned dc_slots = 1, ac_waves = 0, rings = 0;  // per workgroup (= image): DC table slots, AC scans (one wave each), hand-over rings
     for (const ProgImage& pi : prog_images_) {
-        for (int c = 0; c < 4; c++) slots = std::max<unsigned>(slots, pi.chain_len[c]);
-        for (int c = 0; c < 4; c++) waves = std::max<unsigned>(waves, pi.chain_len[c]);
+        unsigned scans = 0, handovers = 0;
+        for (int c = 0; c < 4; c++) {
+            scans += pi.chain_len[c];
+            handovers += pi.chain_len[c] > 0 ? pi.chain_len[c] - 1 : 0;
+        }
+        ac_waves = std::max(ac_waves, scans);
+        rings = std::max(rings, handovers);
         for (uint32_t k = 0; k < pi.num_scans; k++)
-            if (pi.scan[k].ss == 0 && pi.scan[k].ah == 0) slots = std::max<unsigned>(slots, pi.scan[k].ncomp);
+            if (pi.scan[k].ss == 0 && pi.scan[k].ah == 0) dc_slots = std::max<unsigned>(dc_slots, pi.scan[k].ncomp);
     }
-    if (launch_prog_walk(dprog, dimg, (int)prog_images_.size(), slot, std::min<unsigned>(slots, kProgMaxStages), std::min<unsigned>(waves, kProgMaxStages),
-                         stream) != 0)
-        return HIPJPEG_STATUS_HIP_ERROR;
+    static const bool debug_stats = getenv("HIPJPEG_DEBUG_TIMING") != nullptr;
+    if (debug_stats)
+        fprintf(stderr, "[hipjpeg] progressive walk: %zu images, %u + 1 waves per workgroup, %u table slots of %u entries, %u rings\n", prog_images_.size(),
+                ac_waves, dc_slots + ac_waves, slot, rings);
+    if (launch_prog_walk(dprog, dimg, (int)prog_images_.size(), slot, dc_slots, ac_waves, rings, stream) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_prog_replay(dprog, dimg, reinterpret_cast<const HuffUnit*>(device_.data() + prog_units_offset_), (int)prog_units_.size(), slot, stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
     if (hipMemcpyAsync(pinned_.data() + prog_desc_offset_, dprog, sizeof(ProgImage) * prog_images_.size(), hipMemcpyDeviceToHost,

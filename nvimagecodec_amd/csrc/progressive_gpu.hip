@@ -24,18 +24,24 @@ namespace {
 #define HJ_GLOBAL __attribute__((address_space(1)))
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kWalkThreads = 64 * kProgMaxStages;
+constexpr int kWalkMaxWaves = 16;  // one workgroup per image: a wave for the DC scans and one per AC scan (gpu_progressive_eligible)
+constexpr int kWalkThreads = 64 * kWalkMaxWaves;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// One workgroup walks ALL scans of an image: a wave for the DC scans, a wave per AC scan.  (A workgroup per (image, component)
+// held 16 KB of LDS for the two scans of a chroma chain as for the four of luma -- 66 KB per image, three batches filled the
+// compute units; now 27 KB per image and six batches' walks run side by side.  It did not buy throughput: with that many
+// scalar machines resident the SIMDs' instruction issue is what they share.)
+// The history bitmaps a stage hands to its successor live in rings in dynamic LDS (one ring per hand-over, behind the tables).
 struct WalkShared {
-    unsigned long long ring[kProgMaxStages - 1][kProgRing][kProgGroup];  // history bitmaps handed from stage s to stage s + 1
-    uint32_t done[kProgMaxStages];   // groups stage s has published
-    uint32_t taken[kProgMaxStages];  // groups stage s has taken over from its predecessor
+    uint32_t done[kWalkMaxWaves];   // groups the wave's scan has published
+    uint32_t taken[kWalkMaxWaves];  // groups the wave's scan has taken over from its predecessor
     uint32_t abort_flag;
 };
+typedef unsigned long long WalkRing[kProgRing][kProgGroup];
 
 // The scalar machine of prog_walk_ac (progressive_gpu_core.h) on one wave.
 struct DevWalker {
@@ -58,7 +64,9 @@ struct DevWalker {
     int nz;
     // pipeline
     WalkShared* sh;
-    int stage, last_stage;
+    bool has_prev, has_next;                 // the scan refines what another scan of the component left / is refined by another
+    HJ_LDS WalkRing* ring_in;                // history from the predecessor; ring_in + 1 = ring to the successor
+    int self;                                // this wave's index into done[] / taken[] (predecessor self - 1, successor self + 1)
     uint32_t* block_pos;
     uint32_t nblocks;
     bool aborted;
@@ -158,14 +166,14 @@ struct DevWalker {
     {
         hlo = hhi = 0;
         pos_out = 0;
-        if (stage > 0 && !aborted) {
-            if (wait_for(&sh->done[stage - 1], gi)) {
+        if (has_prev && !aborted) {
+            if (wait_for(&sh->done[self - 1], gi)) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const unsigned long long h = sh->ring[stage - 1][gi % kProgRing][lane];
+                const unsigned long long h = (*ring_in)[gi % kProgRing][lane];
                 hlo = (uint32_t)h;
                 hhi = (uint32_t)(h >> 32);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(&sh->taken[stage], gi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_store(&sh->taken[self], gi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -184,12 +192,12 @@ struct DevWalker {
     {
         const uint32_t b = gi * kProgGroup + lane;
         if (b < nblocks) ((HJ_GLOBAL uint32_t*)block_pos)[b] = pos_out;
-        if (stage < last_stage && !aborted) {
+        if (has_next && !aborted) {
             // the slot is free once the next stage has taken group gi - kProgRing
-            if (gi >= (uint32_t)kProgRing && !wait_for(&sh->taken[stage + 1], gi - kProgRing)) return;
-            sh->ring[stage][gi % kProgRing][lane] = ((unsigned long long)hhi << 32) | hlo;
+            if (gi >= (uint32_t)kProgRing && !wait_for(&sh->taken[self + 1], gi - kProgRing)) return;
+            (*(ring_in + 1))[gi % kProgRing][lane] = ((unsigned long long)hhi << 32) | hlo;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(&sh->done[stage], gi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) __hip_atomic_store(&sh->done[self], gi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __device__ __forceinline__ void zeros_build(unsigned long long z)
@@ -333,41 +341,54 @@ __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint
     return true;
 }
 
-__global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __restrict__ images, const HuffImage* __restrict__ himgs, uint32_t slot_words)
+// One workgroup per image.  Wave 0 walks the DC scans; waves 1.. take the AC scans, component after component, the scans of a
+// component in the order of the file (= pipeline stages).  Dynamic LDS: `dc_slots` table slots for the DC scans' tables, one
+// slot per AC wave, then the rings.
+__global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __restrict__ images, const HuffImage* __restrict__ himgs, uint32_t slot_words,
+                                                                 uint32_t dc_slots, uint32_t table_slots)
 {
     __shared__ WalkShared sh;
-    extern __shared__ uint16_t dyn_tables[];  // kProgMaxStages slots of slot_words entries
-    HJ_LDS uint16_t* tables = (HJ_LDS uint16_t*)dyn_tables;
-    ProgImage& im = images[blockIdx.x / kProgChains];
-    const int chain = (int)(blockIdx.x % kProgChains);
+    extern __shared__ unsigned long long dyn_lds[];  // table slots (uint16 entries), then the rings (8-byte aligned: slot_words % 64 == 0)
+    HJ_LDS uint16_t* tables = (HJ_LDS uint16_t*)dyn_lds;
+    HJ_LDS WalkRing* rings = (HJ_LDS WalkRing*)(tables + (size_t)table_slots * slot_words);
+    ProgImage& im = images[blockIdx.x];
     // the wave number is the same in every lane, but only a readfirstlane tells the compiler so: everything the walk branches
     // on derives from it (which scan, its band, its table), and must live in SGPRs
     const int wave = (int)uni(threadIdx.x >> 6);
     const uint32_t lane = lane_id();
-    if (threadIdx.x < kProgMaxStages) {
+    if (threadIdx.x < kWalkMaxWaves) {
         sh.done[threadIdx.x] = 0;
         sh.taken[threadIdx.x] = 0;
     }
     if (threadIdx.x == 0) sh.abort_flag = 0;
     __syncthreads();
     bool ok = true;
-    if (chain == 4) {
-        if (wave != 0) return;
+    if (wave == 0) {
         ok = walk_dc_chain(im, himgs, tables, slot_words, lane);
     } else {
-        const int c = chain;
-        if (c >= (int)im.ncomp || wave >= (int)im.chain_len[c]) return;
-        const ProgScan& sc = im.scan[im.chain[c][wave]];
+        // which component's chain, which stage of it; rings of the chains in front (a chain of n scans has n - 1 hand-overs)
+        int a = wave - 1, c = 0, ring_base = 0;
+        while (c < 4 && a >= (int)uni(im.chain_len[c])) {
+            const int n = (int)uni(im.chain_len[c]);
+            a -= n;
+            ring_base += n > 0 ? n - 1 : 0;
+            c++;
+        }
+        if (c >= 4 || c >= (int)im.ncomp) return;
+        const int chain_len = (int)uni(im.chain_len[c]);
+        const ProgScan& sc = im.scan[im.chain[c][a]];
         const HuffImage& hi = himgs[sc.huff_image];
-        HJ_LDS uint16_t* slot = tables + (size_t)wave * slot_words;
+        HJ_LDS uint16_t* slot = tables + (size_t)(dc_slots + (uint32_t)(wave - 1)) * slot_words;
         stage_table(slot, im.pool, sc.table[0], table_words(im.pool, sc.table[0], lane), lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         DevWalker w;
         w.lane = lane;
         w.sh = &sh;
-        w.stage = wave;
-        w.last_stage = (int)im.chain_len[c] - 1;
+        w.has_prev = a > 0;
+        w.has_next = a + 1 < chain_len;
+        w.ring_in = rings + (ring_base + a - 1);  // not dereferenced without a predecessor; ring_in + 1 = the ring to the successor
+        w.self = wave;
         w.block_pos = sc.block_pos;
         w.nblocks = sc.nblocks;
         w.aborted = false;
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         w.predecode();
         const unsigned long long t0 = wall_clock64();
         ok = prog_walk_ac(w, (int)sc.ss, (int)sc.se, (int)sc.ah, sc.nblocks, hi.total_bits);
-        if (lane == 0) im.scan[im.chain[c][wave]].walk_ticks = (uint32_t)(wall_clock64() - t0);
+        if (lane == 0) im.scan[im.chain[c][a]].walk_ticks = (uint32_t)(wall_clock64() - t0);
         if (w.aborted) ok = false;
         if (!ok && lane == 0) __hip_atomic_store(&sh.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -489,13 +510,16 @@ __global__ __launch_bounds__(kRThreads) void prog_replay_kernel(ProgImage* __res
 
 }  // namespace
 
-int launch_prog_walk(ProgImage* images, const HuffImage* himgs, int nimages, unsigned slot_words, unsigned slots, unsigned waves, void* stream)
+int launch_prog_walk(ProgImage* images, const HuffImage* himgs, int nimages, unsigned slot_words, unsigned dc_slots, unsigned ac_waves, unsigned rings,
+                     void* stream)
 {
     if (nimages <= 0) return 0;
-    // LDS decides how many walks are resident at once (a walk is one wave per scan: the chip is full of them long before it is
-    // busy), so only as many table slots as the longest chain of the batch needs are reserved
-    hipLaunchKernelGGL(prog_walk_kernel, dim3(nimages * kProgChains), dim3(64u * (waves < 1 ? 1u : waves)), slot_words * 2u * slots, (hipStream_t)stream, images, himgs,
-                       slot_words);
+    if (ac_waves + 1 > (unsigned)kWalkMaxWaves) return (int)hipErrorInvalidValue;  // gpu_progressive_eligible() keeps such files away
+    // LDS and wave slots decide how many walks are resident at once (a walk is one wave per scan: the chip is full of them long
+    // before it is busy), so a workgroup gets exactly the waves, table slots and rings the batch's images need
+    const unsigned table_slots = dc_slots + ac_waves;
+    const unsigned lds = table_slots * slot_words * 2u + rings * (unsigned)sizeof(WalkRing);
+    hipLaunchKernelGGL(prog_walk_kernel, dim3(nimages), dim3(64u * (ac_waves + 1)), lds, (hipStream_t)stream, images, himgs, slot_words, dc_slots, table_slots);
     return (int)hipGetLastError();
 }
 

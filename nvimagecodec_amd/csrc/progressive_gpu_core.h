@@ -35,6 +35,7 @@
 namespace hipjpeg {
 
 constexpr int kProgMaxScans = 24;     // scans per image the GPU path takes (libjpeg's script has 10; more -> host entropy stage)
+constexpr int kProgMaxAcScans = 15;   // AC scans of an image the walker takes (a wave each + one for the DC scans: 1024 threads)
 constexpr int kProgMaxStages = 6;     // AC scans per component = pipeline stages (= waves) of a walker workgroup
 constexpr int kProgChains = 5;        // walker workgroups per image: one per component (up to 4) + one for the DC scans
 constexpr int kProgGroup = 64;        // blocks per hand-over unit between pipeline stages (one lane per block)

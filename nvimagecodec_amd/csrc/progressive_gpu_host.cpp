@@ -103,6 +103,7 @@ bool gpu_progressive_eligible(const FrameInfo& f)
             if (w == 0 || w > (size_t)kProgTableMax) return false;
         }
     }
+    if (stages[0] + stages[1] + stages[2] + stages[3] > kProgMaxAcScans) return false;  // one wave per AC scan in the walker's workgroup
     for (int c = 0; c < f.ncomp; c++) {
         if (coef_bits[c][0] < 0) return false;  // a component without a DC scan: the host decoder reports the file as incomplete
         if ((size_t)((f.comp[c].samp_w + 7) / 8) * (size_t)((f.comp[c].samp_h + 7) / 8) >= (1u << 24)) return false;

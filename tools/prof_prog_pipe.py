@@ -16,7 +16,7 @@ batch = [prog[i % 4] for i in range(128)]
 dec = BatchDecoder(0, bench.usable_cpus())
 dec.set_pipeline_depth(depth)
 ring = [dec.allocate_outputs(batch, "rgb_planar") for _ in range(depth)]
-dec.submit(batch, ring[1], fmt="rgb_planar")
+dec.submit(batch, ring[0], fmt="rgb_planar")
 dec.wait()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
