@@ -572,7 +572,8 @@ __device__ __forceinline__ unsigned long long state_in_front(const unsigned long
 // the chains of one group (sync unit `ui`), walked by one wave
 // ---- one chain link by a whole wave ---------------------------------------------------------------------------------------------
 // The last links of a chain are one lane's work with 63 lanes idle, 28 us per subsequence: a lone wave pays 10+ cycles for every
-// dependent instruction of the decode step.  With one or two chains left the wave turns to ONE subsequence instead: lane l decodes
+// dependent instruction of the decode step.  With one or two chains left the wave turns to ONE subsequence instead
+// (cooperative_subsequence in huffman_gpu_core.h, the window below): lane l decodes
 // the symbol that WOULD start l bits behind the current position (as a DC symbol and as an AC symbol of the current MCU position:
 // two lookups per lane, all lanes at once), and the walk itself is scalar -- read the entry at the current offset, add its length,
 // track zigzag position and MCU position -- about a dozen scalar instructions per symbol instead of fifty vector ones.  Same state
@@ -582,72 +583,32 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
 // row: the wave's row buffer (word j of the subsequence at row[j * kTailSlots], kTailRowWords of them), staged by the caller
-__device__ __forceinline__ uint32_t table_changes(const HJ_LDS uint32_t* tsel, uint32_t bpm)
-{
-    uint32_t changes = 0;
-    for (uint32_t q = 0; q < bpm; q++) changes |= (uni(tsel[q]) != uni(tsel[q + 1 == bpm ? 0 : q + 1]) ? 1u : 0u) << q;
-    return changes;
-}
-
-__device__ __forceinline__ SubseqState coop_decode(const HuffGeom& geom, uint32_t pool, const HJ_LDS uint32_t* tsel, uint32_t changes,
-                                                   const HJ_LDS uint32_t* row, uint32_t row_bit0, uint32_t begin, uint32_t limit, uint32_t z, uint32_t k,
-                                                   uint32_t lane)
-{
-    const uint32_t end = uni(limit < geom.total_bits ? limit : geom.total_bits);
-    const uint32_t bpm = uni(geom.blocks_per_mcu);
-    uint32_t pos = uni(begin), nblocks = 0;
-    z = uni(z);
-    k = uni(k);
-    auto entry = [&](uint32_t table, uint32_t w) {
+// The window of cooperative_subsequence (huffman_gpu_core.h) on a wave: lane l holds the entries for bit offset l.
+// row: the wave's row buffer (word j of the subsequence at row[j * kTailSlots], kTailRowWords of them), staged by the caller.
+struct CoopWindow {
+    uint32_t pool;
+    const HJ_LDS uint32_t* tsel;
+    const HJ_LDS uint32_t* row;
+    uint32_t row_bit0, lane;
+    uint32_t edc, eac;
+    __device__ __forceinline__ uint32_t tables(uint32_t k) const { return tsel[k]; }
+    __device__ __forceinline__ uint32_t entry(uint32_t table, uint32_t w) const
+    {
         uint32_t e = *(const HJ_LDS uint16_t*)(uintptr_t)(pool + table + ((w >> (31 - kHuffFastBits)) & ((2u << kHuffFastBits) - 2)));
         if ((e >> 9) == kZadvLong) e = *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0x1FFu) << 7) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
         return e;
-    };
-    // `changes`: which MCU positions are followed by one with other tables (bit k: position k -> k + 1; table_changes()), so that
-    // the end of a block costs a bit test, not an LDS round trip; the tables in use are read again only where they change
-    uint32_t ts = uni(tsel[k]);
-    while (pos < end) {
-        // the 32 bits from bit pos + lane on
-        const uint32_t b = pos + lane - row_bit0, bit = b & 31u;
+    }
+    __device__ __forceinline__ void open(uint32_t pos, uint32_t ts)
+    {
+        const uint32_t b = pos + lane - row_bit0, bit = b & 31u;  // the 32 bits from bit pos + lane on
         const uint32_t w0 = row[(b >> 5) * kTailSlots], w1 = row[((b >> 5) + 1) * kTailSlots];
         const uint32_t w = bit ? __builtin_amdgcn_alignbit(w0, w1, 32u - bit) : w0;
-        const uint32_t edc = entry(ts & 0xFFFFu, w), eac = entry(ts >> 16, w);
-        // symbols that start at offsets below `limit` belong to this window (64 lanes, and the subsequence's end)
-        uint32_t limit = end - pos < 64u ? end - pos : 64u, rel = 0;
-        if (z == 0) {  // the window opens a block: its DC symbol
-            const uint32_t e = lane_read(edc, 0);
-            rel = e & 31u;
-            z = e >> 9;
-        }
-        // coefficients; a block that ends inside the window is followed by the next one's DC symbol right here, so that the loop
-        // itself never asks which table applies -- seven scalar instructions and one taken branch per symbol
-        while (rel < limit) {
-            const uint32_t e = lane_read(eac, rel);
-            rel += e & 31u;
-            z += e >> 9;
-            if (z >= 64) {
-                z = 0;
-                nblocks++;
-                const bool other_tables = (changes >> k) & 1u;
-                k = k + 1 == bpm ? 0 : k + 1;
-                if (other_tables) {
-                    limit = 0;  // the next block uses other tables: the window's entries no longer apply
-                    ts = uni(tsel[k]);
-                } else if (rel < limit) {
-                    const uint32_t d = lane_read(edc, rel);
-                    rel += d & 31u;
-                    z = d >> 9;
-                }
-            }
-        }
-        pos += rel;
+        edc = entry(ts & 0xFFFFu, w);
+        eac = entry(ts >> 16, w);
     }
-    SubseqState st;
-    st.end_bit = pos;
-    st.zk = (uint16_t)((k << 8) | z);
-    st.nblocks = (uint16_t)(nblocks > 0xFFFF ? 0xFFFF : nblocks);
-    return st;
-}
+    __device__ __forceinline__ uint32_t dc(uint32_t rel) const { return lane_read(edc, rel); }
+    __device__ __forceinline__ uint32_t ac(uint32_t rel) const { return lane_read(eac, rel); }
+};
 
 // Round budget.  A 1080p photograph at q90 needs 11 rounds in the tail and 3 in a ripple launch; noise at q98 -- long codes, few
 // symbols per subsequence, slow to fall into step -- 125 and 40 (tests/devtools/rounds_by_quality.py).  A chain that is still
@@ -702,9 +663,14 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, HuffImage&
         if (lane == 0) ws.count[cur ^ 1] = 0;
         wave_sync();
         if (kCoopChains > 0 && n <= (uint32_t)kCoopChains && !rst) {
-            // the few chains that are left, one after the other, each followed to its end by the whole wave (see coop_decode)
-            const HJ_LDS uint32_t* row0 = (const HJ_LDS uint32_t*)&ws.rows[0];
-            const uint32_t changes = table_changes(env.tsel, uni(geom.blocks_per_mcu));
+            // the few chains that are left, one after the other, each followed to its end by the whole wave (cooperative_subsequence)
+            CoopWindow win;
+            win.pool = env.pool;
+            win.tsel = env.tsel;
+            win.row = (const HJ_LDS uint32_t*)&ws.rows[0];
+            win.lane = (uint32_t)lane;
+            win.edc = win.eac = 0;
+            const uint32_t changes = cooperative_table_changes(win, geom.blocks_per_mcu);
             for (uint32_t q = 0; q < n && !unfinished; q++) {
                 for (int task = (int)uni(ws.list[cur][q]);; task++) {
                     if (rounds++ >= (RIPPLE ? kRippleRoundBudget : kTailRoundBudget)) {
@@ -722,8 +688,9 @@ __device__ __forceinline__ void tail_group(TailWave& ws, TailEnv env, HuffImage&
                     }
                     wave_sync();
                     const SubseqState p = unpack_state(before);
-                    const unsigned long long now = pack_state(
-                        coop_decode(geom, env.pool, env.tsel, changes, row0, word0 * 32u, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255u, p.zk >> 8, lane));
+                    win.row_bit0 = word0 * 32u;
+                    const unsigned long long now =
+                        pack_state(cooperative_subsequence(geom, win, changes, p.end_bit, (u.first + task) * kSubseqBits, p.zk & 255u, p.zk >> 8));
                     const bool moved = ((now ^ old) & kSyncMask) != 0;
                     if (lane == 0) __hip_atomic_store(&gstate[u.first - 1 + task], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     wave_sync();

@@ -252,6 +252,31 @@ struct HostEnv {
     int16_t* buf;  // block buffer: 64 coefficients
     void put(int index, int value) const { buf[index] = (int16_t)value; }
 };
+
+// The window of cooperative_subsequence (huffman_gpu_core.h) on the host: what the 64 lanes of the kernel's wave look up at once.
+struct HostWindow {
+    const HostEnv* env;
+    uint32_t edc[64], eac[64];
+    uint32_t tables(uint32_t k) const { return env->tables((int)k); }
+    uint32_t entry(uint32_t table, uint32_t w) const
+    {
+        uint32_t e = env->lookup1(table, w);
+        if ((e >> 9) == kZadvLong) e = env->lookup2(e, w);
+        return e;
+    }
+    void open(uint32_t pos, uint32_t ts)
+    {
+        for (uint32_t l = 0; l < 64; l++) {
+            const uint32_t b = pos + l, bit = b & 31u;
+            const uint32_t w0 = env->word(b >> 5), w1 = env->word((b >> 5) + 1);
+            const uint32_t w = bit ? (w0 << bit) | (w1 >> (32u - bit)) : w0;
+            edc[l] = entry(ts & 0xFFFFu, w);
+            eac[l] = entry(ts >> 16, w);
+        }
+    }
+    uint32_t dc(uint32_t rel) const { return edc[rel]; }
+    uint32_t ac(uint32_t rel) const { return eac[rel]; }
+};
 }  // namespace
 
 int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, int16_t* const coef[4], int* sync_passes)
@@ -304,6 +329,21 @@ int emulate_gpu_entropy(const uint8_t* data, size_t size, const FrameInfo& f, in
         if (passes > (int)ns + 2) return 3;  // cannot happen: the wave of corrections advances one subsequence per pass
     }
     if (sync_passes) *sync_passes = passes;
+    if (!rst) {
+        // The kernels follow the last links of a correction chain with the whole wave on one subsequence (cooperative_subsequence):
+        // the same routine, here, must reproduce the lane decoder's end state for every subsequence -- from its true start state and
+        // from the state pass 0 assumes (a trajectory through garbage).
+        HostWindow win;
+        win.env = &env;
+        const uint32_t changes = cooperative_table_changes(win, geom.blocks_per_mcu);
+        for (uint32_t i = 0; i < ns; i++) {
+            const uint32_t begin = i ? cur[i - 1].end_bit : 0u, z = i ? (cur[i - 1].zk & 255u) : 0u, k = i ? (uint32_t)(cur[i - 1].zk >> 8) : 0u;
+            if (pack_state(cooperative_subsequence(geom, win, changes, begin, (i + 1) * kSubseqBits, z, k)) != pack_state(cur[i])) return 4;
+            if (pack_state(cooperative_subsequence(geom, win, changes, i * kSubseqBits, (i + 1) * kSubseqBits, 0, 0)) !=
+                pack_state(walk(i * kSubseqBits, (i + 1) * kSubseqBits, 0, 0)))
+                return 4;
+        }
+    }
     // block index of each subsequence's first symbol
     std::vector<uint32_t> first_block(ns);
     uint32_t acc = 0;

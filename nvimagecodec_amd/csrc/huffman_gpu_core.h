@@ -337,6 +337,77 @@ HJ_HD SubseqState decode_subsequence(const HuffGeom& im, const Env& env, uint32_
     return st;
 }
 
+// One subsequence by a whole wave (the last links of a correction chain: gpu_huffman.hip coop_decode).  The WINDOW supplies, for
+// the 64 bit offsets behind a position, the table entry of the symbol that WOULD start there -- as a DC symbol and as an AC symbol
+// of one set of tables -- and this routine is the scalar walk over it: same state evolution as decode_subsequence<false>, symbol
+// by symbol (a pair step there is two steps here).  Shared by the kernel and the host emulation (gpu_huffman_host.cpp), so that the
+// CPU tests pin the window / limit / table-change logic.
+//   void     win.open(pos, ts)     entries for the symbols starting at bits pos .. pos + 63, tables ts = tdc | tac << 16
+//   uint32_t win.dc(rel), ac(rel)  the entry at offset rel < 64 (through the second level): total bits [4:0], zigzag advance [15:9]
+//   uint32_t win.tables(k)         Env::tables
+// changes: bit k set = MCU position k is followed by a position with other tables (cooperative_table_changes).
+// HJ_UNIFORM marks values that are the same in every lane of the wave (a readfirstlane on the device: they live in SGPRs).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HJ_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define HJ_UNIFORM(x) ((uint32_t)(x))
+#endif
+template <class Win>
+HJ_HD uint32_t cooperative_table_changes(const Win& win, uint32_t blocks_per_mcu)
+{
+    uint32_t changes = 0;
+    for (uint32_t q = 0; q < blocks_per_mcu; q++)
+        changes |= (HJ_UNIFORM(win.tables(q)) != HJ_UNIFORM(win.tables(q + 1 == blocks_per_mcu ? 0 : q + 1)) ? 1u : 0u) << q;
+    return changes;
+}
+template <class Win>
+HJ_HD SubseqState cooperative_subsequence(const HuffGeom& im, Win& win, uint32_t changes, uint32_t begin, uint32_t limit, uint32_t z, uint32_t k)
+{
+    const uint32_t end = HJ_UNIFORM(limit < im.total_bits ? limit : im.total_bits);
+    const uint32_t bpm = HJ_UNIFORM(im.blocks_per_mcu);
+    uint32_t pos = HJ_UNIFORM(begin), nblocks = 0;
+    z = HJ_UNIFORM(z);
+    k = HJ_UNIFORM(k);
+    uint32_t ts = HJ_UNIFORM(win.tables(k));  // read again only where the tables change
+    while (pos < end) {
+        win.open(pos, ts);
+        // symbols that start at offsets below `room` belong to this window (64 offsets, and the subsequence's end)
+        uint32_t room = end - pos < 64u ? end - pos : 64u, rel = 0;
+        if (z == 0) {  // the window opens a block: its DC symbol
+            const uint32_t e = win.dc(0);
+            rel = e & 31u;
+            z = e >> 9;
+        }
+        // coefficients; a block that ends inside the window is followed by the next one's DC symbol right here, so that the loop
+        // itself never asks which table applies -- on the device seven scalar instructions and one taken branch per symbol
+        while (rel < room) {
+            const uint32_t e = win.ac(rel);
+            rel += e & 31u;
+            z += e >> 9;
+            if (z >= 64) {
+                z = 0;
+                nblocks++;
+                const bool other_tables = (changes >> k) & 1u;
+                k = k + 1 == bpm ? 0 : k + 1;
+                if (other_tables) {
+                    room = 0;  // the next block uses other tables: the window's entries no longer apply
+                    ts = HJ_UNIFORM(win.tables(k));
+                } else if (rel < room) {
+                    const uint32_t d = win.dc(rel);
+                    rel += d & 31u;
+                    z = d >> 9;
+                }
+            }
+        }
+        pos += rel;
+    }
+    SubseqState st;
+    st.end_bit = pos;
+    st.zk = (uint16_t)((k << 8) | z);
+    st.nblocks = (uint16_t)(nblocks > 0xFFFF ? 0xFFFF : nblocks);
+    return st;
+}
+
 // Write pass, step 1 -- where the blocks start.  Same walk as decode_subsequence from the converged start state; calls
 // rec(block, pos) for every block whose first (DC) symbol starts in [begin, limit): `block` = scan-order index, `pos` = bit
 // position (behind the padding of a restart boundary, if one lies in front of it).  `block0` is the index of the block in
