@@ -33,8 +33,8 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 
 // One workgroup walks ALL scans of an image: a wave for the DC scans, a wave per AC scan.  (A workgroup per (image, component)
 // held 16 KB of LDS for the two scans of a chroma chain as for the four of luma -- 66 KB per image, three batches filled the
-// compute units; now 27 KB per image and six batches' walks run side by side.  It did not buy throughput: with that many
-// scalar machines resident the SIMDs' instruction issue is what they share.)
+// compute units; now 27 KB per image and six batches' walks run side by side.  It did not buy throughput: the walk is scalar
+// instructions, a compute unit has one scalar ALU for its four SIMDs, and three batches' walks already saturate it.)
 // The history bitmaps a stage hands to its successor live in rings in dynamic LDS (one ring per hand-over, behind the tables).
 struct WalkShared {
     uint32_t done[kWalkMaxWaves];   // groups the wave's scan has published
