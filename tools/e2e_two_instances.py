@@ -20,8 +20,10 @@ decs = [BatchDecoder(0, threads_each) for _ in range(n_inst)]
 rings = [[d.allocate_outputs(jpegs) for _ in range(3)] for d in decs]
 streams = [torch.cuda.Stream() for _ in range(n_inst)]
 for d, r, s in zip(decs, rings, streams):
-    d.submit(jpegs, r[0], stream=s)
-    d.wait()
+    for k in range(3):  # every page sizes its arenas on first use
+        d.submit(jpegs, r[k], stream=s)
+    for k in range(3):
+        d.wait()
 torch.cuda.synchronize()
 
 

@@ -16,8 +16,10 @@ batch = [prog[i % 4] for i in range(128)]
 dec = BatchDecoder(0, bench.usable_cpus())
 dec.set_pipeline_depth(depth)
 ring = [dec.allocate_outputs(batch, "rgb_planar") for _ in range(depth)]
-dec.submit(batch, ring[0], fmt="rgb_planar")
-dec.wait()
+for k in range(depth):  # every page sizes its arenas on first use
+    dec.submit(batch, ring[k], fmt="rgb_planar")
+for k in range(depth):
+    dec.wait()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(nb):
