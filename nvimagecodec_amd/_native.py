@@ -81,6 +81,7 @@ def load():
     L.hipjpegSetPipelineDepth.argtypes = [vp, i32]
     L.hipjpegTestHostFallbacks.argtypes = [vp]
     L.hipjpegTestHostFallbacks.restype = i32
+    L.hipjpegTestKernelFlavours.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     L.hipjpegDecodeBatchEntropyStats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]
     L.hipjpegEncodeBatchDevice.argtypes = [vp, vp, vp, i32, vp, vp]
     L.hipjpegEncodeBatchRelaunch.argtypes = [vp, vp]

@@ -5,13 +5,15 @@
 
 namespace hipjpeg {
 
-// `exact` selects the 32-bit-multiplier build for images flagged kFlagExactMul32 (separate kernels keep the common
-// case's register count down).
-// K1: IDCT of component blocks into u8 planes.  One WorkUnit = 256 blocks.
-int launch_idct_plane(bool exact, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+// Pass-1 arithmetic of the IDCT, chosen per image by the host (DecodeBatch::finalize): 24-bit-multiplier butterflies, the
+// 32-bit-multiplier build for images flagged kFlagExactMul32, packed int16 dot products for images flagged kFlagFitsInt16
+// (separate kernels keep the common case's register count down).
+enum PlaneFlavour { kPlaneMul24 = 0, kPlaneExact = 1, kPlanePk16 = 2, kNumPlaneFlavours = 3 };
+// K1: IDCT of component blocks into u8 planes.  One WorkUnit = 128 blocks.
+int launch_idct_plane(int pass1, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K2: fused luma IDCT + chroma upsample (factors hs x vs, 0 = no chroma) + colour conversion + store.
 // flavour: which instantiation of the fused luma kernel (decode_kernels.hip luma_color_body)
-enum LumaFlavour { kLumaMul24 = 0, kLumaExact = 1, kLumaCommon = 2, kNumLumaFlavours = 3 };
+enum LumaFlavour { kLumaMul24 = 0, kLumaExact = 1, kLumaCommon = 2, kLumaCommonPk16 = 3, kLumaPk16 = 4, kNumLumaFlavours = 5 };
 int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K3: per-pixel colour stage from planes (replication upsampling) for uncommon sampling layouts.
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);

@@ -254,10 +254,109 @@ __device__ __forceinline__ void column_pass_and_exchange(const u32x4 (&cols)[4],
         }
 }
 
+// ---- IDCT pass 1 on int16 pairs (kFlagFitsInt16) -----------------------------------------------------------------------
+// jpeg_idct_islow's column pass multiplies every input by ONE integer constant on its way to an output and only adds
+// otherwise, and the descale comes last -- before the shift it is a linear map with integer coefficients, so (mod 2^32, like
+// the butterflies above) regrouping it is exact: out[k] = (sum_i M[k][i] * d[i] + rnd) >> 11.  With the dequantized inputs
+// as int16 pairs the even part is four and the odd part eight v_dot2_i32_i16 (two products and the accumulate in one
+// instruction), plus the twelve additions of the output butterfly: 40 instructions per column with unpacking and
+// dequantization, 20 of them full-price, where the butterfly form takes 58.  Needs |coefficient x quantizer| <= 32767 for
+// every AC position (the host proves it per image from the Huffman tables or the decoded data); the DC term is added
+// exactly, as a 32-bit value, through the accumulator.
+constexpr unsigned pk16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | (((unsigned)hi & 0xFFFFu) << 16); }
+using u16x2 = __attribute__((ext_vector_type(2))) unsigned short;
+__device__ __forceinline__ unsigned pk_mul16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b)));
+}
+// a.lo * k.lo + a.hi * k.hi + acc, three-operand form pinned: left alone hipcc picks v_dot2c_i32_i16 (accumulator = destination)
+// and spends a v_mov per product on initialising it
+__device__ __forceinline__ int dot2(unsigned a, unsigned k, int acc)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ int dot2(unsigned a, unsigned k)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(k));
+    return r;
+}
+// even rows (d0,d4), (d2,d6): tmp0/tmp1 = (d0 +- d4) << 13, tmp3 = d2*(F_0_541+F_0_765) + d6*F_0_541, tmp2 = d2*F_0_541 + d6*(F_0_541-F_1_847)
+constexpr unsigned kE0p = pk16(8192, 8192), kE0m = pk16(8192, -8192);
+constexpr unsigned kE3 = pk16(F_0_541 + F_0_765, F_0_541), kE2 = pk16(F_0_541, F_0_541 - F_1_847);
+// odd rows: pairs (d1,d5) = (t3,t1) and (d3,d7) = (t2,t0) in idct8's names; T_k = the odd part's contribution to outputs 3-k / 4+k
+constexpr int kT00 = F_0_298 - F_0_899 - F_1_961 + F_1_175, kT01 = F_1_175, kT02 = F_1_175 - F_1_961, kT03 = F_1_175 - F_0_899;
+constexpr int kT10 = F_1_175, kT11 = F_2_053 - F_2_562 - F_0_390 + F_1_175, kT12 = F_1_175 - F_2_562, kT13 = F_1_175 - F_0_390;
+constexpr int kT20 = F_1_175 - F_1_961, kT21 = F_1_175 - F_2_562, kT22 = F_3_072 - F_2_562 - F_1_961 + F_1_175, kT23 = F_1_175;
+constexpr int kT30 = F_1_175 - F_0_899, kT31 = F_1_175 - F_0_390, kT32 = F_1_175, kT33 = F_1_501 - F_0_899 - F_0_390 + F_1_175;
+constexpr unsigned kOa0 = pk16(kT03, kT01), kOb0 = pk16(kT02, kT00), kOa1 = pk16(kT13, kT11), kOb1 = pk16(kT12, kT10);
+constexpr unsigned kOa2 = pk16(kT23, kT21), kOb2 = pk16(kT22, kT20), kOa3 = pk16(kT33, kT31), kOb3 = pk16(kT32, kT30);
+
+// The packed counterpart of column_pass_and_exchange.  qp: this lane's 16 quantizer pairs (DecodeComponent::qpk[p]).
+__device__ __forceinline__ void column_pass_pk16_and_exchange(const u32x4 (&cols)[4], const unsigned* __restrict__ qp, bool p, int (&rows)[4][8])
+{
+    constexpr int rnd = 1 << 10;
+    int keep[4][4], recv[4][4];
+    // the DC coefficient (lane 0, column 0, row 0) leaves the packed path: its product with the quantizer need not fit int16
+    const unsigned w00 = cols[0].x;
+    const int dcq = p ? 0 : __mul24((int)(short)(w00 & 0xFFFFu), (int)(qp[0] & 0xFFFFu));
+    const int acc_dc = (int)(((unsigned)dcq << 13) + (unsigned)rnd);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const u32x4 q4 = *reinterpret_cast<const u32x4*>(qp + j * 4);
+        unsigned w0 = cols[j].x;
+        if (j == 0) w0 = p ? w0 : (w0 & 0xFFFF0000u);
+        const unsigned D0 = pk_mul16(w0, q4.x), D1 = pk_mul16(cols[j].y, q4.y), D2 = pk_mul16(cols[j].z, q4.z), D3 = pk_mul16(cols[j].w, q4.w);
+        const unsigned E0 = lo_pair((int)D0, (int)D2), O0 = hi_pair((int)D0, (int)D2);  // (d0,d4), (d1,d5)
+        const unsigned E1 = lo_pair((int)D1, (int)D3), O1 = hi_pair((int)D1, (int)D3);  // (d2,d6), (d3,d7)
+        const int init = j == 0 ? acc_dc : rnd;
+        const int tmp0 = dot2(E0, kE0p, init), tmp1 = dot2(E0, kE0m, init);
+        const int tmp3 = dot2(E1, kE3), tmp2 = dot2(E1, kE2);
+        const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        const int T0 = dot2(O1, kOb0, dot2(O0, kOa0)), T1 = dot2(O1, kOb1, dot2(O0, kOa1));
+        const int T2 = dot2(O1, kOb2, dot2(O0, kOa2)), T3 = dot2(O1, kOb3, dot2(O0, kOa3));
+        int d[8];
+        d[0] = (tmp10 + T3) >> 11;
+        d[7] = (tmp10 - T3) >> 11;
+        d[1] = (tmp11 + T2) >> 11;
+        d[6] = (tmp11 - T2) >> 11;
+        d[2] = (tmp12 + T1) >> 11;
+        d[5] = (tmp12 - T1) >> 11;
+        d[3] = (tmp13 + T0) >> 11;
+        d[4] = (tmp13 - T0) >> 11;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            keep[i][j] = d[i];
+            recv[i][j] = pair_swap(d[7 - i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            rows[i][j] = p ? recv[i][j] : keep[i][j];
+            rows[i][4 + j] = p ? keep[i][j] : recv[i][j];
+        }
+}
+
+// MODE of the pass-1 arithmetic: 24-bit multiplier butterflies, 32-bit multiplier butterflies (kFlagExactMul32), packed int16
+// dot products (kFlagFitsInt16)
+enum Pass1 : int { kPass1Mul24 = 0, kPass1Exact = 1, kPass1Pk16 = 2 };
+template <int MODE>
+__device__ __forceinline__ void column_pass(const u32x4 (&cols)[4], const DecodeComponent& cd, bool p, int (&rows)[4][8])
+{
+    if constexpr (MODE == kPass1Pk16)
+        column_pass_pk16_and_exchange(cols, cd.qpk[p], p, rows);
+    else
+        column_pass_and_exchange<MODE == kPass1Exact>(cols, MODE == kPass1Exact ? cd.qpair_exact[p] : cd.qpair[p], p, rows);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: IDCT of 128 consecutive blocks of one component into a u8 plane (internal plane or user output).
 // ------------------------------------------------------------------------------------------------
-template <bool EXACT>
+template <int MODE>
 __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -270,7 +369,7 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
     const int b = wave_first + (lane >> 1);
     if (b >= nblocks) return;  // whole pairs leave together
     int rows[4][8];
-    column_pass_and_exchange<EXACT>(cols, EXACT ? cd.qpair_exact[p] : cd.qpair[p], p, rows);
+    column_pass<MODE>(cols, cd, p, rows);
 
     const int by = b / bw, bx = b - by * bw;
     const bool to_out = (u.mode & 0xFF) == kToOutput;
@@ -308,12 +407,12 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
     }
 }
 
-template <bool EXACT>
+template <int MODE>
 __global__ __launch_bounds__(kThreads, HJ_MIN_WAVES) void idct_plane_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
     __shared__ __attribute__((aligned(16))) char lds[4 * kBlocksPerWave * kLdsBlockStride];
     const WorkUnit u = units[blockIdx.x];
-    idct_plane_body<EXACT>(images[u.image], u, lds);
+    idct_plane_body<MODE>(images[u.image], u, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,7 +515,7 @@ constexpr int kNarrowRowBytes = 16 * 24;                // narrow tiles: 16 pixe
 //   rows are 16-byte aligned, libjpeg's default fancy upsampling.  Same arithmetic, but no wave-uniform format branches and
 //   ~20 fewer live registers (85 instead of 104 VGPRs: five waves per SIMD without spills).  The host picks the kernel per
 //   image (DecodeBatch::finalize).
-template <bool EXACT, int HS, int VS, bool COMMON>
+template <int MODE, int HS, int VS, bool COMMON>
 __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -463,7 +562,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
         }
 
         int rows[4][8];
-        column_pass_and_exchange<EXACT>(cols, EXACT ? im.comp[0].qpair_exact[p] : im.comp[0].qpair[p], p, rows);
+        column_pass<MODE>(cols, im.comp[0], p, rows);
         // additive constants of the colour conversion (kept in VGPRs: a VOP3 instruction reads one scalar operand at most)
         // (+ 128 << 16: the luma offset, see the packed colour stage below)
         const int kr = 32768 - 128 * 91881 + (128 << 16), kb = 32768 - 128 * 116130 + (128 << 16), kg = 32768 + 128 * 22554 + 128 * 46802 + (128 << 16);
@@ -638,12 +737,12 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     }
 }
 
-template <bool EXACT, int HS, int VS, bool COMMON>
+template <int MODE, int HS, int VS, bool COMMON>
 __global__ __launch_bounds__(kThreads, HJ_MIN_WAVES_LUMA) void luma_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
     __shared__ __attribute__((aligned(16))) char lds[4 * kLdsLumaWaveBytes];
     const WorkUnit u = units[blockIdx.x];
-    luma_color_body<EXACT, HS, VS, COMMON>(images[u.image], u, lds);
+    luma_color_body<MODE, HS, VS, COMMON>(images[u.image], u, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -852,30 +951,32 @@ __global__ __launch_bounds__(kThreads) void transform_kernel(const TransformImag
 
 }  // namespace
 
-int launch_idct_plane(bool exact, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+int launch_idct_plane(int pass1, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
 {
     if (nunits <= 0) return 0;
-    if (exact)
-        hipLaunchKernelGGL(idct_plane_kernel<true>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    if (pass1 == kPlaneExact)
+        hipLaunchKernelGGL(idct_plane_kernel<kPass1Exact>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    else if (pass1 == kPlanePk16)
+        hipLaunchKernelGGL(idct_plane_kernel<kPass1Pk16>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
     else
-        hipLaunchKernelGGL(idct_plane_kernel<false>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+        hipLaunchKernelGGL(idct_plane_kernel<kPass1Mul24>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
     return (int)hipGetLastError();
 }
 
-template <bool EXACT, bool COMMON>
+template <int MODE, bool COMMON>
 static int launch_luma_color_t(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, hipStream_t s)
 {
     if (hs == 0) {
         if constexpr (COMMON) return (int)hipErrorInvalidValue;  // gray sources have no colour conversion to specialise
-        else hipLaunchKernelGGL((luma_color_kernel<EXACT, 0, 0, false>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        else hipLaunchKernelGGL((luma_color_kernel<MODE, 0, 0, false>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     } else if (hs == 1 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<EXACT, 1, 1, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<MODE, 1, 1, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<EXACT, 2, 1, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<MODE, 2, 1, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<EXACT, 2, 2, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<MODE, 2, 2, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 1 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<EXACT, 1, 2, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<MODE, 1, 2, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else
         return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
@@ -885,9 +986,11 @@ int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, co
 {
     if (nunits <= 0) return 0;
     switch (flavour) {
-    case kLumaExact: return launch_luma_color_t<true, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case kLumaCommon: return launch_luma_color_t<false, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    default: return launch_luma_color_t<false, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case kLumaExact: return launch_luma_color_t<kPass1Exact, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case kLumaCommon: return launch_luma_color_t<kPass1Mul24, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case kLumaCommonPk16: return launch_luma_color_t<kPass1Pk16, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case kLumaPk16: return launch_luma_color_t<kPass1Pk16, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    default: return launch_luma_color_t<kPass1Mul24, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
     }
 }
 

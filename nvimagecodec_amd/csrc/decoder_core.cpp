@@ -368,6 +368,9 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
                     for (int r = 0; r < 8; r++) {
                         const int q = f.qtab[c][r * 8 + 4 * pp + j];
                         dc.qpair[pp][j * 8 + r] = dc.qpair_exact[pp][j * 8 + r] = (pp && (r & 1)) ? -q : q;
+                        const uint32_t q16 = (uint32_t)((pp && (r & 1)) ? -q : q) & 0xFFFFu;
+                        uint32_t& pk = dc.qpk[pp][j * 4 + (r >> 1)];
+                        pk = (r & 1) ? (pk | (q16 << 16)) : q16;
                     }
             const size_t nblk = (size_t)k.blocks_w * k.blocks_h;
             const size_t units = (nblk + kBlocksPerUnit - 1) / kBlocksPerUnit;
@@ -619,12 +622,14 @@ void DecodeBatch::entropy_stage(int i)
             for (int l = 1; l <= 16; l++) nv += t.bits[l];
             for (int v = 0; v < nv; v++) maxcat = std::max(maxcat, t.vals[v] & 15);
             im.coef_or[c] = 32767u | ((1u << maxcat) - 1);
+            im.ac_bound[c] = (1u << maxcat) - 1;
         }
         return;
     }
     int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int c = 0; c < im.frame.ncomp; c++) coef[c] = reinterpret_cast<int16_t*>(pinned_.data() + im.coef_offset[c]);
     EntropyStatus es = decode_coefficients(im.data, im.size, im.frame, coef, im.coef_or);
+    for (int c = 0; c < 4; c++) im.ac_bound[c] = im.coef_or[c];  // the OR covers the DC values too: an upper bound all the same
     switch (es) {
     case kEntropyOk: break;
     case kEntropyTruncated: im.status = HIPJPEG_STATUS_TRUNCATED; break;
@@ -638,7 +643,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
     fault_point("finalize");
     generic_units_.clear();
     cmyk_units_.clear();
-    for (int e = 0; e < 2; e++) plane_units_[e].clear();
+    for (int e = 0; e < kNumPlaneFlavours; e++) plane_units_[e].clear();
     for (int e = 0; e < kNumLumaFlavours; e++)
         for (auto& v : luma_units_[e]) v.clear();
     const int n = (int)images_.size();
@@ -656,6 +661,17 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             if ((uint64_t)im.coef_or[c] * maxq >= (1u << 21)) exact32 = true;
         }
         if (exact32) d.flags |= kFlagExactMul32;
+        // packed int16 pass 1 (decode_kernels.hip column_pass_pk16_and_exchange): every dequantized AC value must fit int16,
+        // for the quantizer and for its negation; the DC term is 32-bit arithmetic there
+        static const bool no_pk16 = getenv("HIPJPEG_NO_PK16") != nullptr;  // measurement / test aid: the butterfly flavours for every image
+        bool fits16 = !no_pk16;
+        for (int c = 0; c < f.ncomp; c++) {
+            uint32_t maxq_ac = 0;
+            for (int j = 1; j < 64; j++) maxq_ac = std::max<uint32_t>(maxq_ac, f.qtab[c][j]);
+            if ((uint64_t)im.ac_bound[c] * maxq_ac > 32767u) fits16 = false;
+        }
+        if (fits16) d.flags |= kFlagFitsInt16;
+        const int plane_flavour = fits16 ? kPlanePk16 : exact32 ? kPlaneExact : kPlaneMul24;
         const OutFormat fmt = (OutFormat)d.out_format;
         for (int c = 0; c < f.ncomp; c++) {
             const uint32_t nblk = (uint32_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
@@ -663,7 +679,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             bool to_output = (im.variant == -2) && (fmt == kOutPlanarYUV || c == 0);
             if (needs_plane || to_output) {
                 uint32_t mode = to_output ? (uint32_t)(kToOutput | (c << 8)) : (uint32_t)kToPlane;
-                for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) plane_units_[exact32].push_back(WorkUnit{(uint32_t)i, b, (uint32_t)c, mode});
+                for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) plane_units_[plane_flavour].push_back(WorkUnit{(uint32_t)i, b, (uint32_t)c, mode});
             }
         }
         if (im.variant >= 0) {
@@ -676,10 +692,10 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
                 end_col = std::min(end_col, (uint32_t)(im.transform.x1 + 7) / 8);
             }
             // the everyday configuration has a kernel of its own (decode_kernels.hip, COMMON)
-            const bool common = !exact32 && im.variant != kVarGray && d.color_model == 1 && fmt == kOutInterleavedRGB &&
+            const bool common = (fits16 || !exact32) && im.variant != kVarGray && d.color_model == 1 && fmt == kOutInterleavedRGB &&
                                 ((((uintptr_t)d.out[0]) | d.out_pitch[0]) & 15) == 0 && (d.flags & kFlagFancyUpsampling) &&
                                 (im.variant == kVar11 || im.variant == kVar12 || d.comp[1].samp_w > 2);
-            const int flavour = exact32 ? kLumaExact : common ? kLumaCommon : kLumaMul24;
+            const int flavour = fits16 ? (common ? kLumaCommonPk16 : kLumaPk16) : exact32 ? kLumaExact : common ? kLumaCommon : kLumaMul24;
             // a ragged right edge of at most half a tile (1920 pixels = 7.5 tiles) is covered by narrow tiles, 16 x 8 blocks,
             // so that no wave runs half empty
             const uint32_t span = end_col - first_col, ragged = span % kLumaTileW;
@@ -705,7 +721,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         if (!v.empty()) memcpy(base + off, v.data(), v.size() * sizeof(WorkUnit));
         off += v.size() * sizeof(WorkUnit);
     };
-    for (int e = 0; e < 2; e++) put(plane_units_[e], &unit_off_plane_[e]);
+    for (int e = 0; e < kNumPlaneFlavours; e++) put(plane_units_[e], &unit_off_plane_[e]);
     for (int e = 0; e < kNumLumaFlavours; e++)
         for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[e][k], &unit_off_luma_[e][k]);
     put(generic_units_, &unit_off_generic_);
@@ -1090,8 +1106,8 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
         fprintf(stderr, "[hipjpeg] %s units=%d -> %s\n", what, n, hipGetErrorString(e));
     };
     int rc = 0;
-    for (int e = 0; e < 2 && rc == 0 && (which < 0 || which == 0); e++) {
-        rc = launch_idct_plane(e == 1, dimg, units_at(unit_off_plane_[e]), (int)plane_units_[e].size(), stream);
+    for (int e = 0; e < kNumPlaneFlavours && rc == 0 && (which < 0 || which == 0); e++) {
+        rc = launch_idct_plane(e, dimg, units_at(unit_off_plane_[e]), (int)plane_units_[e].size(), stream);
         check("idct_plane", (int)plane_units_[e].size());
     }
     for (int e = 0; e < kNumLumaFlavours; e++)
@@ -1193,7 +1209,8 @@ void DecodeBatch::output_size(int i, int* w, int* h) const
 void DecodeBatch::stats(int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes) const
 {
     if (num_units) {
-        num_units[0] = (int32_t)(plane_units_[0].size() + plane_units_[1].size());
+        num_units[0] = 0;
+        for (int e = 0; e < kNumPlaneFlavours; e++) num_units[0] += (int32_t)plane_units_[e].size();
         num_units[1] = 0;
         for (int e = 0; e < kNumLumaFlavours; e++)
             for (const auto& v : luma_units_[e]) num_units[1] += (int32_t)v.size();

@@ -11,6 +11,7 @@
 
 #include "../../include/hipjpeg.h"
 #include "device_layout.h"
+#include "decode_kernels.h"
 #include "gpu_huffman.h"
 #include "progressive_gpu.h"
 #include "jpeg_syntax.h"
@@ -60,6 +61,7 @@ struct PlannedImage {
     size_t coef_offset[4] = {0, 0, 0, 0};  // byte offset of component c inside the staging area
     int variant = -1;                      // KernelVariant, or -1 = generic colour path, -2 = planes-to-output only, -3 = CMYK / YCCK
     uint32_t coef_or[4] = {0, 0, 0, 0};    // OR of |coefficient| per component (from the entropy stage)
+    uint32_t ac_bound[4] = {32767, 32767, 32767, 32767};  // upper bound of |AC coefficient| per component (packed IDCT pass 1 decision)
     // GPU entropy decoding (flag HIPJPEG_FLAG_GPU_HUFFMAN and an eligible stream): the host only destuffs the scan
     bool gpu_entropy = false;
     int huff_index = -1;          // index into the HuffImage array
@@ -129,6 +131,14 @@ public:
     int host_fallback_images() const { return host_fallback_images_; }  // GPU-entropy images the host decoder took over in resolve()
     bool has_progressive() const { return !prog_to_image_.empty(); }
     uint64_t stream_bytes() const { return stream_bytes_total_; }
+    void flavour_units(int32_t plane_units[kNumPlaneFlavours], int32_t luma_units[kNumLumaFlavours]) const
+    {
+        for (int e = 0; e < kNumPlaneFlavours; e++) plane_units[e] = (int32_t)plane_units_[e].size();
+        for (int e = 0; e < kNumLumaFlavours; e++) {
+            luma_units[e] = 0;
+            for (const auto& v : luma_units_[e]) luma_units[e] += (int32_t)v.size();
+        }
+    }
 
     int size() const { return (int)images_.size(); }
     const PlannedImage& image(int i) const { return images_[i]; }
@@ -143,9 +153,9 @@ private:
     std::vector<PlannedImage> images_;
     std::vector<DecodeImage> desc_;  // host copy (device pointers inside)
     // index [0] = 24-bit multiplier kernels, [1] = exact 32-bit multiplier kernels
-    std::vector<WorkUnit> plane_units_[2], luma_units_[3][kNumLumaVariants], generic_units_, cmyk_units_;  // luma: [LumaFlavour]
+    std::vector<WorkUnit> plane_units_[kNumPlaneFlavours], luma_units_[kNumLumaFlavours][kNumLumaVariants], generic_units_, cmyk_units_;  // luma: [LumaFlavour]
     size_t desc_offset_ = 0, units_offset_ = 0, coef_offset_ = 0, staging_bytes_ = 0, plane_bytes_ = 0;
-    size_t unit_off_plane_[2] = {0, 0}, unit_off_luma_[3][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0, unit_off_cmyk_ = 0;
+    size_t unit_off_plane_[kNumPlaneFlavours] = {0}, unit_off_luma_[kNumLumaFlavours][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0, unit_off_cmyk_ = 0;
     uint64_t coef_bytes_ = 0, output_bytes_ = 0;
     bool finalized_ = false;
     // ---- GPU entropy stage

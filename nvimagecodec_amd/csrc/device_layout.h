@@ -27,6 +27,7 @@ enum ImageFlags : uint8_t {
     kFlagFancyUpsampling = 1,  // libjpeg do_fancy_upsampling
     kFlagExactMul32 = 2,       // coefficient range too wide for 24-bit multiplies in IDCT pass 1
     kFlagAdobeMarker = 4,      // the file carries an Adobe APP14 segment (selects the reference's CMYK -> RGB formula)
+    kFlagFitsInt16 = 8,        // every dequantized AC coefficient provably fits int16: IDCT pass 1 runs on packed pairs (v_dot2_i32_i16)
 };
 
 // Per-component part of the descriptor.  Kept as one aligned record per component (rather than parallel arrays inside
@@ -49,6 +50,10 @@ struct alignas(16) DecodeComponent {
     // qpair serves both the 24-bit-multiplier kernels and the exact ones (same values).
     int32_t qpair[2][32];
     int32_t qpair_exact[2][32];
+    // The same quantizers as int16 pairs for the packed column pass (kFlagFitsInt16): qpk[p][j*4 + i] = q(row 2i, column 4p+j) in
+    // the low half, q(row 2i+1, column 4p+j) in the high half (negated for p == 1, as above) -- the layout of a block's 16-byte
+    // column chunk, so that ONE v_pk_mul_lo_u16 dequantizes two coefficients.
+    uint32_t qpk[2][16];
 };
 
 struct alignas(16) DecodeImage {

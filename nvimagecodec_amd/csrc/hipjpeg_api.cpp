@@ -418,6 +418,15 @@ int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle)
     return handle ? handle->cur().host_fallback_images() : -1;
 }
 
+hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[3], int32_t luma_units[5])
+{
+    return guarded([&]() -> hipjpegStatus_t {
+    if (!handle || !plane_units || !luma_units) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    handle->cur().flavour_units(plane_units, luma_units);
+    return HIPJPEG_STATUS_SUCCESS;
+    });
+}
+
 // ---------------------------------------------------------------- encode
 hipjpegStatus_t hipjpegEncodeBatchDevice(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
                                          int batch_size, hipjpegStatus_t* statuses, void* stream)

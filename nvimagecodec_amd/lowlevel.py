@@ -200,6 +200,15 @@ class BatchDecoder:
         """Images of the last settled batch that the GPU entropy stage handed back to the host entropy decoder."""
         return int(N.load().hipjpegTestHostFallbacks(self._h))
 
+    def kernel_flavours(self):
+        """(plane_units[3], luma_units[5]) of the current batch: which arithmetic its images were given (hipjpegTestKernelFlavours)."""
+        import ctypes
+        a, b = (ctypes.c_int32 * 3)(), (ctypes.c_int32 * 5)()
+        st = N.load().hipjpegTestKernelFlavours(self._h, a, b)
+        if st:
+            raise N.HipJpegError(st, "hipjpegTestKernelFlavours")
+        return list(a), list(b)
+
     def set_pipeline_depth(self, depth):
         st = N.load().hipjpegSetPipelineDepth(self._h, int(depth))
         if st:

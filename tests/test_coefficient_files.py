@@ -1,0 +1,85 @@
+"""Files written from chosen coefficients (tests/helpers/jpeg_from_coefficients.py): the writer is pinned against the oracle's entropy
+decoder (same coefficients back) and -- where Pillow is importable -- the oracle's pixels against the real libjpeg-turbo on these
+files, whose dequantized values sit at the edges where the GPU kernels change arithmetic (packed int16 pass 1 up to
+|coefficient x quantizer| = 32767, 24-bit multipliers above, 32-bit multipliers beyond 2^21)."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle  # noqa: E402
+from tests.helpers import jpeg_from_coefficients as jc  # noqa: E402
+
+CASES = [  # (name, sampling, quantizer, extreme magnitude)
+    ("gray_q32_1023", [(1, 1)], 32, 1023),          # 32,736: the largest product the packed pass takes with Annex K tables
+    ("gray_q33_1023", [(1, 1)], 33, 1023),          # 33,759: one past it -> butterflies on the 24-bit multiplier
+    ("gray_q255_1023", [(1, 1)], 255, 1023),        # 260,865
+    ("420_q32_1023", [(2, 2), (1, 1), (1, 1)], 32, 1023),
+    ("420_q33_1023", [(2, 2), (1, 1), (1, 1)], 33, 1023),
+    ("422_q16_1023", [(2, 1), (1, 1), (1, 1)], 16, 1023),
+    ("444_q1_1023", [(1, 1), (1, 1), (1, 1)], 1, 1023),
+    ("440_q32_1000", [(1, 2), (1, 1), (1, 1)], 32, 1000),
+]
+
+
+# the same layouts with every sample inside the range an 8-bit picture can take by a wide margin (|sample - 128| < 512, workspace values
+# far inside int16): here libjpeg-turbo's C and SIMD IDCTs agree, and Pillow's build of it pins the oracle
+IN_GAMUT = [
+    ("gray_q32_e12", [(1, 1)], 32, 12),
+    ("gray_q1_e380", [(1, 1)], 1, 380),
+    ("420_q32_e12", [(2, 2), (1, 1), (1, 1)], 32, 12),
+    ("420_q3_e120", [(2, 2), (1, 1), (1, 1)], 3, 120),
+    ("422_q16_e24", [(2, 1), (1, 1), (1, 1)], 16, 24),
+    ("444_q2_e190", [(1, 1), (1, 1), (1, 1)], 2, 190),
+    ("440_q8_e48", [(1, 2), (1, 1), (1, 1)], 8, 48),
+]
+
+
+def make_case(name, sampling, q, extreme, width=83, height=61):
+    rng = np.random.default_rng(sum(map(ord, name)))
+    in_gamut = "_e" in name
+    coefs = jc.random_coefficients(rng, width, height, sampling, extreme, small=max(1, 32 // q) if in_gamut else 3, dc=30 if in_gamut else 60)
+    qt = [np.full(64, q, dtype=np.int32) for _ in sampling]
+    for t in qt:
+        t[0] = min(q, 16)  # a DC quantizer of its own: the DC term takes a separate route in the packed pass
+    return jc.write_baseline(width, height, sampling, coefs, qt), coefs, qt
+
+
+@pytest.mark.parametrize("case", CASES + IN_GAMUT, ids=[c[0] for c in CASES + IN_GAMUT])
+def test_writer_round_trips_through_the_oracle_entropy_decoder(case):
+    data, coefs, qt = make_case(*case)
+    got, qts = oracle.decode_coefficients(data)
+    for c in range(len(coefs)):
+        assert np.array_equal(got[c].astype(np.int32), coefs[c]), case[0]
+        assert np.array_equal(qts[c].astype(np.int32), qt[c])
+
+
+@pytest.mark.parametrize("case", IN_GAMUT, ids=[c[0] for c in IN_GAMUT])
+def test_oracle_matches_libjpeg_turbo_on_coefficient_files(case):
+    """Out of gamut (CASES) there is nothing to pin against: libjpeg-turbo's own two IDCTs part ways -- jidctint.c indexes the range-limit
+    table modulo 1024 and keeps 32-bit intermediates, the SIMD builds (what Pillow ships) add coefficients as int16 and pack the
+    workspace with saturation.  The oracle and the kernels follow jidctint.c there; `test_simd_and_c_idct_part_ways_out_of_gamut` records it."""
+    Image = pytest.importorskip("PIL.Image")
+    data, _, _ = make_case(*case)
+    im = Image.open(io.BytesIO(data))
+    im.draft = lambda *a, **k: None
+    ref = np.asarray(im.convert("RGB") if im.mode != "L" else im)
+    if case[1] == [(1, 1)]:
+        assert np.array_equal(oracle.decode(data, oracle.FMT_GRAY), ref)
+    else:
+        assert np.array_equal(oracle.decode(data), ref)
+
+
+def test_simd_and_c_idct_part_ways_out_of_gamut():
+    """Documents WHY the out-of-gamut cases are pinned by the oracle alone: on a file whose samples leave the 10-bit range of the
+    range-limit table the SIMD build of libjpeg-turbo (Pillow's) and the jidctint.c restatement give different pictures."""
+    Image = pytest.importorskip("PIL.Image")
+    data, _, _ = make_case(*CASES[0])
+    ref = np.asarray(Image.open(io.BytesIO(data)))
+    got = oracle.decode(data, oracle.FMT_GRAY)
+    if np.array_equal(got, ref):
+        pytest.skip("this libjpeg-turbo build runs the C IDCT (no SIMD): the two agree here")
+    assert got.shape == ref.shape

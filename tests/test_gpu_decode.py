@@ -194,3 +194,27 @@ def test_extreme_coefficients_take_the_exact_multiplier_path(dec):
             outs, _ = dec.decode([j])
             _sync()
             assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(j)), (q, sub)
+
+
+def test_coefficient_files_on_each_pass1_arithmetic(dec):
+    """Files written from chosen coefficients (tests/test_coefficient_files.py): dequantized AC values of exactly 32,736 (the packed
+    int16 pass 1 must take them: kernel_flavours says so), one quantizer step further (butterflies), far beyond (24/32-bit multipliers),
+    and in-gamut files pinned by the real libjpeg-turbo -- GPU and host entropy stages, interleaved / planar / gray outputs, bit-exact
+    against the oracle."""
+    from test_coefficient_files import CASES, IN_GAMUT, make_case
+    for case in CASES + IN_GAMUT:
+        data = make_case(*case)[0]
+        for gh in (True, False):
+            for fmt in ("rgb", "rgb_planar", "y"):
+                outs, st = dec.decode([data], fmt=fmt, gpu_huffman=gh)
+                _sync()
+                plane, luma = dec.kernel_flavours()
+                got = outs[0].cpu().numpy()
+                ref = oracle.decode(data, oracle.FMT_GRAY if fmt == "y" else oracle.FMT_RGB)
+                if fmt == "rgb_planar":
+                    ref = ref.transpose(2, 0, 1)
+                assert np.array_equal(got, ref), (case[0], gh, fmt)
+                if gh:  # the table bound decides for GPU-decoded streams: 1023 x the largest AC quantizer
+                    packed = 1023 * case[2] <= 32767
+                    assert (plane[2] + luma[3] + luma[4] > 0) == packed, (case[0], fmt, plane, luma)
+                    assert (plane[0] + plane[1] + luma[0] + luma[1] + luma[2] > 0) == (not packed), (case[0], fmt, plane, luma)
