@@ -512,7 +512,7 @@ def main():
         # ---- end to end from HOST bytes (PCIe inclusive; never `value`)
         # (a) pipelined GPU-entropy path: header parse + staging + H2D of the bitstreams + every kernel, three batches in flight
         ring = [outs, dec.allocate_outputs(jpegs, "rgb"), dec.allocate_outputs(jpegs, "rgb")]
-        pipe_batches = 24
+        pipe_batches = 48
         for k in range(3):  # warm-up: every one of the three pages sizes its pinned and device arenas on first use (11-15 ms each)
             dec.submit(jpegs, ring[k])
         for k in range(3):

@@ -160,7 +160,8 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchTransfer(hipjpegHandle_t handle, v
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDevice(hipjpegHandle_t handle, void* stream);
 /* One kernel family of the device stage at a time (0 = idct_plane, 1 = luma_color, 2 = generic_color, 3 = GPU entropy stage
  * followed by the blocking read-back of its verdicts, 4 = geometry pass, 6 = GPU entropy stage enqueued only: its verdicts
- * are settled by the next hipjpegDecodeBatchGetStatuses), so a caller can bracket each with events.
+ * are settled by the next hipjpegDecodeBatchGetStatuses, 7 = idct_plane and luma_color alternating over slices of
+ * HIPJPEG_PIXEL_CHUNK images -- a measurement aid), so a caller can bracket each with events.
  * hipjpegDecodeBatchDevice == entropy (if any image uses it), then 0, 1, 2, 4. */
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handle, int which, void* stream);
 /* Pipelined submission.  Submit = host stage + H2D copy (on an internal copy stream) + every kernel on `stream`, without

@@ -1106,6 +1106,31 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
         fprintf(stderr, "[hipjpeg] %s units=%d -> %s\n", what, n, hipGetErrorString(e));
     };
     int rc = 0;
+    if (which == 7) {
+        // measurement aid: K1 and K2 alternate over slices of HIPJPEG_PIXEL_CHUNK images, so that a slice's chroma
+        // planes are still in the 256 MB Infinity Cache when its K2 reads them -- DESIGN.md 3.1 has what it measured
+        static const int chunk = getenv("HIPJPEG_PIXEL_CHUNK") ? std::max(1, atoi(getenv("HIPJPEG_PIXEL_CHUNK"))) : 16;
+        auto slice = [](const std::vector<WorkUnit>& v, uint32_t a, uint32_t b, size_t* first) {
+            auto lo = std::lower_bound(v.begin(), v.end(), a, [](const WorkUnit& u, uint32_t x) { return u.image < x; });
+            auto hi = std::lower_bound(lo, v.end(), b, [](const WorkUnit& u, uint32_t x) { return u.image < x; });
+            *first = (size_t)(lo - v.begin());
+            return (int)(hi - lo);
+        };
+        const uint32_t n = (uint32_t)images_.size();
+        for (uint32_t a = 0; a < n && rc == 0; a += (uint32_t)chunk) {
+            size_t first = 0;
+            for (int e = 0; e < kNumPlaneFlavours && rc == 0; e++) {
+                const int cnt = slice(plane_units_[e], a, a + chunk, &first);
+                rc = launch_idct_plane(e, dimg, units_at(unit_off_plane_[e]) + first, cnt, stream);
+            }
+            for (int e = 0; e < kNumLumaFlavours; e++)
+                for (int k = 0; k < kNumLumaVariants && rc == 0; k++) {
+                    const int cnt = slice(luma_units_[e][k], a, a + chunk, &first);
+                    rc = launch_luma_color(e, hs[k], vs[k], dimg, units_at(unit_off_luma_[e][k]) + first, cnt, stream);
+                }
+        }
+        return rc;
+    }
     for (int e = 0; e < kNumPlaneFlavours && rc == 0 && (which < 0 || which == 0); e++) {
         rc = launch_idct_plane(e, dimg, units_at(unit_off_plane_[e]), (int)plane_units_[e].size(), stream);
         check("idct_plane", (int)plane_units_[e].size());

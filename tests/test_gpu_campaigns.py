@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.parametrize("script,seed,rounds", [("fuzz_gpu.py", 2, 2), ("fuzz_damage.py", 3, 4), ("fuzz_geometry.py", 4, 2), ("fuzz_outputs.py", 5, 2),
-                                                ("fuzz_encode.py", 6, 4), ("fuzz_plugin.py", 7, 3)])
+                                                ("fuzz_encode.py", 6, 4), ("fuzz_plugin.py", 7, 3), ("fuzz_pass1.py", 8, 2)])
 def test_campaign(script, seed, rounds, monkeypatch, capsys):
     monkeypatch.setattr(sys, "argv", [script, str(seed), str(rounds)])
     runpy.run_path(os.path.join(HERE, "campaigns", script), run_name="__main__")

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
-#define N 4096
+#define N 16384
 
 __global__ void k_salu(unsigned* out, unsigned seed)
 {
@@ -119,7 +119,28 @@ int main()
         }
         printf("%-52s %8.1f clock64 ticks per element (loop overhead included)\n", e.name, h[1] / (double)(N * 8));
     }
-    unsigned long long c0, c1;
-    (void)c0; (void)c1;
+    // The same chains with MANY waves resident: what a compute unit's one scalar unit delivers when the progressive walker's waves of
+    // several batches share it.  One workgroup = one wave; `waves per CU` x 256 workgroups (the dispatcher spreads them evenly).
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    struct { const char* name; void (*k)(unsigned*, unsigned); int per_iter; } ms[] = {{"dependent SALU", k_salu, 8}, {"readlane -> 2 SALU -> readlane", k_readlane, 24},
+        {"dependent VALU", k_valu, 8}};
+    for (auto& e : ms)
+        for (int waves : {1, 2, 4, 8, 16, 32}) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                hipEventRecord(e0, 0);
+                hipLaunchKernelGGL(e.k, dim3(256 * waves), dim3(64), 0, 0, d, 12345u);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                float t;
+                hipEventElapsedTime(&t, e0, e1);
+                best = t < best ? t : best;
+            }
+            const double instr = (double)N * e.per_iter * 256.0 * waves;
+            printf("%-34s %2d waves per CU: %7.3f ms, %6.2f G instructions/s per CU = %.2f per cycle per CU at 2.4 GHz\n", e.name, waves, best,
+                   instr / (best * 1e-3) / 256.0 / 1e9, instr / (best * 1e-3) / 256.0 / 2.4e9);
+        }
     return 0;
 }
