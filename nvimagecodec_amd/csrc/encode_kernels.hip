@@ -299,44 +299,10 @@ __global__ __launch_bounds__(kThreads) void forward_kernel(const EncodeImage* __
 // kernel above holds a whole block in registers (240 VGPRs, two waves per SIMD) and stays for every other layout.
 //   lane p of a pair loads and colour-converts four pixel rows of the block -- lane 0 rows 0,1,2,3, lane 1 rows 7,6,5,4 --
 //   downsamples its chroma patch into the LDS chroma tile, runs the FDCT row pass on its four rows and leaves them in the
-//   block's LDS slot as int16; after the hand-off it reads columns 4p..4p+3 of all eight rows back, lane 1 from the bottom
-//   row up: reversing the input of the 1-D FDCT leaves the even outputs alone and negates the odd ones, which lane 1 undoes
-//   with a rounding term one smaller and a sign flip after the quantizer (fdct8_columns) -- no lane-dependent selects anywhere.  Quantized coefficients go back into the slot in natural order; the wave's copy-out gathers them in
+//   block's LDS slot as int16; after the hand-off it reads columns 4p..4p+3 of all eight rows back and runs the column pass on
+//   int16 pairs (fdct8_pk16).  Quantized coefficients go back into the slot in natural order; the wave's copy-out gathers them in
 //   zigzag order (each lane always fetches the same eight positions) and stores 16 bytes per lane, fully coalesced.
 // ------------------------------------------------------------------------------------------------
-// jfdctint.c column pass (final descale).  `rnd` is the rounding term of the four odd outputs: 1 << 14 for a lane that feeds
-// the rows top-down.  A lane that feeds them bottom-up (input reversed) gets the even outputs unchanged and the odd part
-// negated BEFORE the rounding shift; with rnd = (1 << 14) - 1 its odd outputs are then exactly the negated true values
-// ((-x + h) >> n == -((x + h - 1) >> n)), and the caller flips their sign after the (sign-symmetric) quantizer.
-__device__ __forceinline__ void fdct8_columns(int (&d)[8], int rnd)
-{
-    int t0 = d[0] + d[7], t7 = d[0] - d[7];
-    int t1 = d[1] + d[6], t6 = d[1] - d[6];
-    int t2 = d[2] + d[5], t5 = d[2] - d[5];
-    int t3 = d[3] + d[4], t4 = d[3] - d[4];
-    int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
-    d[0] = descale(t10 + t11, 2);
-    d[4] = descale(t10 - t11, 2);
-    int z1 = __mul24(t12 + t13, F_0_541);
-    d[2] = descale(z1 + __mul24(t13, F_0_765), 15);
-    d[6] = descale(z1 + __mul24(t12, -F_1_847), 15);
-    z1 = t4 + t7;
-    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
-    int z5 = __mul24(z3 + z4, F_1_175);
-    t4 = __mul24(t4, F_0_298);
-    t5 = __mul24(t5, F_2_053);
-    t6 = __mul24(t6, F_3_072);
-    t7 = __mul24(t7, F_1_501);
-    z1 = __mul24(z1, -F_0_899);
-    z2 = __mul24(z2, -F_2_562);
-    z3 = __mul24(z3, -F_1_961) + z5;
-    z4 = __mul24(z4, -F_0_390) + z5;
-    d[7] = (t4 + z1 + z3 + rnd) >> 15;
-    d[5] = (t5 + z2 + z4 + rnd) >> 15;
-    d[3] = (t6 + z2 + z3 + rnd) >> 15;
-    d[1] = (t7 + z1 + z4 + rnd) >> 15;
-}
-
 __device__ __forceinline__ void pair_lds_fence()
 {
     // LDS operations of one wave execute in order; only the compiler has to be kept from reordering across the hand-off
@@ -346,19 +312,83 @@ __device__ __forceinline__ void pair_lds_fence()
 }
 
 __device__ __forceinline__ unsigned pack16(int a, int b) { return __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x05040100u); }  // a[15:0] | b[15:0] << 16
+__device__ __forceinline__ unsigned hi16_pair(int a, int b) { return __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x07060302u); }  // a[31:16] | b[31:16] << 16
 
 using lds_char = __attribute__((address_space(3))) char;
 
-// FDCT row pass of one block row (level-shifted samples) and hand-off: the row goes into the block's LDS slot as int16.
-__device__ __forceinline__ void row_pass_store(int (&s)[8], lds_char* slot, int row)
+// ---- FDCT passes on int16 pairs ------------------------------------------------------------------------------------------
+// jfdctint.c's pass 2 is a linear map with integer coefficients in front of its descale (every input meets ONE constant on the
+// way to an output), and its inputs -- the row pass's outputs, at most 8 x 128 x 4 = 4,096 in magnitude -- always fit int16 (so
+// do the sums and differences of two of them: the libjpeg SIMD builds rely on the same bound).  So: the mirrored sums and
+// differences t0..t7 as packed 16-bit adds on pairs of rows, then every output as two v_dot2_i32_i16 (two products and the
+// accumulate, rounding term included, in one instruction) -- 4 + 4 + 16 + 8 shifts = 32 instructions per column where the
+// butterfly form takes 54 with its unpacking.  Exact: regrouping integer sums does not change them (mod 2^32, no overflow here).
+using i16x2 = __attribute__((ext_vector_type(2))) short;
+constexpr unsigned pk16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | (((unsigned)hi & 0xFFFFu) << 16); }
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) + __builtin_bit_cast(i16x2, b))); }
+__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) - __builtin_bit_cast(i16x2, b))); }
+// a.lo * k.lo + a.hi * k.hi + acc (three-operand form pinned: hipcc prefers v_dot2c, whose accumulator is the destination, and pays
+// a v_mov per product for it)
+__device__ __forceinline__ int dot2(unsigned a, unsigned k, int acc)
 {
-    fdct8<true>(s);
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ int dot2_plus2(unsigned a, unsigned k)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 2" : "=v"(r) : "v"(a), "s"(k));
+    return r;
+}
+// even outputs from (t0,t1), (t2,t3); odd outputs from (t7,t6), (t5,t4) -- fdct8's names
+constexpr int kFa = F_0_541, kFb = F_0_541 + F_0_765, kFe = F_0_541 - F_1_847;
+constexpr int kA44 = F_0_298 - F_0_899 - F_1_961 + F_1_175, kA45 = F_1_175, kA46 = F_1_175 - F_1_961, kA47 = F_1_175 - F_0_899;
+constexpr int kA54 = F_1_175, kA55 = F_2_053 - F_2_562 - F_0_390 + F_1_175, kA56 = F_1_175 - F_2_562, kA57 = F_1_175 - F_0_390;
+constexpr int kA64 = F_1_175 - F_1_961, kA65 = F_1_175 - F_2_562, kA66 = F_3_072 - F_2_562 - F_1_961 + F_1_175, kA67 = F_1_175;
+constexpr int kA74 = F_1_175 - F_0_899, kA75 = F_1_175 - F_0_390, kA76 = F_1_175, kA77 = F_1_501 - F_0_899 - F_0_390 + F_1_175;
+
+__device__ __forceinline__ int dot2_plus0(unsigned a, unsigned k)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(k));
+    return r;
+}
+// One 1-D pass from the four input pairs P0 = (x0,x1), P1 = (x2,x3), P2 = (x7,x6), P3 = (x5,x4): d[k] = output k.
+// PASS1: the row pass (outputs scaled up by 2^PASS1_BITS, rnd = 1 << 10); else the column pass (final descale, rnd = 1 << 14).
+template <bool PASS1>
+__device__ __forceinline__ void fdct8_pk16(unsigned P0, unsigned P1, unsigned P2, unsigned P3, int rnd, int (&d)[8])
+{
+    constexpr int S = PASS1 ? 11 : 15;
+    const unsigned S01 = pk_add16(P0, P2), D01 = pk_sub16(P0, P2);  // (t0,t1), (t7,t6)
+    const unsigned S23 = pk_add16(P1, P3), D23 = pk_sub16(P1, P3);  // (t2,t3), (t5,t4)
+    if constexpr (PASS1) {
+        d[0] = dot2(S01, pk16(4, 4), dot2_plus0(S23, pk16(4, 4)));
+        d[4] = dot2(S01, pk16(4, -4), dot2_plus0(S23, pk16(-4, 4)));
+    } else {
+        d[0] = dot2(S01, pk16(1, 1), dot2_plus2(S23, pk16(1, 1))) >> 2;
+        d[4] = dot2(S01, pk16(1, -1), dot2_plus2(S23, pk16(-1, 1))) >> 2;
+    }
+    d[2] = dot2(S01, pk16(kFb, kFa), dot2(S23, pk16(-kFa, -kFb), rnd)) >> S;
+    d[6] = dot2(S01, pk16(kFa, kFe), dot2(S23, pk16(-kFe, -kFa), rnd)) >> S;
+    d[7] = dot2(D01, pk16(kA47, kA46), dot2(D23, pk16(kA45, kA44), rnd)) >> S;
+    d[5] = dot2(D01, pk16(kA57, kA56), dot2(D23, pk16(kA55, kA54), rnd)) >> S;
+    d[3] = dot2(D01, pk16(kA67, kA66), dot2(D23, pk16(kA65, kA64), rnd)) >> S;
+    d[1] = dot2(D01, pk16(kA77, kA76), dot2(D23, pk16(kA75, kA74), rnd)) >> S;
+}
+
+// FDCT row pass of one block row from its sample pairs (level-shifted, int16) and hand-off: the row goes into the block's LDS slot
+// as int16.
+__device__ __forceinline__ void row_pass_store_pk16(unsigned P0, unsigned P1, unsigned P2, unsigned P3, lds_char* slot, int row)
+{
+    int s[8];
+    fdct8_pk16<true>(P0, P1, P2, P3, 1 << 10, s);
     const u32x4 v = {pack16(s[0], s[1]), pack16(s[2], s[3]), pack16(s[4], s[5]), pack16(s[6], s[7])};
     *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(slot + row * 16) = v;
 }
 
-// After every row of the block is in the slot: column pass of columns 4p..4p+3 (lane 1 bottom row first, see above),
-// quantization, and the quantized coefficients back into the slot in natural order (int16).  The caller fences afterwards.
+// After every row of the block is in the slot: column pass of columns 4p..4p+3, quantization, and the quantized coefficients back
+// into the slot in natural order (int16).  The caller fences afterwards.
 // qmagic / qhalf16: tables in LDS, COLUMN-major over the natural block (index column * 8 + row), half16 = half << 4.
 __device__ __forceinline__ void column_pass_quantize(lds_char* slot, bool p, const __attribute__((address_space(3))) unsigned* qmagic,
                                                      const __attribute__((address_space(3))) unsigned* qhalf16)
@@ -367,26 +397,24 @@ __device__ __forceinline__ void column_pass_quantize(lds_char* slot, bool p, con
     using lds_u32x4 = __attribute__((address_space(3))) u32x4;
     pair_lds_fence();
     u32x2 rd[8];
-    lds_char* mine = slot + (p ? 7 * 16 + 8 : 0);
-    const int step = p ? -16 : 16;
+    lds_char* mine = slot + (p ? 8 : 0);
 #pragma unroll
-    for (int n = 0; n < 8; n++) rd[n] = *reinterpret_cast<const lds_u32x2*>(mine + n * step);
+    for (int n = 0; n < 8; n++) rd[n] = *reinterpret_cast<const lds_u32x2*>(mine + n * 16);
     pair_lds_fence();  // the partner has read too before anything below overwrites the slot (same wave: program order)
-    const int flip = p ? -1 : 0;
-    const int rnd = p ? (1 << 14) - 1 : (1 << 14);
+    const int rnd15 = 1 << 14;
     // two columns at a time; the tables are stored column-major so the eight quantizers of a column are two 16-byte reads
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         int r[2][8];
+        unsigned w[8];
+#pragma unroll
+        for (int n = 0; n < 8; n++) w[n] = half ? rd[n].y : rd[n].x;  // row n: column 4p + 2 half in the low, the next one in the high half
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
+            const unsigned sel = jj ? 0x07060302u : 0x05040100u;  // x.half | y.half << 16
             int d[8];
-#pragma unroll
-            for (int n = 0; n < 8; n++) {
-                const unsigned w = half ? rd[n].y : rd[n].x;
-                d[n] = jj ? ((int)w >> 16) : (int)(short)(w & 0xFFFF);
-            }
-            fdct8_columns(d, rnd);
+            fdct8_pk16<false>(__builtin_amdgcn_perm(w[1], w[0], sel), __builtin_amdgcn_perm(w[3], w[2], sel), __builtin_amdgcn_perm(w[6], w[7], sel),
+                              __builtin_amdgcn_perm(w[4], w[5], sel), rnd15, d);
             const int tcol = ((p ? 4 : 0) + 2 * half + jj) * 8;
             const u32x4 ma = *reinterpret_cast<const lds_u32x4*>(qmagic + tcol), mb = *reinterpret_cast<const lds_u32x4*>(qmagic + tcol + 4);
             const u32x4 ha = *reinterpret_cast<const lds_u32x4*>(qhalf16 + tcol), hb = *reinterpret_cast<const lds_u32x4*>(qhalf16 + tcol + 4);
@@ -398,8 +426,7 @@ __device__ __forceinline__ void column_pass_quantize(lds_char* slot, bool p, con
                 const int sgn = v >> 31;
                 const unsigned a16 = (((unsigned)((v ^ sgn) - sgn)) << 4) + h8[k];
                 const int m = (int)__umulhi(a16, m8[k]);
-                const int sg2 = (k & 1) ? (sgn ^ flip) : sgn;  // odd rows of the bottom-up lane are negated (fdct8_columns)
-                r[jj][k] = (m ^ sg2) - sg2;
+                r[jj][k] = (m ^ sgn) - sgn;
             }
         }
 #pragma unroll
@@ -500,18 +527,18 @@ __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forwa
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = p ? 7 - i : i;
-            int yrow[8], cb[8], cr[8];
+            int yacc[8], cb[8], cr[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const int c0 = (int)((w[i][(3 * c) >> 2] >> (8 * ((3 * c) & 3))) & 0xFF);
                 const int c1 = (int)((w[i][(3 * c + 1) >> 2] >> (8 * ((3 * c + 1) & 3))) & 0xFF);
                 const int c2 = (int)((w[i][(3 * c + 2) >> 2] >> (8 * ((3 * c + 2) & 3))) & 0xFF);
                 // jccolor.c rgb_ycc_convert, SCALEBITS 16
-                yrow[c] = (__mul24(c0, y0w) + __mul24(c1, 38470) + __mul24(c2, y2w) + kyc) >> 16;
+                yacc[c] = __mul24(c0, y0w) + __mul24(c1, 38470) + __mul24(c2, y2w) + kyc;  // bits 31..16: the level-shifted luma sample
                 cb[c] = (__mul24(c0, cb0w) + __mul24(c1, -21709) + __mul24(c2, cb2w) + kcc) >> 16;
                 cr[c] = (__mul24(c0, cr0w) + __mul24(c1, -27439) + __mul24(c2, cr2w) + kcc) >> 16;
             }
-            row_pass_store(yrow, slot, r);
+            row_pass_store_pk16(hi16_pair(yacc[0], yacc[1]), hi16_pair(yacc[2], yacc[3]), hi16_pair(yacc[7], yacc[6]), hi16_pair(yacc[5], yacc[4]), slot, r);
             // chroma into the (downsampled) LDS tile: jcsample.c h2v2_downsample (bias 1,2,1,2), h2v1_downsample (bias 0,1,0,1),
             // fullsize_downsample
             using lds_u32 = __attribute__((address_space(3))) unsigned;
@@ -583,10 +610,11 @@ __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forwa
             const int r = p ? 7 - i : i;
             const int lrow = min(gcy * 8 + r, last_row) - (int)u.tile_by * kChromaH;
             const u32x2 v = *(const __attribute__((address_space(3))) u32x2*)&lds_chroma[comp][lrow][cbx * 8];
-            int srow[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) srow[c] = (int)(((c < 4 ? v.x : v.y) >> (8 * (c & 3))) & 0xFF) - 128;
-            row_pass_store(srow, slot, r);
+            // bytes b0..b7 -> (b0,b1), (b2,b3), (b7,b6), (b5,b4) as int16 pairs, level shift as one packed subtraction each
+            constexpr unsigned kShift = 0x00800080u;
+            const unsigned P0 = pk_sub16(__builtin_amdgcn_perm(0u, v.x, 0x0c010c00u), kShift), P1 = pk_sub16(__builtin_amdgcn_perm(0u, v.x, 0x0c030c02u), kShift);
+            const unsigned P2 = pk_sub16(__builtin_amdgcn_perm(0u, v.y, 0x0c020c03u), kShift), P3 = pk_sub16(__builtin_amdgcn_perm(0u, v.y, 0x0c000c01u), kShift);
+            row_pass_store_pk16(P0, P1, P2, P3, slot, r);
         }
         column_pass_quantize(slot, p, qtab + 128, qtab + 192);
         pair_lds_fence();

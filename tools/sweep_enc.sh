@@ -2,7 +2,7 @@
 # dev tool: rebuild the encode kernels with different occupancy targets and time the forward kernel
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for w in 3 4; do
+for w in ${SWEEP_WAVES:-3 4}; do
   rm -f nvimagecodec_amd/csrc/build/encode_kernels.o
   make -C nvimagecodec_amd/csrc -j8 EXTRA_FLAGS="-DHJ_PAIR_WAVES=$w" > /dev/null 2>&1
   echo "== min waves/SIMD $w"
