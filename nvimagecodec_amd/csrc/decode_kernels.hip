@@ -178,7 +178,11 @@ __device__ __forceinline__ void fetch_half_block(const DecodeComponent& cd, int 
 #ifdef HJ_ABLATE_COEF
         if (g < nchunks) v = u32x4{(unsigned)g, 1u, 0u, 0u};
 #else
+#ifdef HJ_DEC_PLAIN_LOADS
+        if (g < nchunks) v = *((const HJ_GLOBAL u32x4*)src + g);
+#else
         if (g < nchunks) v = __builtin_nontemporal_load((const HJ_GLOBAL u32x4*)src + g);
+#endif
 #endif
         *reinterpret_cast<u32x4*>(lds_wave + (g >> 3) * kLdsBlockStride + (g & 7) * 16) = v;
     }
@@ -208,7 +212,11 @@ __device__ __forceinline__ void fetch_tile_half_block(const DecodeComponent& cd,
         u32x4 v = {0u, 0u, 0u, 0u};
         // byte offset in 32 bits (a component's blocks are far below 4 GB): SGPR base + VGPR offset addressing
         if (row < bh && col < bw)
+#ifdef HJ_DEC_PLAIN_LOADS
+            v = *(const HJ_GLOBAL u32x4*)((const HJ_GLOBAL char*)src + ((unsigned)(row * bw + col) * 128u + (unsigned)(g & 7) * 16u));
+#else
             v = __builtin_nontemporal_load((const HJ_GLOBAL u32x4*)((const HJ_GLOBAL char*)src + ((unsigned)(row * bw + col) * 128u + (unsigned)(g & 7) * 16u)));
+#endif
         *reinterpret_cast<u32x4*>(lds_wave + j * kLdsBlockStride + (g & 7) * 16) = v;
     }
     wave_lds_fence();
@@ -728,7 +736,11 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 #ifdef HJ_ABLATE_STORE
                 if (v.x == 0x12345678u && v.y == 0x9abcdef0u)  // practically never: keeps the value live, drops the traffic
 #endif
+#ifdef HJ_DEC_PLAIN_STORES
+                *(HJ_GLOBAL u32x4*)dst = v;
+#else
                 __builtin_nontemporal_store(v, (HJ_GLOBAL u32x4*)dst);
+#endif
             } else {
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
                 for (int j = 0; j < row_bytes - off; j++) dst[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));

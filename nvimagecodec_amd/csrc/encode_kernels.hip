@@ -510,7 +510,14 @@ __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forwa
             if (interior) {
                 // (explicitly global: through a generic pointer these become FLAT loads, which also count against the LDS counter)
                 const auto* v = (const __attribute__((address_space(1))) u32x2*)(rowp + (size_t)x0 * 3);
+                // plain loads: the three 8-byte pieces of a lane's 24 bytes are three instructions over the same cache lines (a wave's
+                // 768-byte row segment, a third of it per instruction); as non-temporal loads each of them fetched the lines again --
+                // 1.056 ms against 0.867 (tools/ab_enc_flag.sh "-DHJ_ENC_NT_LOADS")
+#ifdef HJ_ENC_NT_LOADS
                 const u32x2 a = __builtin_nontemporal_load(v), b = __builtin_nontemporal_load(v + 1), c = __builtin_nontemporal_load(v + 2);
+#else
+                const u32x2 a = v[0], b = v[1], c = v[2];
+#endif
                 w[i][0] = a.x; w[i][1] = a.y; w[i][2] = b.x; w[i][3] = b.y; w[i][4] = c.x; w[i][5] = c.y;
             } else {
 #pragma unroll

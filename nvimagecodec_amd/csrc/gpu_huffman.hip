@@ -1060,7 +1060,11 @@ __global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __res
             int16_t* p = sh.dst[blk];
             if (p) {
                 const u32x4 v = *(const HJ_LDS u32x4*)&sh.blocks[blk * kBlockBufBytes + chunk * 16];
+#ifdef HJ_BLOCKS_PLAIN_STORES
+                *((HJ_GLOBAL u32x4*)p + chunk) = v;
+#else
                 __builtin_nontemporal_store(v, (HJ_GLOBAL u32x4*)p + chunk);
+#endif
             }
         }
         if (base + kBThreads < items) {
