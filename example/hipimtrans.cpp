@@ -113,7 +113,7 @@ int main(int argc, char** argv)
         else if (a == "-s") p.subsampling = next();
         else if (a == "-d") p.device = atoi(next());
         else if (a == "-t") p.threads = atoi(next());
-        else if (a == "-p") p.in_flight = std::max(1, std::min(3, atoi(next())));
+        else if (a == "-p") p.in_flight = std::max(1, std::min(6, atoi(next())));
         else if (a == "--options") p.options = next();
         else if (a == "--skip_encode") p.skip_encode = true;
         else if (a == "--jpeg_encoding") p.progressive = std::string(next()) == "progressive_dct";

@@ -130,7 +130,7 @@ private:
     bool gpu_huffman_ = true;  // entropy-decode eligible streams on the GPU (the reference's GPU_HYBRID backend analogue)
     bool ok_ = false;
     int device_ = 0;
-    static constexpr int kJobPages = 3;
+    static constexpr int kJobPages = 6;  // batches (or pieces of one) in flight: each has its own page (arenas), stream and event; arenas are sized on first use
     std::unique_ptr<Job> jobs_[kJobPages];
     int next_job_ = 0;
     int pipeline_chunks_ = 0;  // option: pieces a large batch is cut into (0 = choose by size, 1 = never cut)
@@ -460,15 +460,27 @@ void HipJpegDecoder::complete(Job* job)
         release_inputs(job);
     } catch (...) {
     }
+    // the consumers' streams must not run ahead of the decode (reference cuda_decoder.cpp:552-556): one wait per DISTINCT stream of
+    // the job -- a batch's samples nearly always share one, and 256 runtime calls per batch were a quarter of this thread's time
+    void* waited[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool waited_ok[4] = {false, false, false, false};
+    int nwaited = 0;
+    auto order_after_decode = [&](void* user_stream) {
+        for (int k = 0; k < nwaited; k++)
+            if (waited[k] == user_stream) return waited_ok[k];
+        const bool ok = hipStreamWaitEvent((hipStream_t)user_stream, job->event, 0) == hipSuccess;
+        if (nwaited < 4) {
+            waited[nwaited] = user_stream;
+            waited_ok[nwaited++] = ok;
+        }
+        return ok;
+    };
     for (int i = 0; i < n; i++) {
         Sample& s = job->samples[i];
         nvimgcodecProcessingStatus_t ps = s.early_status;
         if (ps == NVIMGCODEC_PROCESSING_STATUS_SUCCESS) {
             ps = gpu_ok ? to_processing_status(job->statuses[i]) : (nvimgcodecProcessingStatus_t)NVIMGCODEC_PROCESSING_STATUS_FAIL;
-            // the consumer's stream must not run ahead of the decode (reference cuda_decoder.cpp:552-556)
-            if (ps == NVIMGCODEC_PROCESSING_STATUS_SUCCESS &&
-                hipStreamWaitEvent((hipStream_t)s.user_stream, job->event, 0) != hipSuccess)
-                ps = NVIMGCODEC_PROCESSING_STATUS_FAIL;
+            if (ps == NVIMGCODEC_PROCESSING_STATUS_SUCCESS && !order_after_decode(s.user_stream)) ps = NVIMGCODEC_PROCESSING_STATUS_FAIL;
         }
         try {
             report(job, i, ps);
@@ -488,6 +500,15 @@ nvimgcodecStatus_t HipJpegDecoder::decode(nvimgcodecCodeStreamDesc_t** code_stre
     if (batch_size < 1) return NVIMGCODEC_STATUS_INVALID_PARAMETER;
     std::lock_guard<std::mutex> serial(decode_mutex_);
     int chunks = pipeline_chunks_ > 0 ? pipeline_chunks_ : (batch_size >= 192 ? 3 : batch_size >= 96 ? 2 : 1);
+    if (pipeline_chunks_ <= 0) {
+        // a caller that keeps several decode() calls outstanding already has what the pieces are for -- the host stage and copy of
+        // one call beside the kernels of the call before -- and whole batches use the latency-bound entropy kernels better than thirds
+        // of them do: with a page still busy the batch goes out in one piece
+        for (auto& j : jobs_) {
+            std::lock_guard<std::mutex> lk(j->m);
+            if (j->busy) chunks = 1;
+        }
+    }
     chunks = std::max(1, std::min(chunks, std::min(batch_size, kJobPages)));
     nvimgcodecStatus_t result = NVIMGCODEC_STATUS_SUCCESS;
     for (int c = 0; c < chunks; c++) {
