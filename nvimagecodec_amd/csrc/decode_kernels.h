@@ -13,7 +13,7 @@ enum PlaneFlavour { kPlaneMul24 = 0, kPlaneExact = 1, kPlanePk16 = 2, kNumPlaneF
 int launch_idct_plane(int pass1, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K2: fused luma IDCT + chroma upsample (factors hs x vs, 0 = no chroma) + colour conversion + store.
 // flavour: which instantiation of the fused luma kernel (decode_kernels.hip luma_color_body)
-enum LumaFlavour { kLumaMul24 = 0, kLumaExact = 1, kLumaCommon = 2, kLumaCommonPk16 = 3, kLumaPk16 = 4, kNumLumaFlavours = 5 };
+enum LumaFlavour { kLumaMul24 = 0, kLumaExact = 1, kLumaCommon = 2, kLumaCommonPk16 = 3, kLumaPk16 = 4, kLumaCommonExact = 5, kNumLumaFlavours = 6 };
 int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K3: per-pixel colour stage from planes (replication upsampling) for uncommon sampling layouts.
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);

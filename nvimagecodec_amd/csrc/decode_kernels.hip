@@ -1002,6 +1002,7 @@ int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, co
     case kLumaCommon: return launch_luma_color_t<kPass1Mul24, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
     case kLumaCommonPk16: return launch_luma_color_t<kPass1Pk16, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
     case kLumaPk16: return launch_luma_color_t<kPass1Pk16, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case kLumaCommonExact: return launch_luma_color_t<kPass1Exact, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
     default: return launch_luma_color_t<kPass1Mul24, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
     }
 }
