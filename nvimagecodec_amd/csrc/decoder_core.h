@@ -61,7 +61,7 @@ struct PlannedImage {
     size_t coef_offset[4] = {0, 0, 0, 0};  // byte offset of component c inside the staging area
     int variant = -1;                      // KernelVariant, or -1 = generic colour path, -2 = planes-to-output only, -3 = CMYK / YCCK
     uint32_t coef_or[4] = {0, 0, 0, 0};    // OR of |coefficient| per component (from the entropy stage)
-    uint32_t ac_bound[4] = {32767, 32767, 32767, 32767};  // upper bound of |AC coefficient| per component (packed IDCT pass 1 decision)
+    uint32_t ac_bound[4] = {32768, 32768, 32768, 32768};  // upper bound of |AC coefficient| per component (packed IDCT pass 1 decision); default: any int16, -32768 included
     // GPU entropy decoding (flag HIPJPEG_FLAG_GPU_HUFFMAN and an eligible stream): the host only destuffs the scan
     bool gpu_entropy = false;
     int huff_index = -1;          // index into the HuffImage array
