@@ -188,7 +188,7 @@ def encode(rgb, subsampling="420", quality=90, restart_interval=0):
     h, w = rgb.shape[:2]
     ncomp = 1 if subsampling == "gray" else 3
     hs, vs = _SUBS[subsampling]
-    cap = w * h * 3 + (1 << 16)
+    cap = w * h * 6 + (1 << 16)  # noise at quality 100 codes to more than the raw picture
     out = np.zeros(cap, dtype=np.uint8)
     n = lib().oj_encode(rgb.ctypes.data, rgb.strides[0], w, h, ncomp, hs, vs, int(quality), int(restart_interval), out.ctypes.data, cap)
     if n < 0 or n > cap:
