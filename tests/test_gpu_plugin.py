@@ -416,3 +416,63 @@ def test_planar_ycbcr_image_through_the_encoder_plugin(torch_mod):
     assert st != A.PS_SUCCESS and data is None
     st, data = encode(planes, A.SAMPLING_420, A.SAMPLING_420, A.COLORSPEC_SRGB)
     assert st != A.PS_SUCCESS and data is None
+
+
+def test_several_decode_calls_outstanding(torch_mod):
+    """What a throughput-minded caller does (hipimtrans -p N): nvimgcodecDecoderDecode returns a future, the next batch is submitted
+    before the first is waited for.  With an earlier call in flight the plugin sends a batch out whole instead of in pieces (six
+    pages); five calls of 120 mixed goldens each outstanding at once -- every sample reports exactly once, every picture bit-exact,
+    a corrupt file in one batch fails alone."""
+    lib = _native.load()
+    inst, dec = _setup(lib)
+    before = lib.hipjpegTestDoubleReports()
+    entries = [e for e in _M["decode"] if e["pixels"]][:30]
+    cases = [load_decode_case(e) for e in entries]
+    ncalls, per_call = 5, 120
+    calls = []
+    for c in range(ncalls):
+        streams, images, outs, keep = [], [], [], []
+        for i in range(per_call):
+            jpeg, rgb = cases[(i + 7 * c) % len(cases)]
+            if c == 2 and i == 50:
+                jpeg = jpeg[:150]  # truncated inside the headers / first bytes of the scan
+            arr = np.frombuffer(jpeg, dtype=np.uint8)
+            keep.append(arr)
+            cs = C.c_void_p()
+            assert lib.nvimgcodecCodeStreamCreateFromHostMem(inst, C.byref(cs), arr.ctypes.data, arr.size) == 0
+            h, w = rgb.shape[:2]
+            t = torch_mod.zeros((h, w, 3), dtype=torch_mod.uint8, device="cuda")
+            info = A.init(A.ImageInfo, A.ST_IMAGE_INFO, sample_format=A.SAMPLEFORMAT_I_RGB, color_spec=A.COLORSPEC_SRGB, num_planes=1,
+                          buffer=t.data_ptr(), buffer_size=w * 3 * h, buffer_kind=A.BUFFER_KIND_STRIDED_DEVICE, cuda_stream=0)
+            pi = info.plane_info[0]
+            pi.width, pi.height, pi.row_stride, pi.num_channels, pi.sample_type = w, h, w * 3, 3, A.SAMPLE_DATA_TYPE_UINT8
+            im = C.c_void_p()
+            assert lib.nvimgcodecImageCreate(inst, C.byref(im), C.byref(info)) == 0
+            streams.append(cs)
+            images.append(im)
+            outs.append(t)
+        dp = A.init(A.DecodeParams, A.ST_DECODE_PARAMS)
+        fut = C.c_void_p()
+        cs_arr, im_arr = (C.c_void_p * per_call)(*streams), (C.c_void_p * per_call)(*images)
+        assert lib.nvimgcodecDecoderDecode(dec, cs_arr, im_arr, per_call, C.byref(dp), C.byref(fut)) == 0
+        calls.append((fut, streams, images, outs, keep, cs_arr, im_arr, dp))
+    for c, (fut, streams, images, outs, keep, *_rest) in enumerate(calls):
+        assert lib.nvimgcodecFutureWaitForAll(fut) == 0
+        st = (C.c_uint32 * per_call)()
+        n = C.c_size_t()
+        lib.nvimgcodecFutureGetProcessingStatus(fut, st, C.byref(n))
+        assert n.value == per_call
+        torch_mod.cuda.synchronize()
+        for i in range(per_call):
+            if c == 2 and i == 50:
+                assert st[i] != A.PS_SUCCESS
+            else:
+                assert st[i] == A.PS_SUCCESS, (c, i, st[i])
+                assert np.array_equal(outs[i].cpu().numpy(), cases[(i + 7 * c) % len(cases)][1]), (c, i)
+        lib.nvimgcodecFutureDestroy(fut)
+        for i in range(per_call):
+            lib.nvimgcodecImageDestroy(images[i])
+            lib.nvimgcodecCodeStreamDestroy(streams[i])
+    assert lib.hipjpegTestDoubleReports() == before
+    lib.nvimgcodecDecoderDestroy(dec)
+    lib.nvimgcodecInstanceDestroy(inst)
