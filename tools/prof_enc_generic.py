@@ -1,0 +1,29 @@
+"""Dev tool: the one-lane-per-block forward kernel (every layout the pair kernel does not take) on 256 x 1080p -- interleaved RGB at a
+base address that is not a multiple of 8 -- and the planar-YCbCr kernel; ms per batch by HIP events."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nvimagecodec_amd.lowlevel import BatchEncoder
+from nvimagecodec_amd.synth import synth_image
+
+W, H = 1920, 1080
+src = [torch.from_numpy(synth_image(W, H, seed=s)).cuda() for s in range(4)]
+imgs = []
+for i in range(256):
+    buf = torch.zeros(H * W * 3 + 64, dtype=torch.uint8, device="cuda")
+    a = torch.as_strided(buf, (H, W, 3), (W * 3, 3, 1), storage_offset=3)
+    a.copy_(src[i % 4])
+    imgs.append(a)
+enc = BatchEncoder(device=0, num_threads=8)
+enc.device_stage(imgs, "420", 90, "rgb")
+for _ in range(10):
+    enc.relaunch()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    enc.relaunch()
+e1.record()
+torch.cuda.synchronize()
+print("forward_kernel (one lane per block), 256 x 1080p interleaved RGB at an odd base, 4:2:0: %.3f ms per batch" % (e0.elapsed_time(e1) / 10))
