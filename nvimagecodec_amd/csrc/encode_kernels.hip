@@ -509,7 +509,9 @@ __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forwa
             const unsigned char* rowp = in0 + (size_t)y * pitch;
             if (interior) {
                 // (explicitly global: through a generic pointer these become FLAT loads, which also count against the LDS counter)
-                const auto* v = (const __attribute__((address_space(1))) u32x2*)(rowp + (size_t)x0 * 3);
+                // (any byte alignment: gfx950 fetches an unaligned 8-byte piece in one go)
+                typedef u32x2 __attribute__((aligned(1))) u32x2_unaligned;
+                const auto* v = (const __attribute__((address_space(1))) u32x2_unaligned*)(rowp + (size_t)x0 * 3);
                 // plain loads: the three 8-byte pieces of a lane's 24 bytes are three instructions over the same cache lines (a wave's
                 // 768-byte row segment, a third of it per instruction); as non-temporal loads each of them fetched the lines again --
                 // 1.056 ms against 0.867 (tools/ab_enc_flag.sh "-DHJ_ENC_NT_LOADS")

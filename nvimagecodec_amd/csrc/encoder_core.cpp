@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "encode_kernels.h"
@@ -120,9 +121,11 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
         }
         // tiles cover the real luma blocks only
         const int tiles_x = (g.real_w[0] + kTileBX - 1) / kTileBX, tiles_y = (g.real_h[0] + kTileBY - 1) / kTileBY;
-        // interleaved 8-byte-aligned RGB/BGR into 4:2:0 / 4:2:2 / 4:4:4 has a kernel of its own (encode_kernels.hip forward_pair_kernel)
+        // interleaved RGB/BGR (any base address and pitch) into 4:2:0 / 4:2:2 / 4:4:4 has a kernel of its own (encode_kernels.hip
+        // forward_pair_kernel).  HIPJPEG_ENCODE_ONE_LANE_KERNEL (read per batch) sends everything to the one-lane-per-block kernel:
+        // the cross-check campaigns compare the two on the same pixels.
         int flavour = 0;
-        if (g.ncomp == 3 && (fmt == HIPJPEG_OUTPUT_RGBI || fmt == HIPJPEG_OUTPUT_BGRI) && ((((uintptr_t)in.plane[0]) | in.pitch[0]) & 7) == 0)
+        if (g.ncomp == 3 && (fmt == HIPJPEG_OUTPUT_RGBI || fmt == HIPJPEG_OUTPUT_BGRI) && getenv("HIPJPEG_ENCODE_ONE_LANE_KERNEL") == nullptr)
             flavour = (g.hs == 2 && g.vs == 2) ? 1 : (g.hs == 2 && g.vs == 1) ? 2 : (g.hs == 1 && g.vs == 1) ? 3 : 0;
         if (fmt == HIPJPEG_OUTPUT_YUV_PLANAR) {
             // planes that are components already: one lane per real block of each component

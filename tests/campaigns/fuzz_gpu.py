@@ -1,7 +1,7 @@
 """Randomized cross-check campaign (dev tool, run on the GPU box): many valid streams of random shape / quality / sampling /
 restart interval / Huffman tables through independent routes of the product, which must agree bit for bit:
   decode: GPU entropy stage vs host entropy stage (same pixel kernels), a sample also against the CPU oracle;
-  encode: two-lanes-per-block kernel (8-byte-aligned input) vs one-lane-per-block kernel (same pixels, misaligned base),
+  encode: two-lanes-per-block kernel (aligned input, and the same pixels at a misaligned base) vs one-lane-per-block kernel,
           GPU entropy coder vs host entropy coder; a sample also against the CPU oracle."""
 import sys, os, random, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -36,7 +36,16 @@ for rnd in range(rounds):
         buf2 = torch.zeros(h * pitch + 64, dtype=torch.uint8, device="cuda")
         b = torch.as_strided(buf2, (h, w, 3), (pitch, 3, 1), storage_offset=3); b.copy_(torch.from_numpy(im).cuda()); skewed.append(b)
     s_pair_g = enc_g.encode(aligned, subsampling=subs, quality=quals)
-    s_gen_h = enc_h.encode(skewed, subsampling=subs, quality=quals)
+    # the same pixels at a base address that is not a multiple of 8: once through the pair kernel (it takes any alignment), once through
+    # the one-lane-per-block kernel (HIPJPEG_ENCODE_ONE_LANE_KERNEL is read per batch) -- three routes, one answer
+    s_pair_skewed = enc_g.encode(skewed, subsampling=subs, quality=quals)
+    os.environ["HIPJPEG_ENCODE_ONE_LANE_KERNEL"] = "1"
+    try:
+        s_gen_h = enc_h.encode(skewed, subsampling=subs, quality=quals)
+    finally:
+        del os.environ["HIPJPEG_ENCODE_ONE_LANE_KERNEL"]
+    for i, (x, y) in enumerate(zip(s_pair_g, s_pair_skewed)):
+        assert x == y, ("pair kernel: aligned and unaligned input disagree", rnd, i, imgs[i].shape, subs[i], quals[i])
     for i, (x, y) in enumerate(zip(s_pair_g, s_gen_h)):
         assert x == y, ("encode routes disagree", rnd, i, imgs[i].shape, subs[i], quals[i])
     for i in rng.sample(range(len(imgs)), 4):

@@ -111,9 +111,11 @@ def test_pitched_input(enc, torch_mod):
 
 
 def test_pair_kernel_ragged_edges(enc, torch_mod):
-    """forward_pair_kernel (two lanes per block) takes interleaved RGB/BGR whose base and pitch are multiples of 8 bytes.  Odd
-    widths only get there through a padded pitch: ragged right / bottom edges (libjpeg's edge replication), images smaller
-    than one MCU, widths that end inside / exactly on / one block past a 32-block tile, 4:2:0 / 4:2:2 / 4:4:4, both byte orders."""
+    """forward_pair_kernel (two lanes per block) takes interleaved RGB/BGR at any base address and pitch (8-byte pieces fetched
+    unaligned): padded pitches and tight ones at odd offsets, ragged right / bottom edges (libjpeg's edge replication), images smaller
+    than one MCU, widths that end inside / exactly on / one block past a 32-block tile, 4:2:0 / 4:2:2 / 4:4:4, both byte orders --
+    and the same views through the one-lane-per-block kernel (HIPJPEG_ENCODE_ONE_LANE_KERNEL), all against the oracle's bytes."""
+    import os
     torch = torch_mod
     sizes = [(1, 1), (7, 9), (17, 13), (33, 65), (250, 63), (257, 66), (264, 70), (300, 200), (519, 131)]
     for fmt in ("rgb", "bgr"):
@@ -129,9 +131,26 @@ def test_pair_kernel_ragged_edges(enc, torch_mod):
                 view.copy_(torch.from_numpy(np.ascontiguousarray(src)).cuda())
                 views.append(view)
                 refs.append(im)
-            streams = enc.encode(views, subsampling=sub, quality=85, input_format=fmt)
-            for (w, h), s, im in zip(sizes, streams, refs):
-                assert s == oracle.encode(im, sub, 85), f"{w}x{h} {sub} {fmt}"
+            tight = []
+            for k, ((w, h), im) in enumerate(zip(sizes, refs)):
+                off = (1, 3, 5, 7, 2)[k % 5]
+                buf = torch.zeros(h * w * 3 + 64, dtype=torch.uint8, device="cuda")
+                view = torch.as_strided(buf, (h, w, 3), (w * 3, 3, 1), storage_offset=off)
+                src = im[:, :, ::-1] if fmt == "bgr" else im
+                view.copy_(torch.from_numpy(np.ascontiguousarray(src)).cuda())
+                tight.append(view)
+            expected = [oracle.encode(im, sub, 85) for im in refs]
+            for what, vs in (("padded", views), ("tight", tight)):
+                streams = enc.encode(vs, subsampling=sub, quality=85, input_format=fmt)
+                for (w, h), s, e in zip(sizes, streams, expected):
+                    assert s == e, f"{what} {w}x{h} {sub} {fmt}"
+            os.environ["HIPJPEG_ENCODE_ONE_LANE_KERNEL"] = "1"
+            try:
+                streams = enc.encode(tight, subsampling=sub, quality=85, input_format=fmt)
+            finally:
+                del os.environ["HIPJPEG_ENCODE_ONE_LANE_KERNEL"]
+            for (w, h), s, e in zip(sizes, streams, expected):
+                assert s == e, f"one-lane kernel {w}x{h} {sub} {fmt}"
 
 
 def test_config2_1080p_420_q90_batch_and_roundtrip(enc, torch_mod):

@@ -1,5 +1,5 @@
-"""Dev tool: the one-lane-per-block forward kernel (every layout the pair kernel does not take) on 256 x 1080p -- interleaved RGB at a
-base address that is not a multiple of 8 -- and the planar-YCbCr kernel; ms per batch by HIP events."""
+"""Dev tool: 256 x 1080p interleaved RGB at a base address that is not a multiple of 8 through the encode device stage, ms per batch by
+HIP events -- the pair kernel by default (it takes any alignment), the one-lane-per-block kernel with HIPJPEG_ENCODE_ONE_LANE_KERNEL=1."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,4 +26,5 @@ for _ in range(10):
     enc.relaunch()
 e1.record()
 torch.cuda.synchronize()
-print("forward_kernel (one lane per block), 256 x 1080p interleaved RGB at an odd base, 4:2:0: %.3f ms per batch" % (e0.elapsed_time(e1) / 10))
+print("%s, 256 x 1080p interleaved RGB at an odd base, 4:2:0: %.3f ms per batch" % (
+    "one-lane-per-block kernel" if os.environ.get("HIPJPEG_ENCODE_ONE_LANE_KERNEL") else "pair kernel", e0.elapsed_time(e1) / 10))
