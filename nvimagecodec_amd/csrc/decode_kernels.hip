@@ -519,8 +519,8 @@ constexpr int kOutRowBytes = kBlocksPerWave * 24 + 16;  // one pixel row of a wa
 constexpr int kLdsLumaWaveBytes = 8 * kOutRowBytes;     // 6,272 B: first the coefficient staging (4,608 B), then the RGB tile
 constexpr int kNarrowRowBytes = 16 * 24;                // narrow tiles: 16 pixel rows of 16 blocks (6,144 B)
 
-//   COMMON = the configuration nearly every caller uses, fixed at compile time: YCbCr source, interleaved RGB output whose
-//   rows are 16-byte aligned, libjpeg's default fancy upsampling.  Same arithmetic, but no wave-uniform format branches and
+//   COMMON = the configuration nearly every caller uses, fixed at compile time: YCbCr source, interleaved RGB output (any base
+//   address and pitch), libjpeg's default fancy upsampling.  Same arithmetic, but no wave-uniform format branches and
 //   ~20 fewer live registers (85 instead of 104 VGPRs: five waves per SIMD without spills).  The host picks the kernel per
 //   image (DecodeBatch::finalize).
 template <int MODE, int HS, int VS, bool COMMON>
@@ -549,9 +549,9 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     const bool bgr = !COMMON && (fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR);
     const bool ycc = COMMON || im.color_model == 1;
     const bool full = x0 + 8 <= W;
-    // Interleaved output whose rows are 16-byte aligned goes through an LDS tile so that the wave emits 16 B per lane,
-    // fully coalesced, instead of 24-byte-strided 8-byte stores.
-    const bool staged = COMMON || (!planar && ((((uintptr_t)im.out[0]) | im.out_pitch[0]) & 15) == 0);
+    // Interleaved output goes through an LDS tile so that the wave emits 16 B per lane, fully coalesced, instead of
+    // 24-byte-strided 8-byte stores.
+    const bool staged = COMMON || !planar;  // (any base address and pitch: gfx950 stores an unaligned 16-byte piece in one go)
 
     if (valid) {
         // chroma window rows for this lane's four image rows (issued before the IDCT so the loads fly while we compute)
@@ -736,10 +736,11 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 #ifdef HJ_ABLATE_STORE
                 if (v.x == 0x12345678u && v.y == 0x9abcdef0u)  // practically never: keeps the value live, drops the traffic
 #endif
+                typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
 #ifdef HJ_DEC_PLAIN_STORES
-                *(HJ_GLOBAL u32x4*)dst = v;
+                *(HJ_GLOBAL u32x4_unaligned*)dst = v;
 #else
-                __builtin_nontemporal_store(v, (HJ_GLOBAL u32x4*)dst);
+                __builtin_nontemporal_store(v, (HJ_GLOBAL u32x4_unaligned*)dst);
 #endif
             } else {
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
