@@ -546,7 +546,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 
     const int fmt = im.out_format;
     const bool planar = !COMMON && (fmt == kOutPlanarRGB || fmt == kOutPlanarBGR);
-    const bool bgr = !COMMON && (fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR);
+    const bool bgr = fmt == kOutInterleavedBGR || (!COMMON && fmt == kOutPlanarBGR);
     const bool ycc = COMMON || im.color_model == 1;
     const bool full = x0 + 8 <= W;
     // Interleaved output goes through an LDS tile so that the wave emits 16 B per lane, fully coalesced, instead of
@@ -565,15 +565,24 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
             const int wx = HS == 2 ? 4 * bx - 1 : 8 * bx;
             // VS == 2: image rows 0..3 need chroma rows 4by-1 .. 4by+2, rows 4..7 need 4by+1 .. 4by+4;  VS == 1: rows map 1:1
             const int first = VS == 2 ? 4 * by - 1 + (p ? 2 : 0) : 8 * by + (p ? 4 : 0);
-            load_chroma_rows<NW>(im.comp[1].plane, im.comp[1].plane_pitch, dw, dh, wx, first, p, cbw);
-            load_chroma_rows<NW>(im.comp[2].plane, im.comp[2].plane_pitch, dw, dh, wx, first, p, crw);
+            // BGR output of a YCbCr source costs nothing: the two chroma windows trade places (a scalar pointer select) and so do the
+            // constants of the colour conversion below -- what comes out first is then B, what comes out third is R
+            const uint8_t* plane1 = im.comp[1].plane;
+            const uint8_t* plane2 = im.comp[2].plane;
+            const unsigned pitch1 = im.comp[1].plane_pitch, pitch2 = im.comp[2].plane_pitch;
+            const bool swap = ycc && bgr;
+            load_chroma_rows<NW>(swap ? plane2 : plane1, swap ? pitch2 : pitch1, dw, dh, wx, first, p, cbw);
+            load_chroma_rows<NW>(swap ? plane1 : plane2, swap ? pitch1 : pitch2, dw, dh, wx, first, p, crw);
         }
 
         int rows[4][8];
         column_pass<MODE>(cols, im.comp[0], p, rows);
         // additive constants of the colour conversion (kept in VGPRs: a VOP3 instruction reads one scalar operand at most)
         // (+ 128 << 16: the luma offset, see the packed colour stage below)
-        const int kr = 32768 - 128 * 91881 + (128 << 16), kb = 32768 - 128 * 116130 + (128 << 16), kg = 32768 + 128 * 22554 + 128 * 46802 + (128 << 16);
+        const bool swapped = ycc && bgr;  // crw holds Cb and cbw holds Cr (see the window loads above)
+        const int mr = swapped ? 116130 : 91881, mb = swapped ? 91881 : 116130;       // multiplier of the term built from crw / cbw
+        const int gr = swapped ? -22554 : -46802, gb = swapped ? -46802 : -22554;     // green's multipliers for crw / cbw
+        const int kr = 32768 - 128 * mr + (128 << 16), kb = 32768 - 128 * mb + (128 << 16), kg = 32768 + 128 * 22554 + 128 * 46802 + (128 << 16);
 
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -603,13 +612,13 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 #pragma unroll
                     for (int c = 0; c < 8; c += 2) {
                         const unsigned yp = clamp_s8_pair(lo_pair(__builtin_amdgcn_sbfe(rows[i][c], 0, 10), __builtin_amdgcn_sbfe(rows[i][c + 1], 0, 10)));
-                        const unsigned tr = hi_pair(mad24(cr[c], 91881, kr), mad24(cr[c + 1], 91881, kr));
-                        const unsigned tb = hi_pair(mad24(cb[c], 116130, kb), mad24(cb[c + 1], 116130, kb));
-                        const unsigned tg = hi_pair(mad24(cr[c], -46802, mad24(cb[c], -22554, kg)), mad24(cr[c + 1], -46802, mad24(cb[c + 1], -22554, kg)));
-                        const unsigned sr = pk_add16(yp, tr), sb = pk_add16(yp, tb);
-                        s0[c >> 1] = bgr ? sb : sr;
+                        // (names as for RGB output; for BGR the windows and constants have traded places: tr is then the blue term)
+                        const unsigned tr = hi_pair(mad24(cr[c], mr, kr), mad24(cr[c + 1], mr, kr));
+                        const unsigned tb = hi_pair(mad24(cb[c], mb, kb), mad24(cb[c + 1], mb, kb));
+                        const unsigned tg = hi_pair(mad24(cr[c], gr, mad24(cb[c], gb, kg)), mad24(cr[c + 1], gr, mad24(cb[c + 1], gb, kg)));
+                        s0[c >> 1] = pk_add16(yp, tr);
                         s1[c >> 1] = pk_add16(yp, tg);
-                        s2[c >> 1] = bgr ? sr : sb;
+                        s2[c >> 1] = pk_add16(yp, tb);
                     }
                     if (planar) {
                         q[0] = sat_pk4(s0[0], s0[1]);

@@ -692,7 +692,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
                 end_col = std::min(end_col, (uint32_t)(im.transform.x1 + 7) / 8);
             }
             // the everyday configuration has a kernel of its own (decode_kernels.hip, COMMON)
-            const bool common = im.variant != kVarGray && d.color_model == 1 && fmt == kOutInterleavedRGB && (d.flags & kFlagFancyUpsampling) &&
+            const bool common = im.variant != kVarGray && d.color_model == 1 && (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR) &&
+                                (d.flags & kFlagFancyUpsampling) &&
                                 (im.variant == kVar11 || im.variant == kVar12 || d.comp[1].samp_w > 2);
             const int flavour = fits16 ? (common ? kLumaCommonPk16 : kLumaPk16) : exact32 ? (common ? kLumaCommonExact : kLumaExact) : common ? kLumaCommon : kLumaMul24;
             // a ragged right edge of at most half a tile (1920 pixels = 7.5 tiles) is covered by narrow tiles, 16 x 8 blocks,
