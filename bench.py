@@ -458,7 +458,8 @@ def main():
     # which instantiations the batch was given (pass-1 arithmetic of the IDCT: 0 = 24-bit multiplier, 1 = 32-bit, 2 = packed int16)
     plane_fl, luma_fl = dec.kernel_flavours()
     k1_name = "idct_plane_kernel<%d>" % max(range(3), key=lambda e: plane_fl[e])
-    k2_name = "luma_color_kernel<%s>" % ("0,2,2,false", "1,2,2,false", "0,2,2,true", "2,2,2,true", "2,2,2,false", "1,2,2,true")[max(range(6), key=lambda e: luma_fl[e])]
+    k2_fl = max(range(9), key=lambda e: luma_fl[e])  # = arithmetic x 3 + layout (0 generic, 1 everyday interleaved, 2 everyday planar)
+    k2_name = "luma_color_kernel<%d, 2, 2, %d>" % (k2_fl // 3, k2_fl % 3)
     assert gst["gpu_entropy_images"] == BATCH, "the bench batch must take the GPU entropy stage"
 
     def step(ev=None):

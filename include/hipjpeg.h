@@ -115,9 +115,10 @@ HIPJPEG_API int hipjpegTestDoubleReports(void);
  * (damaged streams, and periodic streams whose corrections would have to travel through the image subsequence by subsequence). */
 HIPJPEG_API int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle);
 /* Test hook: work units of the handle's current batch per kernel flavour -- plane_units[3]: IDCT pass 1 on the 24-bit multiplier,
- * the 32-bit multiplier, packed int16 pairs; luma_units[6]: generic, exact, common, common + packed, generic + packed, common + exact
- * (csrc/decode_kernels.h PlaneFlavour / LumaFlavour).  Tests use it to see that a crafted file took the arithmetic it was crafted for. */
-HIPJPEG_API hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[3], int32_t luma_units[6]);
+ * the 32-bit multiplier, packed int16 pairs; luma_units[9]: index = that arithmetic x 3 + layout (0 generic, 1 the everyday interleaved
+ * kernel, 2 the everyday planar kernel; csrc/decode_kernels.h PlaneFlavour / luma_flavour).  Tests use it to see that a crafted file took
+ * the arithmetic it was crafted for. */
+HIPJPEG_API hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[3], int32_t luma_units[9]);
 
 /* ---- host-only entry points (usable without a GPU) ---- */
 HIPJPEG_API hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t length, hipjpegImageInfo_t* info);

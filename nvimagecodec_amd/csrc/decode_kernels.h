@@ -13,7 +13,10 @@ enum PlaneFlavour { kPlaneMul24 = 0, kPlaneExact = 1, kPlanePk16 = 2, kNumPlaneF
 int launch_idct_plane(int pass1, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K2: fused luma IDCT + chroma upsample (factors hs x vs, 0 = no chroma) + colour conversion + store.
 // flavour: which instantiation of the fused luma kernel (decode_kernels.hip luma_color_body)
-enum LumaFlavour { kLumaMul24 = 0, kLumaExact = 1, kLumaCommon = 2, kLumaCommonPk16 = 3, kLumaPk16 = 4, kLumaCommonExact = 5, kNumLumaFlavours = 6 };
+// = pass-1 arithmetic (PlaneFlavour) x 3 + layout: 0 = generic (format flags read at run time), 1 = COMMON (YCbCr source, interleaved
+// RGB / BGR, fancy upsampling), 2 = COMMON with planar RGB / BGR output
+constexpr int kNumLumaLayouts = 3, kNumLumaFlavours = kNumPlaneFlavours * kNumLumaLayouts;
+constexpr int luma_flavour(int pass1, int layout) { return pass1 * kNumLumaLayouts + layout; }
 int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // K3: per-pixel colour stage from planes (replication upsampling) for uncommon sampling layouts.
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);

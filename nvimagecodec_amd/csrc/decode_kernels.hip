@@ -523,7 +523,10 @@ constexpr int kNarrowRowBytes = 16 * 24;                // narrow tiles: 16 pixe
 //   address and pitch), libjpeg's default fancy upsampling.  Same arithmetic, but no wave-uniform format branches and
 //   ~20 fewer live registers (85 instead of 104 VGPRs: five waves per SIMD without spills).  The host picks the kernel per
 //   image (DecodeBatch::finalize).
-template <int MODE, int HS, int VS, bool COMMON>
+// LAYOUT: 0 = whatever the descriptor says (run-time branches), 1 = COMMON, 2 = COMMON with planar output (P_RGB / P_BGR: what
+// CHW consumers ask for) -- same arithmetic, one set of format flags fixed at compile time each
+enum LumaLayout : int { kLayoutAny = 0, kLayoutInterleaved = 1, kLayoutPlanar = 2 };
+template <int MODE, int HS, int VS, int LAYOUT>
 __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -545,13 +548,15 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     const bool valid = bx < bw && by < bh && x0 < W && y0 < H;  // false: pair idles (block is MCU padding or outside the tile)
 
     const int fmt = im.out_format;
-    const bool planar = !COMMON && (fmt == kOutPlanarRGB || fmt == kOutPlanarBGR);
-    const bool bgr = fmt == kOutInterleavedBGR || (!COMMON && fmt == kOutPlanarBGR);
+    constexpr bool COMMON = LAYOUT != kLayoutAny;
+    const bool planar = LAYOUT == kLayoutPlanar || (!COMMON && (fmt == kOutPlanarRGB || fmt == kOutPlanarBGR));
+    const bool bgr = LAYOUT == kLayoutPlanar ? fmt == kOutPlanarBGR : LAYOUT == kLayoutInterleaved ? fmt == kOutInterleavedBGR
+                                                                       : (fmt == kOutInterleavedBGR || fmt == kOutPlanarBGR);
     const bool ycc = COMMON || im.color_model == 1;
     const bool full = x0 + 8 <= W;
     // Interleaved output goes through an LDS tile so that the wave emits 16 B per lane, fully coalesced, instead of
     // 24-byte-strided 8-byte stores.
-    const bool staged = COMMON || !planar;  // (any base address and pitch: gfx950 stores an unaligned 16-byte piece in one go)
+    const bool staged = !planar;  // (any base address and pitch: gfx950 stores an unaligned 16-byte piece in one go)
 
     if (valid) {
         // chroma window rows for this lane's four image rows (issued before the IDCT so the loads fly while we compute)
@@ -759,12 +764,12 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     }
 }
 
-template <int MODE, int HS, int VS, bool COMMON>
+template <int MODE, int HS, int VS, int LAYOUT>
 __global__ __launch_bounds__(kThreads, HJ_MIN_WAVES_LUMA) void luma_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
     __shared__ __attribute__((aligned(16))) char lds[4 * kLdsLumaWaveBytes];
     const WorkUnit u = units[blockIdx.x];
-    luma_color_body<MODE, HS, VS, COMMON>(images[u.image], u, lds);
+    luma_color_body<MODE, HS, VS, LAYOUT>(images[u.image], u, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -985,20 +990,20 @@ int launch_idct_plane(int pass1, const DecodeImage* images, const WorkUnit* unit
     return (int)hipGetLastError();
 }
 
-template <int MODE, bool COMMON>
+template <int MODE, int LAYOUT>
 static int launch_luma_color_t(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, hipStream_t s)
 {
     if (hs == 0) {
-        if constexpr (COMMON) return (int)hipErrorInvalidValue;  // gray sources have no colour conversion to specialise
-        else hipLaunchKernelGGL((luma_color_kernel<MODE, 0, 0, false>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        if constexpr (LAYOUT != kLayoutAny) return (int)hipErrorInvalidValue;  // gray sources have no colour conversion to specialise
+        else hipLaunchKernelGGL((luma_color_kernel<MODE, 0, 0, kLayoutAny>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     } else if (hs == 1 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<MODE, 1, 1, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<MODE, 1, 1, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<MODE, 2, 1, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<MODE, 2, 1, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<MODE, 2, 2, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<MODE, 2, 2, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 1 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<MODE, 1, 2, COMMON>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<MODE, 1, 2, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else
         return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
@@ -1007,13 +1012,18 @@ static int launch_luma_color_t(int hs, int vs, const DecodeImage* images, const 
 int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
 {
     if (nunits <= 0) return 0;
+    // flavour = pass-1 arithmetic x 3 + layout (decode_kernels.h luma_flavour)
     switch (flavour) {
-    case kLumaExact: return launch_luma_color_t<kPass1Exact, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case kLumaCommon: return launch_luma_color_t<kPass1Mul24, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case kLumaCommonPk16: return launch_luma_color_t<kPass1Pk16, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case kLumaPk16: return launch_luma_color_t<kPass1Pk16, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case kLumaCommonExact: return launch_luma_color_t<kPass1Exact, true>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    default: return launch_luma_color_t<kPass1Mul24, false>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 0: return launch_luma_color_t<kPass1Mul24, kLayoutAny>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 1: return launch_luma_color_t<kPass1Mul24, kLayoutInterleaved>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 2: return launch_luma_color_t<kPass1Mul24, kLayoutPlanar>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 3: return launch_luma_color_t<kPass1Exact, kLayoutAny>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 4: return launch_luma_color_t<kPass1Exact, kLayoutInterleaved>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 5: return launch_luma_color_t<kPass1Exact, kLayoutPlanar>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 6: return launch_luma_color_t<kPass1Pk16, kLayoutAny>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 7: return launch_luma_color_t<kPass1Pk16, kLayoutInterleaved>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 8: return launch_luma_color_t<kPass1Pk16, kLayoutPlanar>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    default: return (int)hipErrorInvalidValue;
     }
 }
 

@@ -692,10 +692,10 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
                 end_col = std::min(end_col, (uint32_t)(im.transform.x1 + 7) / 8);
             }
             // the everyday configuration has a kernel of its own (decode_kernels.hip, COMMON)
-            const bool common = im.variant != kVarGray && d.color_model == 1 && (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR) &&
-                                (d.flags & kFlagFancyUpsampling) &&
-                                (im.variant == kVar11 || im.variant == kVar12 || d.comp[1].samp_w > 2);
-            const int flavour = fits16 ? (common ? kLumaCommonPk16 : kLumaPk16) : exact32 ? (common ? kLumaCommonExact : kLumaExact) : common ? kLumaCommon : kLumaMul24;
+            const bool everyday = im.variant != kVarGray && d.color_model == 1 && (d.flags & kFlagFancyUpsampling) &&
+                                  (im.variant == kVar11 || im.variant == kVar12 || d.comp[1].samp_w > 2);
+            const int layout = !everyday ? 0 : (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR) ? 1 : (fmt == kOutPlanarRGB || fmt == kOutPlanarBGR) ? 2 : 0;
+            const int flavour = luma_flavour(plane_flavour, layout);
             // a ragged right edge of at most half a tile (1920 pixels = 7.5 tiles) is covered by narrow tiles, 16 x 8 blocks,
             // so that no wave runs half empty
             const uint32_t span = end_col - first_col, ragged = span % kLumaTileW;

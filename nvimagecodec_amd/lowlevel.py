@@ -201,9 +201,9 @@ class BatchDecoder:
         return int(N.load().hipjpegTestHostFallbacks(self._h))
 
     def kernel_flavours(self):
-        """(plane_units[3], luma_units[6]) of the current batch: which arithmetic its images were given (hipjpegTestKernelFlavours)."""
+        """(plane_units[3], luma_units[9]) of the current batch: which arithmetic its images were given (hipjpegTestKernelFlavours)."""
         import ctypes
-        a, b = (ctypes.c_int32 * 3)(), (ctypes.c_int32 * 6)()
+        a, b = (ctypes.c_int32 * 3)(), (ctypes.c_int32 * 9)()
         st = N.load().hipjpegTestKernelFlavours(self._h, a, b)
         if st:
             raise N.HipJpegError(st, "hipjpegTestKernelFlavours")

@@ -24,7 +24,7 @@ nrng = np.random.default_rng(seed)
 dec = BatchDecoder(0, 8)
 t0 = time.time()
 n = 0
-used = np.zeros(9, dtype=np.int64)  # plane flavours 0..2, luma flavours 0..5
+used = np.zeros(12, dtype=np.int64)  # plane flavours 0..2, luma flavours 0..8 (arithmetic x 3 + layout)
 SAMPLINGS = {"gray": [(1, 1)], "444": [(1, 1)] * 3, "422": [(2, 1), (1, 1), (1, 1)], "420": [(2, 2), (1, 1), (1, 1)], "440": [(1, 2), (1, 1), (1, 1)]}
 for rnd in range(rounds):
     jpegs = []
@@ -58,7 +58,7 @@ for rnd in range(rounds):
                 ref = ref.transpose(2, 0, 1)
             assert np.array_equal(o.cpu().numpy(), ref), ("decode vs oracle", seed, rnd, i, fmt, gh)
         n += len(jpegs)
-    print("round %d ok: %d decodes against the oracle, %.1f s; batches that used each flavour (plane 24-bit/32-bit/packed, luma generic/exact/"
-          "common/common+packed/generic+packed/common+exact): %s" % (rnd, n, time.time() - t0, used.tolist()), flush=True)
+    print("round %d ok: %d decodes against the oracle, %.1f s; batches that used each flavour (plane 24-bit/32-bit/packed, luma = each of those x "
+          "generic/interleaved/planar): %s" % (rnd, n, time.time() - t0, used.tolist()), flush=True)
 assert used[2] > 0 and used[0] + used[1] > 0, used
 print("pass-1 campaign ok", n)

@@ -80,8 +80,8 @@ def test_kernels_do_not_spill_in_the_everyday_configuration(device_disassembly):
     checked = 0
     for b in blocks:
         head = b.split("\n", 1)[0]
-        # luma_color_kernel<MODE (any pass-1 arithmetic), HS, VS, COMMON=true> and every idct_plane_kernel flavour
-        if re.search(r"luma_color_kernelILi[012]ELi\dELi\dELb1EE", head) or "idct_plane_kernel" in head:
+        # luma_color_kernel<MODE (any pass-1 arithmetic), HS, VS, LAYOUT = everyday interleaved / planar> and every idct_plane_kernel flavour
+        if re.search(r"luma_color_kernelILi[012]ELi\dELi\dELi[12]EE", head) or "idct_plane_kernel" in head:
             checked += 1
             assert "scratch_" not in b, head
-    assert checked >= 15
+    assert checked >= 27

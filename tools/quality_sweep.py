@@ -13,7 +13,7 @@ quals = [int(a) for a in sys.argv[1:]] or [30, 50, 70, 75, 85, 90, 95]
 imgs = [synth_image(bench.WIDTH, bench.HEIGHT, seed=1234 + s) for s in range(bench.NUM_SOURCES)]
 dec = BatchDecoder(0, bench.usable_cpus())
 PLANE = ("24-bit", "32-bit", "packed")
-LUMA = ("generic", "generic 32-bit", "common", "common packed", "generic packed", "common 32-bit")
+LUMA = tuple("%s %s" % (a, l) for a in ("24-bit", "32-bit", "packed") for l in ("generic", "common", "planar"))
 for q in quals:
     src = [bench._pil_encode(im, q, "420") for im in imgs]
     jpegs = [src[i % len(src)] for i in range(256)]
@@ -36,6 +36,6 @@ for q in quals:
     assert all(s == 0 for s in dec.statuses(256))
     step = sum(tot)
     print("q%-3d %6.0f KB/image  K1 %-7s K2 %-15s entropy %.3f ms  K1 %.3f  K2 %.3f  step %.3f ms = %6.0f images/s" % (
-        q, sum(len(j) for j in jpegs) / 256 / 1024, PLANE[max(range(3), key=lambda e: plane[e])], LUMA[max(range(6), key=lambda e: luma[e])],
+        q, sum(len(j) for j in jpegs) / 256 / 1024, PLANE[max(range(3), key=lambda e: plane[e])], LUMA[max(range(9), key=lambda e: luma[e])],
         tot[0], tot[1], tot[2], step, 256 / step * 1e3), flush=True)
     del outs
