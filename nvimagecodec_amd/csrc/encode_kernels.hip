@@ -458,7 +458,9 @@ __device__ __forceinline__ u32x4 gather_zigzag_piece(const lds_char* slot, const
 #endif
 constexpr int kPairSlotStride = 144;  // 128 B block + 16 B pad
 
-template <int HS, int VS>
+// PLANAR: three separate input planes (P_RGB / P_BGR: CHW tensors) instead of interleaved pixels -- eight bytes per plane and row
+// per lane, consecutive blocks consecutive addresses; the arithmetic does not know the difference
+template <int HS, int VS, bool PLANAR>
 // (4:4:4: the full-resolution chroma tile limits it to three waves per SIMD)
 __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forward_pair_kernel(const EncodeImage* __restrict__ images, const EncodeUnit* __restrict__ units)
 {
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forwa
     }
     const uint4 zoff = *reinterpret_cast<const uint4*>(&kZigzagPieceOffsets[lane & 7][0]);
     // colour weights: for BGR input the first and third byte swap roles -- wave-uniform scalars, no per-pixel work
-    const bool bgr = im.in_format == kInInterleavedBGR;
+    const bool bgr = im.in_format == (PLANAR ? kInPlanarBGR : kInInterleavedBGR);
     const int y0w = bgr ? 7471 : 19595, y2w = bgr ? 19595 : 7471;
     const int cb0w = bgr ? 32768 : -11059, cb2w = bgr ? -11059 : 32768;
     const int cr0w = bgr ? -5329 : 32768, cr2w = bgr ? 32768 : -5329;
@@ -492,6 +494,9 @@ __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forwa
     const auto* qtab = (const __attribute__((address_space(3))) unsigned*)&lds_quant[0][0];
     const unsigned char* in0 = im.in[0];
     const unsigned pitch = im.in_pitch[0];
+    const unsigned char* in1 = PLANAR ? im.in[1] : nullptr;
+    const unsigned char* in2 = PLANAR ? im.in[2] : nullptr;
+    const unsigned pitch1 = PLANAR ? im.in_pitch[1] : 0u, pitch2 = PLANAR ? im.in_pitch[2] : 0u;
 
     // ---- phase A: wave w takes block rows 2w and 2w+1 of the tile, 32 blocks each
 #pragma unroll 1
@@ -507,10 +512,25 @@ __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forwa
             const int r = p ? 7 - i : i;
             const int y = min(y0 + r, H - 1);  // rows past the image replicate the last row (jcprepct.c expand_bottom_edge)
             const unsigned char* rowp = in0 + (size_t)y * pitch;
-            if (interior) {
+            typedef u32x2 __attribute__((aligned(1))) u32x2_unaligned;  // any byte alignment: gfx950 fetches an unaligned 8-byte piece in one go
+            if constexpr (PLANAR) {
+                // w[i][2k], w[i][2k+1] = the row's eight bytes of plane k
+                const unsigned char* rows3[3] = {rowp, in1 + (size_t)y * pitch1, in2 + (size_t)y * pitch2};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    if (interior) {
+                        const u32x2 a = *(const __attribute__((address_space(1))) u32x2_unaligned*)(rows3[k] + x0);
+                        w[i][2 * k] = a.x;
+                        w[i][2 * k + 1] = a.y;
+                    } else {
+                        w[i][2 * k] = w[i][2 * k + 1] = 0;
+#pragma unroll
+                        for (int c = 0; c < 8; c++)  // columns past the image replicate the last pixel (expand_right_edge)
+                            w[i][2 * k + (c >> 2)] |= (unsigned)rows3[k][min(x0 + c, W - 1)] << (8 * (c & 3));
+                    }
+                }
+            } else if (interior) {
                 // (explicitly global: through a generic pointer these become FLAT loads, which also count against the LDS counter)
-                // (any byte alignment: gfx950 fetches an unaligned 8-byte piece in one go)
-                typedef u32x2 __attribute__((aligned(1))) u32x2_unaligned;
                 const auto* v = (const __attribute__((address_space(1))) u32x2_unaligned*)(rowp + (size_t)x0 * 3);
                 // plain loads: the three 8-byte pieces of a lane's 24 bytes are three instructions over the same cache lines (a wave's
                 // 768-byte row segment, a third of it per instruction); as non-temporal loads each of them fetched the lines again --
@@ -539,9 +559,9 @@ __global__ __launch_bounds__(kThreads, (HS == 1 ? 3 : HJ_PAIR_WAVES)) void forwa
             int yacc[8], cb[8], cr[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const int c0 = (int)((w[i][(3 * c) >> 2] >> (8 * ((3 * c) & 3))) & 0xFF);
-                const int c1 = (int)((w[i][(3 * c + 1) >> 2] >> (8 * ((3 * c + 1) & 3))) & 0xFF);
-                const int c2 = (int)((w[i][(3 * c + 2) >> 2] >> (8 * ((3 * c + 2) & 3))) & 0xFF);
+                const int c0 = PLANAR ? (int)((w[i][c >> 2] >> (8 * (c & 3))) & 0xFF) : (int)((w[i][(3 * c) >> 2] >> (8 * ((3 * c) & 3))) & 0xFF);
+                const int c1 = PLANAR ? (int)((w[i][2 + (c >> 2)] >> (8 * (c & 3))) & 0xFF) : (int)((w[i][(3 * c + 1) >> 2] >> (8 * ((3 * c + 1) & 3))) & 0xFF);
+                const int c2 = PLANAR ? (int)((w[i][4 + (c >> 2)] >> (8 * (c & 3))) & 0xFF) : (int)((w[i][(3 * c + 2) >> 2] >> (8 * ((3 * c + 2) & 3))) & 0xFF);
                 // jccolor.c rgb_ycc_convert, SCALEBITS 16
                 yacc[c] = __mul24(c0, y0w) + __mul24(c1, 38470) + __mul24(c2, y2w) + kyc;  // bits 31..16: the level-shifted luma sample
                 cb[c] = (__mul24(c0, cb0w) + __mul24(c1, -21709) + __mul24(c2, cb2w) + kcc) >> 16;
@@ -698,18 +718,25 @@ int launch_forward_planes(const EncodeImage* images, const EncodeUnit* units, in
     return (int)hipGetLastError();
 }
 
-int launch_forward_pair(int hs, int vs, const EncodeImage* images, const EncodeUnit* units, int nunits, void* stream)
+template <bool PLANAR>
+static int launch_forward_pair_t(int hs, int vs, const EncodeImage* images, const EncodeUnit* units, int nunits, hipStream_t stream)
 {
-    if (nunits <= 0) return 0;
     if (hs == 2 && vs == 2)
-        hipLaunchKernelGGL((forward_pair_kernel<2, 2>), dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+        hipLaunchKernelGGL((forward_pair_kernel<2, 2, PLANAR>), dim3(nunits), dim3(kThreads), 0, stream, images, units);
     else if (hs == 2 && vs == 1)
-        hipLaunchKernelGGL((forward_pair_kernel<2, 1>), dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+        hipLaunchKernelGGL((forward_pair_kernel<2, 1, PLANAR>), dim3(nunits), dim3(kThreads), 0, stream, images, units);
     else if (hs == 1 && vs == 1)
-        hipLaunchKernelGGL((forward_pair_kernel<1, 1>), dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+        hipLaunchKernelGGL((forward_pair_kernel<1, 1, PLANAR>), dim3(nunits), dim3(kThreads), 0, stream, images, units);
     else
         return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
+}
+
+int launch_forward_pair(int hs, int vs, bool planar, const EncodeImage* images, const EncodeUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    return planar ? launch_forward_pair_t<true>(hs, vs, images, units, nunits, (hipStream_t)stream)
+                  : launch_forward_pair_t<false>(hs, vs, images, units, nunits, (hipStream_t)stream);
 }
 
 }  // namespace hipjpeg

@@ -125,8 +125,12 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
         // forward_pair_kernel).  HIPJPEG_ENCODE_ONE_LANE_KERNEL (read per batch) sends everything to the one-lane-per-block kernel:
         // the cross-check campaigns compare the two on the same pixels.
         int flavour = 0;
-        if (g.ncomp == 3 && (fmt == HIPJPEG_OUTPUT_RGBI || fmt == HIPJPEG_OUTPUT_BGRI) && getenv("HIPJPEG_ENCODE_ONE_LANE_KERNEL") == nullptr)
+        const bool interleaved = fmt == HIPJPEG_OUTPUT_RGBI || fmt == HIPJPEG_OUTPUT_BGRI;
+        const bool planar_rgb = fmt == HIPJPEG_OUTPUT_RGB_PLANAR || fmt == HIPJPEG_OUTPUT_BGR_PLANAR;
+        if (g.ncomp == 3 && (interleaved || planar_rgb) && getenv("HIPJPEG_ENCODE_ONE_LANE_KERNEL") == nullptr) {
             flavour = (g.hs == 2 && g.vs == 2) ? 1 : (g.hs == 2 && g.vs == 1) ? 2 : (g.hs == 1 && g.vs == 1) ? 3 : 0;
+            if (flavour != 0 && planar_rgb) flavour += 4;
+        }
         if (fmt == HIPJPEG_OUTPUT_YUV_PLANAR) {
             // planes that are components already: one lane per real block of each component
             for (int c = 0; c < 3; c++)
@@ -138,7 +142,7 @@ hipjpegStatus_t EncodeBatch::device_stage(const hipjpegEncodeInput_t* inputs, co
         pixel_bytes_ += (uint64_t)g.width * g.height * (g.ncomp == 1 ? 1 : 3);
         for (int c = 0; c < g.ncomp; c++) coef_bytes_ += (uint64_t)g.real_w[c] * g.real_h[c] * 128;
     }
-    for (int f = 0; f < 5; f++) {  // one table, the flavours back to back
+    for (int f = 0; f < kUnitLists; f++) {  // one table, the flavours back to back
         unit_first_[f] = units_.size();
         units_.insert(units_.end(), unit_lists_[f].begin(), unit_lists_[f].end());
     }
@@ -170,7 +174,9 @@ hipjpegStatus_t EncodeBatch::relaunch(void* stream)
     const EncodeUnit* dunits = reinterpret_cast<const EncodeUnit*>(device_.data() + units_offset_);
     static const int pair_hs[4] = {0, 2, 2, 1}, pair_vs[4] = {0, 2, 1, 1};
     int rc = launch_forward(dimg, dunits + unit_first_[0], (int)unit_lists_[0].size(), stream);
-    for (int f = 1; f < 4 && rc == 0; f++) rc = launch_forward_pair(pair_hs[f], pair_vs[f], dimg, dunits + unit_first_[f], (int)unit_lists_[f].size(), stream);
+    for (int f = 1; f < 4 && rc == 0; f++) rc = launch_forward_pair(pair_hs[f], pair_vs[f], false, dimg, dunits + unit_first_[f], (int)unit_lists_[f].size(), stream);
+    for (int f = 1; f < 4 && rc == 0; f++)
+        rc = launch_forward_pair(pair_hs[f], pair_vs[f], true, dimg, dunits + unit_first_[4 + f], (int)unit_lists_[4 + f].size(), stream);
     if (rc == 0) rc = launch_forward_planes(dimg, dunits + unit_first_[4], (int)unit_lists_[4].size(), stream);
     if (rc != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (!event_) {

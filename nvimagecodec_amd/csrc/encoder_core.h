@@ -54,8 +54,11 @@ private:
     std::vector<PlannedEncode> images_;
     std::vector<EncodeImage> desc_;
     std::vector<EncodeUnit> units_;            // every tile of the batch, grouped by kernel flavour
-    std::vector<EncodeUnit> unit_lists_[5];    // [0] one-lane-per-block kernel, [1..3] forward_pair_kernel 4:2:0 / 4:2:2 / 4:4:4, [4] planar YCbCr
-    size_t unit_first_[5] = {0, 0, 0, 0, 0};
+    // [0] one-lane-per-block kernel, [1..3] forward_pair_kernel 4:2:0 / 4:2:2 / 4:4:4 on interleaved input, [4] planar YCbCr,
+    // [5..7] forward_pair_kernel on planar RGB / BGR input
+    static constexpr int kUnitLists = 8;
+    std::vector<EncodeUnit> unit_lists_[kUnitLists];
+    size_t unit_first_[kUnitLists] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t units_offset_ = 0, coef_offset_ = 0, desc_bytes_ = 0, coef_total_ = 0;
     uint64_t pixel_bytes_ = 0, coef_bytes_ = 0;
     void* stream_ = nullptr;

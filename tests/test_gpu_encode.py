@@ -293,3 +293,26 @@ def test_planar_ycbcr_input_goes_into_the_stream_as_it_is(sub, hs, vs):
         for c in range(3):
             assert np.array_equal(got[c], ref[c]), (sub, w, h, c)
     enc.close()
+
+
+@pytest.mark.parametrize("fmt", ["rgb_planar", "bgr_planar"])
+def test_pair_kernel_planar_input(enc, torch_mod, fmt):
+    """Planar RGB / BGR (CHW tensors) through forward_pair_kernel<.., PLANAR>: ragged edges, images smaller than one MCU, widths around a
+    32-block tile, every sampling it takes -- and the same tensors through the one-lane-per-block kernel; all against the oracle's bytes."""
+    import os
+    torch = torch_mod
+    sizes = [(1, 1), (7, 9), (17, 13), (33, 65), (250, 63), (257, 66), (264, 70), (300, 200), (519, 131)]
+    for sub in ("420", "422", "444"):
+        refs = [synth_image(w, h, seed=7 * w + h) for (w, h) in sizes]
+        feed = [torch.from_numpy(np.ascontiguousarray((im[:, :, ::-1] if fmt == "bgr_planar" else im).transpose(2, 0, 1))).cuda() for im in refs]
+        expected = [oracle.encode(im, sub, 85) for im in refs]
+        streams = enc.encode(feed, subsampling=sub, quality=85, input_format=fmt)
+        for (w, h), s, e in zip(sizes, streams, expected):
+            assert s == e, f"pair kernel {w}x{h} {sub} {fmt}"
+        os.environ["HIPJPEG_ENCODE_ONE_LANE_KERNEL"] = "1"
+        try:
+            streams = enc.encode(feed, subsampling=sub, quality=85, input_format=fmt)
+        finally:
+            del os.environ["HIPJPEG_ENCODE_ONE_LANE_KERNEL"]
+        for (w, h), s, e in zip(sizes, streams, expected):
+            assert s == e, f"one-lane kernel {w}x{h} {sub} {fmt}"

@@ -28,3 +28,18 @@ e1.record()
 torch.cuda.synchronize()
 print("%s, 256 x 1080p interleaved RGB at an odd base, 4:2:0: %.3f ms per batch" % (
     "one-lane-per-block kernel" if os.environ.get("HIPJPEG_ENCODE_ONE_LANE_KERNEL") else "pair kernel", e0.elapsed_time(e1) / 10))
+
+# planar RGB (CHW) input
+planes = [s.permute(2, 0, 1).contiguous() for s in src]
+pl = [planes[i % 4].clone() for i in range(256)]
+enc.device_stage(pl, "420", 90, "rgb_planar")
+for _ in range(10):
+    enc.relaunch()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(10):
+    enc.relaunch()
+e1.record()
+torch.cuda.synchronize()
+print("%s, 256 x 1080p planar RGB, 4:2:0: %.3f ms per batch" % (
+    "one-lane-per-block kernel" if os.environ.get("HIPJPEG_ENCODE_ONE_LANE_KERNEL") else "pair kernel", e0.elapsed_time(e1) / 10))
