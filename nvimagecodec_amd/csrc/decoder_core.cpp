@@ -209,8 +209,10 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     ScopedRange range("hipjpeg plan (parse headers, lay out staging)");
     fault_point("plan");
     finalized_ = false;
-    images_.assign(n, PlannedImage());
-    desc_.assign(n, DecodeImage());
+    // (every element is reset by its own prepare() below -- on the pool: a batch of a thousand small pictures spent a third of its
+    // plan() clearing these two arrays on the caller's thread)
+    images_.resize((size_t)n);
+    desc_.resize((size_t)n);
     const bool fancy = (flags & HIPJPEG_FLAG_FANCY_UPSAMPLING) != 0;
     const bool want_gpu_entropy = (flags & HIPJPEG_FLAG_GPU_HUFFMAN) != 0;
     entropy_done_ = false;
@@ -235,6 +237,8 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     // per-image header work (marker walk through the whole file, eligibility, table sizing) is independent: all cores
     auto prepare = [&](int i) {
         PlannedImage& im = images_[i];
+        im = PlannedImage();
+        desc_[i] = DecodeImage();
         im.data = data[i];
         im.size = lengths[i];
         if (formats && ((int)formats[i] < 0 || (int)formats[i] > (int)HIPJPEG_OUTPUT_YUV_PLANAR)) {
@@ -298,20 +302,9 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
             im.gpu_entropy = im.gpu_prog = true;
             im.pool_words = prog_pool_words(f);
         }
-    };
-    if (pool && n > 1)
-        pool->parallel_for(n, [&](int i, int) { prepare(i); });
-    else
-        for (int i = 0; i < n; i++) prepare(i);
-
-    for (int i = 0; i < n; i++) {
-        PlannedImage& im = images_[i];
-        const OutFormat fmt = (OutFormat)(formats && im.status != HIPJPEG_STATUS_INVALID_ARGUMENT ? formats[i] : format);
-        const FrameInfo& f = im.frame;
-        if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
-
+        if (im.status != HIPJPEG_STATUS_SUCCESS) return;
+        // the part of the device descriptor that does not depend on where things will lie in the arenas
         DecodeImage& d = desc_[i];
-        memset(&d, 0, sizeof d);
         d.width = (uint32_t)f.width;
         d.height = (uint32_t)f.height;
         d.ncomp = (uint32_t)f.ncomp;
@@ -324,6 +317,38 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
             d.out[p] = static_cast<uint8_t*>(outputs[i].plane[p]);
             d.out_pitch[p] = outputs[i].pitch[p];
         }
+        for (int c = 0; c < f.ncomp; c++) {
+            const Component& k = f.comp[c];
+            DecodeComponent& dc = d.comp[c];
+            dc.blocks_w = (uint16_t)k.blocks_w;
+            dc.blocks_h = (uint16_t)k.blocks_h;
+            dc.samp_w = (uint16_t)k.samp_w;
+            dc.samp_h = (uint16_t)k.samp_h;
+            dc.h = (uint16_t)k.h;
+            dc.v = (uint16_t)k.v;
+            for (int pp = 0; pp < 2; pp++)
+                for (int j = 0; j < 4; j++)
+                    for (int r = 0; r < 8; r++) {
+                        const int q = f.qtab[c][r * 8 + 4 * pp + j];
+                        dc.qpair[pp][j * 8 + r] = dc.qpair_exact[pp][j * 8 + r] = (pp && (r & 1)) ? -q : q;
+                        const uint32_t q16 = (uint32_t)((pp && (r & 1)) ? -q : q) & 0xFFFFu;
+                        uint32_t& pk = dc.qpk[pp][j * 4 + (r >> 1)];
+                        pk = (r & 1) ? (pk | (q16 << 16)) : q16;
+                    }
+        }
+    };
+    if (pool && n > 1)
+        pool->parallel_for(n, [&](int i, int) { prepare(i); });
+    else
+        for (int i = 0; i < n; i++) prepare(i);
+
+    for (int i = 0; i < n; i++) {
+        PlannedImage& im = images_[i];
+        const OutFormat fmt = (OutFormat)(formats && im.status != HIPJPEG_STATUS_INVALID_ARGUMENT ? formats[i] : format);
+        const FrameInfo& f = im.frame;
+        if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
+
+        DecodeImage& d = desc_[i];  // (prepare() filled in what does not depend on the layout)
         if (im.has_transform) {
             // the pixel kernels write a full-frame intermediate picture (same format, 16-byte aligned rows); the geometry
             // pass copies the region, turned upright, into the caller's buffer
@@ -357,21 +382,6 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
         for (int c = 0; c < f.ncomp; c++) {
             const Component& k = f.comp[c];
             DecodeComponent& dc = d.comp[c];
-            dc.blocks_w = (uint16_t)k.blocks_w;
-            dc.blocks_h = (uint16_t)k.blocks_h;
-            dc.samp_w = (uint16_t)k.samp_w;
-            dc.samp_h = (uint16_t)k.samp_h;
-            dc.h = (uint16_t)k.h;
-            dc.v = (uint16_t)k.v;
-            for (int pp = 0; pp < 2; pp++)
-                for (int j = 0; j < 4; j++)
-                    for (int r = 0; r < 8; r++) {
-                        const int q = f.qtab[c][r * 8 + 4 * pp + j];
-                        dc.qpair[pp][j * 8 + r] = dc.qpair_exact[pp][j * 8 + r] = (pp && (r & 1)) ? -q : q;
-                        const uint32_t q16 = (uint32_t)((pp && (r & 1)) ? -q : q) & 0xFFFFu;
-                        uint32_t& pk = dc.qpk[pp][j * 4 + (r >> 1)];
-                        pk = (r & 1) ? (pk | (q16 << 16)) : q16;
-                    }
             const size_t nblk = (size_t)k.blocks_w * k.blocks_h;
             const size_t units = (nblk + kBlocksPerUnit - 1) / kBlocksPerUnit;
             // which components go through an intermediate plane
