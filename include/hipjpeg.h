@@ -120,6 +120,11 @@ HIPJPEG_API int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle);
  * the arithmetic it was crafted for. */
 HIPJPEG_API hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[3], int32_t luma_units[9]);
 
+/* Test hook (host only): the parser's per-chunk counts of the bytes that byte-stuffing removal drops from scan `scan_index` (16,384-byte
+ * chunks of the entropy-coded segment; the GPU entropy stage's compact kernel works from them).  Returns the number of chunks, or a
+ * negative value when the file does not parse / has no such scan; at most `capacity` counts are written. */
+HIPJPEG_API int32_t hipjpegTestScanChunkDrops(const uint8_t* data, size_t length, int scan_index, uint32_t* drops, int32_t capacity);
+
 /* ---- host-only entry points (usable without a GPU) ---- */
 HIPJPEG_API hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t length, hipjpegImageInfo_t* info);
 

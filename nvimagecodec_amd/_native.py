@@ -81,6 +81,8 @@ def load():
     L.hipjpegSetPipelineDepth.argtypes = [vp, i32]
     L.hipjpegTestHostFallbacks.argtypes = [vp]
     L.hipjpegTestHostFallbacks.restype = i32
+    L.hipjpegTestScanChunkDrops.argtypes = [vp, ctypes.c_size_t, i32, ctypes.POINTER(ctypes.c_uint32), i32]
+    L.hipjpegTestScanChunkDrops.restype = i32
     L.hipjpegTestKernelFlavours.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     L.hipjpegDecodeBatchEntropyStats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]
     L.hipjpegEncodeBatchDevice.argtypes = [vp, vp, vp, i32, vp, vp]

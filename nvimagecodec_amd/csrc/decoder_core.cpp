@@ -481,7 +481,8 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     huff_list_offset_ = align_up(huff_dc_units_offset_ + sizeof(HuffUnit) * ng * 4, 256);
     // (the HuffImage array holds the baseline images first, then one entry per scan of the progressive images)
     huff_chunk_units_offset_ = align_up(huff_list_offset_ + sizeof(uint32_t) * ng, 256);
-    xform_desc_offset_ = align_up(huff_chunk_units_offset_ + sizeof(HuffUnit) * huff_chunks_total, 256);
+    huff_drops_offset_ = align_up(huff_chunk_units_offset_ + sizeof(HuffUnit) * huff_chunks_total, 256);
+    xform_desc_offset_ = align_up(huff_drops_offset_ + sizeof(uint32_t) * huff_chunks_total, 256);
     xform_units_offset_ = align_up(xform_desc_offset_ + sizeof(TransformImage) * xform_desc_.size(), 256);
     prog_desc_offset_ = align_up(xform_units_offset_ + sizeof(WorkUnit) * max_xform_units, 256);
     prog_units_offset_ = align_up(prog_desc_offset_ + sizeof(ProgImage) * prog_to_image_.size(), 256);
@@ -574,6 +575,16 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     return HIPJPEG_STATUS_SUCCESS;
 }
 
+// The parser counted, per kDestuffChunk-byte chunk of the scan, the bytes that byte-stuffing removal drops; they ride to the device with
+// the bitstream (the compact kernel reads them where round 1's count kernel left its results).
+void DecodeBatch::stage_chunk_drops(const ScanHeader& sc, uint32_t first_chunk)
+{
+    static_assert(kScanChunkBytes == (size_t)kDestuffChunk, "the parser counts in the destuff kernels' chunks");
+    uint32_t* dst = reinterpret_cast<uint32_t*>(pinned_.data() + huff_drops_offset_) + first_chunk;
+    const size_t chunks = (sc.data_end - sc.data_begin + kScanChunkBytes - 1) / kScanChunkBytes;
+    for (size_t c = 0; c < chunks; c++) dst[c] = c < sc.chunk_drops.size() ? sc.chunk_drops[c] : 0u;
+}
+
 void DecodeBatch::entropy_stage(int i)
 {
     PlannedImage& im = images_[i];
@@ -594,6 +605,7 @@ void DecodeBatch::entropy_stage(int i)
             h.raw_bytes = (uint32_t)len;
             h.first_chunk = im.prog_first_chunk[sidx];
             im.stream_bytes += (uint32_t)len;
+            stage_chunk_drops(sc, h.first_chunk);
         }
         fill_prog_image(f, &prog_images_[im.prog_index], reinterpret_cast<uint16_t*>(pinned_.data() + im.tables_offset));
         for (int c = 0; c < f.ncomp; c++) im.coef_or[c] = 32767u;  // successive approximation: any int16 may come out
@@ -607,6 +619,7 @@ void DecodeBatch::entropy_stage(int i)
         uint8_t* raw = pinned_.data() + im.raw_offset;
         copy_to_staging(raw, im.data + sc.data_begin, im.stream_bytes);
         memset(raw + im.stream_bytes, 0x01, align_up((size_t)im.stream_bytes, 16) + 16 - im.stream_bytes);  // neither FF nor 00
+        stage_chunk_drops(sc, im.first_chunk);
         HuffImage& h = huff_images_[im.huff_index];
         fill_huff_image(im.frame, im.stream_bytes, &h);
         build_gpu_pool(sc, &h, reinterpret_cast<uint16_t*>(pinned_.data() + im.tables_offset));
@@ -872,8 +885,12 @@ hipjpegStatus_t DecodeBatch::enqueue_gpu_entropy(void* stream)
     if (huff_units_.empty() && prog_units_.empty()) return HIPJPEG_STATUS_SUCCESS;
     EntropyLaunch L = entropy_launch_args();
     if (hipMemsetAsync(L.changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    // the per-chunk counts of bytes to drop came up with the bitstreams (the parser's marker walk sees every FF anyway);
+    // HIPJPEG_DEVICE_DESTUFF_COUNT=1 counts them on the device as round 1 did (A/B and cross-check aid)
+    static const bool device_count = getenv("HIPJPEG_DEVICE_DESTUFF_COUNT") != nullptr;
     if (launch_destuff(L.dimg, reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(),
-                       reinterpret_cast<uint32_t*>(work_.data() + work_drops_), stream) != 0)
+                       device_count ? reinterpret_cast<uint32_t*>(work_.data() + work_drops_) : reinterpret_cast<uint32_t*>(device_.data() + huff_drops_offset_),
+                       device_count, stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
     if (!prog_units_.empty()) {
         const hipjpegStatus_t ps = enqueue_progressive(stream);

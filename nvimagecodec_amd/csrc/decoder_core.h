@@ -173,6 +173,7 @@ private:
     };
     EntropyLaunch entropy_launch_args();
     bool entropy_write_passes(const EntropyLaunch& L, void* stream);
+    void stage_chunk_drops(const ScanHeader& sc, uint32_t first_chunk);
     hipjpegStatus_t enqueue_gpu_entropy(void* stream);
     int launch_pixel_kernels(void* stream, int which);
     bool entropy_pending_ = false, pixels_launched_ = false, copy_pending_ = false;
@@ -188,6 +189,7 @@ private:
     size_t gpu_coef_begin_ = 0, gpu_coef_bytes_ = 0, total_subseq_ = 0, max_huff_units_ = 0, max_pool_words_ = 0;
     size_t work_first_block_ = 0, work_changed_ = 0, work_incoming_ = 0, work_tail_ = 0, work_dc_diff_ = 0, work_block_pos_ = 0, work_drops_ = 0, work_streams_ = 0, work_group_sums_ = 0;
     size_t huff_chunk_units_offset_ = 0, huff_wunits_offset_ = 0, max_huff_wunits_ = 0;
+    size_t huff_drops_offset_ = 0;  // per destuff chunk: bytes to drop, counted by the parser's marker walk (ScanHeader::chunk_drops)
     std::vector<TransformImage> xform_desc_;
     std::vector<WorkUnit> xform_units_;
     size_t xform_desc_offset_ = 0, xform_units_offset_ = 0;

@@ -1226,10 +1226,11 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
 
 }  // namespace
 
-int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, void* stream)
+int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, bool count_on_device, void* stream)
 {
     if (nchunks <= 0) return 0;
-    hipLaunchKernelGGL(destuff_count_kernel, dim3(nchunks), dim3(kThreads), 0, (hipStream_t)stream, images, chunk_units, drops);
+    if (count_on_device)
+        hipLaunchKernelGGL(destuff_count_kernel, dim3(nchunks), dim3(kThreads), 0, (hipStream_t)stream, images, chunk_units, drops);
     hipLaunchKernelGGL(destuff_compact_kernel, dim3(nchunks), dim3(kThreads), 0, (hipStream_t)stream, images, chunk_units, drops);
     return (int)hipGetLastError();
 }

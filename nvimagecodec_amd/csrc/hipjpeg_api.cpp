@@ -413,6 +413,20 @@ hipjpegStatus_t hipjpegDecodeBatchEntropyStats(hipjpegHandle_t handle, int32_t* 
     });
 }
 
+int32_t hipjpegTestScanChunkDrops(const uint8_t* data, size_t length, int scan_index, uint32_t* drops, int32_t capacity)
+{
+    int32_t result = -1;
+    (void)guarded([&]() -> hipjpegStatus_t {
+        hipjpeg::FrameInfo f;
+        if (hipjpeg::parse_jpeg(data, length, &f) != hipjpeg::kParseOk || scan_index < 0 || scan_index >= (int)f.scans.size()) return HIPJPEG_STATUS_BAD_JPEG;
+        const auto& d = f.scans[scan_index].chunk_drops;
+        for (int32_t c = 0; c < (int32_t)d.size() && c < capacity && drops; c++) drops[c] = d[c];
+        result = (int32_t)d.size();
+        return HIPJPEG_STATUS_SUCCESS;
+    });
+    return result;
+}
+
 int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle)
 {
     return handle ? handle->cur().host_fallback_images() : -1;

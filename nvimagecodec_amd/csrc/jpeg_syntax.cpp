@@ -29,15 +29,27 @@ struct ScanWalk {
     size_t begin, stuffed = 0, markers = 0;
     bool* plain;
     std::vector<uint32_t>* rst_after;
+    std::vector<uint32_t>* drops = nullptr;  // ScanHeader::chunk_drops
+    inline void drop(size_t index, uint32_t count = 1)
+    {
+        const size_t c = (index - begin) / kScanChunkBytes;
+        if (c >= drops->size()) drops->resize(c + 1, 0u);
+        (*drops)[c] += count;
+    }
     // looks at the FF at offset i (i + 1 < size): false = the scan ends here
     inline bool visit(const uint8_t* data, size_t i)
     {
         const uint8_t m = data[i + 1];
         if (m == 0x00) {
             stuffed++;
+            if (drops) drop(i + 1);
         } else if (m >= 0xD0 && m <= 0xD7) {
             if ((unsigned)(m - 0xD0) != (markers & 7)) *plain = false;
             markers++;
+            if (drops) {
+                drop(i);
+                drop(i + 1);
+            }
             if (rst_after) rst_after->push_back((uint32_t)(i + 2 - begin - stuffed - 2 * markers));
         } else if (m == 0xFF) {
             *plain = false;  // fill byte; the next FF is looked at in its turn
@@ -75,6 +87,18 @@ __attribute__((target("avx2,popcnt"))) size_t find_scan_end_avx2(const uint8_t* 
         const uint32_t stuffing = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(y, zero));
         if ((mask & ~stuffing) == 0) {  // nothing but FF 00 in this chunk: no data-dependent branch per FF
             w.stuffed += (size_t)__builtin_popcount(mask);
+            if (w.drops && mask) {
+                // the dropped bytes are the ones behind the FFs: offsets pos + 1 .. pos + 32, in one or two counting chunks
+                const size_t first = (pos + 1 - w.begin) / kScanChunkBytes, last = (pos + 32 - w.begin) / kScanChunkBytes;
+                if (first == last) {
+                    w.drop(pos + 1, (uint32_t)__builtin_popcount(mask));
+                } else {
+                    const size_t in_first = last * kScanChunkBytes + w.begin - (pos + 1);  // FFs at pos .. pos + in_first - 1 drop into `first`
+                    const uint32_t low = mask & (uint32_t)((1ull << in_first) - 1);
+                    if (low) w.drop(pos + 1, (uint32_t)__builtin_popcount(low));
+                    if (mask & ~low) w.drop(pos + 32, (uint32_t)__builtin_popcount(mask & ~low));
+                }
+            }
             pos += 32;
             continue;
         }
@@ -89,18 +113,24 @@ __attribute__((target("avx2,popcnt"))) size_t find_scan_end_avx2(const uint8_t* 
 }
 #endif
 
-size_t find_scan_end(const uint8_t* data, size_t pos, size_t size, bool* plain, std::vector<uint32_t>* rst_after)
+size_t find_scan_end(const uint8_t* data, size_t pos, size_t size, bool* plain, std::vector<uint32_t>* rst_after, std::vector<uint32_t>* chunk_drops)
 {
     *plain = true;
     ScanWalk w;
     w.begin = pos;
     w.plain = plain;
     w.rst_after = rst_after;
+    w.drops = chunk_drops;
+    size_t end;
 #if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
-    if (avx2) return find_scan_end_avx2(data, pos, size, w);
+    if (avx2)
+        end = find_scan_end_avx2(data, pos, size, w);
+    else
 #endif
-    return find_scan_end_plain(data, pos, size, w);
+        end = find_scan_end_plain(data, pos, size, w);
+    if (chunk_drops) chunk_drops->resize((end - pos + kScanChunkBytes - 1) / kScanChunkBytes, 0u);  // chunks without an FF count zero
+    return end;
 }
 
 ParseStatus finish_frame(FrameInfo* f)
@@ -307,7 +337,8 @@ ParseStatus parse_jpeg(const uint8_t* data, size_t size, FrameInfo* f, bool head
             }
             sc.restart_interval = restart_interval;
             sc.data_begin = pos + L;
-            sc.data_end = find_scan_end(data, sc.data_begin, size, &sc.plain_stuffing, headers_only ? nullptr : &sc.rst_after);
+            sc.data_end = find_scan_end(data, sc.data_begin, size, &sc.plain_stuffing, headers_only ? nullptr : &sc.rst_after,
+                                        headers_only ? nullptr : &sc.chunk_drops);
             f->scans.push_back(sc);
             pos = sc.data_end;
             continue;

@@ -44,7 +44,12 @@ struct ScanHeader {
     bool plain_stuffing = true;  // the segment consists of data bytes, FF 00 pairs and RSTn markers in their proper order
                                  // (no fill bytes, no lone FF at the end of the input)
     std::vector<uint32_t> rst_after;  // per RSTn marker: offset of the byte behind it in the destuffed segment
+    // per kScanChunkBytes-byte chunk of [data_begin, data_end): how many of its bytes byte-stuffing removal drops (the 00 behind an
+    // FF, both bytes of an RSTn marker).  The marker walk sees every FF anyway; the GPU entropy stage takes these counts instead of
+    // counting again (gpu_huffman.hip destuff_count_kernel).  Meaningful for plain_stuffing scans only.
+    std::vector<uint32_t> chunk_drops;
 };
+constexpr size_t kScanChunkBytes = 16384;
 
 struct FrameInfo {
     int width = 0, height = 0, precision = 8, ncomp = 0;
