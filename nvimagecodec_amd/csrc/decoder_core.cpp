@@ -884,13 +884,13 @@ hipjpegStatus_t DecodeBatch::enqueue_gpu_entropy(void* stream)
     entropy_done_ = true;
     if (huff_units_.empty() && prog_units_.empty()) return HIPJPEG_STATUS_SUCCESS;
     EntropyLaunch L = entropy_launch_args();
-    if (hipMemsetAsync(L.changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+    if (huff_chunk_units_.empty() && hipMemsetAsync(L.changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;  // (else: the compact kernel clears them)
     // the per-chunk counts of bytes to drop came up with the bitstreams (the parser's marker walk sees every FF anyway);
     // HIPJPEG_DEVICE_DESTUFF_COUNT=1 counts them on the device as round 1 did (A/B and cross-check aid)
     static const bool device_count = getenv("HIPJPEG_DEVICE_DESTUFF_COUNT") != nullptr;
     if (launch_destuff(L.dimg, reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(),
                        device_count ? reinterpret_cast<uint32_t*>(work_.data() + work_drops_) : reinterpret_cast<uint32_t*>(device_.data() + huff_drops_offset_),
-                       device_count, stream) != 0)
+                       device_count, L.changed, stream) != 0)
         return HIPJPEG_STATUS_HIP_ERROR;
     if (!prog_units_.empty()) {
         const hipjpegStatus_t ps = enqueue_progressive(stream);

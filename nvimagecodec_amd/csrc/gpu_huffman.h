@@ -15,7 +15,9 @@ struct HuffUnit {
 // Byte-stuffing removal (count + compact): chunk_units[i] = {image, chunk index inside the image}; drops = one uint32 per chunk.
 // Writes HuffImage::stream contents and total_bits / num_subseq / stream_words.
 // count_on_device = false: `drops` already holds the per-chunk counts (from the host's marker walk)
-int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, bool count_on_device, void* stream);
+// counters: 64 words the compact kernel clears (the stage's convergence counters)
+int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, bool count_on_device, unsigned int* counters,
+                   void* stream);
 
 // pool_bytes = dynamic LDS for the lookup tables: 2 * the largest HuffImage::pool_words of the batch
 // units[i].first = first owned subsequence of workgroup i, a multiple of kHuffOwn; incoming = one uint64 per unit

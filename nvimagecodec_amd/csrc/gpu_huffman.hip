@@ -311,8 +311,11 @@ __global__ __launch_bounds__(kThreads) void destuff_count_kernel(const HuffImage
 }
 
 __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
-                                                                   const uint32_t* __restrict__ drops)
+                                                                   const uint32_t* __restrict__ drops, unsigned int* __restrict__ counters)
 {
+    // the stage's convergence counters (64 words) start at zero: cleared here, by the first kernel of the stage, instead of by a
+    // fill kernel of their own in front of it
+    if (blockIdx.x == 0 && threadIdx.x < 64 && counters) counters[threadIdx.x] = 0u;
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t wave_base[4];
     __shared__ uint32_t out_words[kDestuffChunk / 4 + 2];
@@ -1226,12 +1229,13 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
 
 }  // namespace
 
-int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, bool count_on_device, void* stream)
+int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, bool count_on_device, unsigned int* counters,
+                   void* stream)
 {
     if (nchunks <= 0) return 0;
     if (count_on_device)
         hipLaunchKernelGGL(destuff_count_kernel, dim3(nchunks), dim3(kThreads), 0, (hipStream_t)stream, images, chunk_units, drops);
-    hipLaunchKernelGGL(destuff_compact_kernel, dim3(nchunks), dim3(kThreads), 0, (hipStream_t)stream, images, chunk_units, drops);
+    hipLaunchKernelGGL(destuff_compact_kernel, dim3(nchunks), dim3(kThreads), 0, (hipStream_t)stream, images, chunk_units, drops, counters);
     return (int)hipGetLastError();
 }
 
