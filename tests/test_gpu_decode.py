@@ -214,7 +214,7 @@ def test_coefficient_files_on_each_pass1_arithmetic(dec):
                 if fmt == "rgb_planar":
                     ref = ref.transpose(2, 0, 1)
                 assert np.array_equal(got, ref), (case[0], gh, fmt)
-                if gh:  # the table bound decides for GPU-decoded streams: 1023 x the largest AC quantizer
+                if gh and not os.environ.get("HIPJPEG_NO_PK16"):  # the table bound decides for GPU-decoded streams: 1023 x the largest AC quantizer
                     packed = 1023 * case[2] <= 32767
                     assert (plane[2] + sum(luma[6:9]) > 0) == packed, (case[0], fmt, plane, luma)
                     assert (plane[0] + plane[1] + sum(luma[0:6]) > 0) == (not packed), (case[0], fmt, plane, luma)
