@@ -1,4 +1,5 @@
 """Dev tool: where the caller's thread spends its time in the pipelined end-to-end decode (configs[1], three batches in flight)."""
+import gc
 import os
 import sys
 import time
@@ -17,6 +18,8 @@ for k in range(3):
 torch.cuda.synchronize()
 K = int(os.environ.get('E2E_STEPS', '60'))
 ts, tw = [], []
+if os.environ.get('E2E_NO_GC'):
+    gc.disable()
 t0 = time.perf_counter()
 for i in range(K):
     a = time.perf_counter()
