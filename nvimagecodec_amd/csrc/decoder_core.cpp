@@ -209,6 +209,7 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     ScopedRange range("hipjpeg plan (parse headers, lay out staging)");
     fault_point("plan");
     finalized_ = false;
+    host_drops_missing_.store(false, std::memory_order_relaxed);
     // (every element is reset by its own prepare() below -- on the pool: a batch of a thousand small pictures spent a third of its
     // plan() clearing these two arrays on the caller's thread)
     images_.resize((size_t)n);
@@ -582,7 +583,11 @@ void DecodeBatch::stage_chunk_drops(const ScanHeader& sc, uint32_t first_chunk)
     static_assert(kScanChunkBytes == (size_t)kDestuffChunk, "the parser counts in the destuff kernels' chunks");
     uint32_t* dst = reinterpret_cast<uint32_t*>(pinned_.data() + huff_drops_offset_) + first_chunk;
     const size_t chunks = (sc.data_end - sc.data_begin + kScanChunkBytes - 1) / kScanChunkBytes;
-    for (size_t c = 0; c < chunks; c++) dst[c] = c < sc.chunk_drops.size() ? sc.chunk_drops[c] : 0u;
+    if (sc.chunk_drops.size() != chunks) {  // a frame that was parsed without the walk's counts: the device counts for this batch
+        host_drops_missing_.store(true, std::memory_order_relaxed);
+        return;
+    }
+    memcpy(dst, sc.chunk_drops.data(), chunks * sizeof(uint32_t));
 }
 
 void DecodeBatch::entropy_stage(int i)
@@ -887,7 +892,8 @@ hipjpegStatus_t DecodeBatch::enqueue_gpu_entropy(void* stream)
     if (huff_chunk_units_.empty() && hipMemsetAsync(L.changed, 0, 256, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;  // (else: the compact kernel clears them)
     // the per-chunk counts of bytes to drop came up with the bitstreams (the parser's marker walk sees every FF anyway);
     // HIPJPEG_DEVICE_DESTUFF_COUNT=1 counts them on the device as round 1 did (A/B and cross-check aid)
-    static const bool device_count = getenv("HIPJPEG_DEVICE_DESTUFF_COUNT") != nullptr;
+    static const bool force_device_count = getenv("HIPJPEG_DEVICE_DESTUFF_COUNT") != nullptr;
+    const bool device_count = force_device_count || host_drops_missing_.load(std::memory_order_relaxed);
     if (launch_destuff(L.dimg, reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(),
                        device_count ? reinterpret_cast<uint32_t*>(work_.data() + work_drops_) : reinterpret_cast<uint32_t*>(device_.data() + huff_drops_offset_),
                        device_count, L.changed, stream) != 0)

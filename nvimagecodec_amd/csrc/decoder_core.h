@@ -5,6 +5,7 @@
 // MI355X counterpart of the reference's per-thread {pinned buffer, device buffer, stream} resources
 // (extensions/nvjpeg/cuda_decoder.h:54-75), but sized for a whole batch so the device stage is one launch per kernel.
 #pragma once
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <vector>
@@ -190,6 +191,7 @@ private:
     size_t work_first_block_ = 0, work_changed_ = 0, work_incoming_ = 0, work_tail_ = 0, work_dc_diff_ = 0, work_block_pos_ = 0, work_drops_ = 0, work_streams_ = 0, work_group_sums_ = 0;
     size_t huff_chunk_units_offset_ = 0, huff_wunits_offset_ = 0, max_huff_wunits_ = 0;
     size_t huff_drops_offset_ = 0;  // per destuff chunk: bytes to drop, counted by the parser's marker walk (ScanHeader::chunk_drops)
+    std::atomic<bool> host_drops_missing_{false};  // set by a host task that found a scan without counts: the device counts instead
     std::vector<TransformImage> xform_desc_;
     std::vector<WorkUnit> xform_units_;
     size_t xform_desc_offset_ = 0, xform_units_offset_ = 0;
