@@ -48,7 +48,10 @@ constexpr int kSyncThreads = HJ_SYNC_THREADS;  // lanes of a workgroup of the sy
 constexpr int kHuffOwn = kSyncThreads - 1;     // subsequences such a workgroup owns (one lane is the halo)
 constexpr int kTailTaskBytes = 2 * kSyncThreads;  // per workgroup: the subsequences (uint16) it hands to the tail kernel
 constexpr int kHuffBlocksPerWg = 256;   // lanes per workgroup of the block pass (one block per lane per round)
-constexpr int kHuffMcusPerWg = 128;     // MCUs a workgroup of the block pass covers
+#ifndef HJ_MCUS_PER_WG
+#define HJ_MCUS_PER_WG 128  // entropy stage per 256 x 1080p: 64 -> 2.12 ms, 128 -> 1.99, 256 -> 1.99, 512 -> 2.02 (tools/ab_full_flag.sh)
+#endif
+constexpr int kHuffMcusPerWg = HJ_MCUS_PER_WG;     // MCUs a workgroup of the block pass covers
 constexpr int kDestuffChunk = 16384;   // raw bytes one workgroup of the destuff kernels handles
 constexpr int kMaxPoolWords = 12288;   // uint16 entries of lookup tables per image the kernels accept (24 KB of LDS)
 
