@@ -59,8 +59,19 @@ def lib():
         L.oj_encode.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_int, u8p, ctypes.c_size_t]
         L.oj_encode.restype = ctypes.c_long
+        L.oj_set_idct_variant.argtypes = [ctypes.c_int]
+        L.oj_set_idct_variant.restype = None
         _lib = L
     return _lib
+
+
+IDCT_SIMD, IDCT_C = 0, 1
+
+
+def set_idct_variant(variant):
+    """Which jpeg_idct_islow the decode functions restate: IDCT_SIMD (default; libjpeg-turbo's x86-64 SIMD routine, what the reference's
+    CPU path runs) or IDCT_C (jidctint.c, what JSIMD_FORCENONE=1 selects).  They agree on every stream an encoder can write."""
+    lib().oj_set_idct_variant(int(variant))
 
 
 def _buf(data):

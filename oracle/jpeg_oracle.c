@@ -12,7 +12,9 @@
  * an un-vendored submodule that is NOT under /root/reference.  The steps below therefore restate
  * libjpeg-turbo's published algorithm (file names of that library given per function):
  *   entropy decode    jdhuff.c / jdphuff.c   (ITU T.81 Annex F / G)
- *   dequant + IDCT    jidctint.c jpeg_idct_islow (CONST_BITS 13, PASS1_BITS 2) + range-limit table (jdmaster.c)
+ *   dequant + IDCT    jpeg_idct_islow (CONST_BITS 13, PASS1_BITS 2) as the x86-64 SIMD builds run it (jidctint-sse2/avx2.asm; default)
+ *                     and as jidctint.c + the range-limit table of jdmaster.c do (oj_set_idct_variant(1)); equal on every stream an
+ *                     encoder can write, different out of gamut -- see oj_idct_block_simd
  *   upsampling        jdsample.c h2v1_fancy / h2v2_fancy / h1v2_fancy / int_upsample (replication)
  *   colour            jdcolor.c ycc_rgb_convert (SCALEBITS 16), gray->rgb, rgb passthrough
  *   encode            jccolor.c, jcsample.c, jfdctint.c, jcdctmgr.c, jcparam.c, jchuff.c, jcmarker.c
@@ -680,56 +682,52 @@ static int oj_parse(oj_dec* d, const uint8_t* data, size_t len, int want_coef)
 
 #define OJ_DESCALE(x, n) (((x) + ((int32_t)1 << ((n)-1))) >> (n))
 
-/* int32 arithmetic wraps modulo 2^32 exactly like the compiled C of libjpeg on two's-complement targets */
-static inline int32_t w_mul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
-static inline int32_t w_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
-static inline int32_t w_sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
-static inline int32_t w_shl(int32_t a, int n) { return (int32_t)((uint32_t)a << n); }
-
+/* jidctint.c computes in JLONG -- `long`, 64 bits on the LP64 targets the reference builds for -- and stores pass 1 into an `int`
+ * workspace; nothing wraps before that store. */
 static void oj_idct1d(const int32_t in[8], int32_t out[8], int shift)
 {
-    int32_t z1, z2, z3, z4, z5, tmp0, tmp1, tmp2, tmp3, tmp10, tmp11, tmp12, tmp13;
-    int32_t rnd = (int32_t)1 << (shift - 1);
+    int64_t z1, z2, z3, z4, z5, tmp0, tmp1, tmp2, tmp3, tmp10, tmp11, tmp12, tmp13;
+    const int64_t rnd = (int64_t)1 << (shift - 1);
     z2 = in[2];
     z3 = in[6];
-    z1 = w_mul(w_add(z2, z3), F_0_541);
-    tmp2 = w_add(z1, w_mul(z3, -F_1_847));
-    tmp3 = w_add(z1, w_mul(z2, F_0_765));
-    tmp0 = w_shl(w_add(in[0], in[4]), 13);
-    tmp1 = w_shl(w_sub(in[0], in[4]), 13);
-    tmp10 = w_add(tmp0, tmp3);
-    tmp13 = w_sub(tmp0, tmp3);
-    tmp11 = w_add(tmp1, tmp2);
-    tmp12 = w_sub(tmp1, tmp2);
+    z1 = (z2 + z3) * F_0_541;
+    tmp2 = z1 + z3 * -F_1_847;
+    tmp3 = z1 + z2 * F_0_765;
+    tmp0 = ((int64_t)in[0] + in[4]) * 8192;
+    tmp1 = ((int64_t)in[0] - in[4]) * 8192;
+    tmp10 = tmp0 + tmp3;
+    tmp13 = tmp0 - tmp3;
+    tmp11 = tmp1 + tmp2;
+    tmp12 = tmp1 - tmp2;
     tmp0 = in[7];
     tmp1 = in[5];
     tmp2 = in[3];
     tmp3 = in[1];
-    z1 = w_add(tmp0, tmp3);
-    z2 = w_add(tmp1, tmp2);
-    z3 = w_add(tmp0, tmp2);
-    z4 = w_add(tmp1, tmp3);
-    z5 = w_mul(w_add(z3, z4), F_1_175);
-    tmp0 = w_mul(tmp0, F_0_298);
-    tmp1 = w_mul(tmp1, F_2_053);
-    tmp2 = w_mul(tmp2, F_3_072);
-    tmp3 = w_mul(tmp3, F_1_501);
-    z1 = w_mul(z1, -F_0_899);
-    z2 = w_mul(z2, -F_2_562);
-    z3 = w_add(w_mul(z3, -F_1_961), z5);
-    z4 = w_add(w_mul(z4, -F_0_390), z5);
-    tmp0 = w_add(tmp0, w_add(z1, z3));
-    tmp1 = w_add(tmp1, w_add(z2, z4));
-    tmp2 = w_add(tmp2, w_add(z2, z3));
-    tmp3 = w_add(tmp3, w_add(z1, z4));
-    out[0] = w_add(w_add(tmp10, tmp3), rnd) >> shift;
-    out[7] = w_add(w_sub(tmp10, tmp3), rnd) >> shift;
-    out[1] = w_add(w_add(tmp11, tmp2), rnd) >> shift;
-    out[6] = w_add(w_sub(tmp11, tmp2), rnd) >> shift;
-    out[2] = w_add(w_add(tmp12, tmp1), rnd) >> shift;
-    out[5] = w_add(w_sub(tmp12, tmp1), rnd) >> shift;
-    out[3] = w_add(w_add(tmp13, tmp0), rnd) >> shift;
-    out[4] = w_add(w_sub(tmp13, tmp0), rnd) >> shift;
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    z4 = tmp1 + tmp3;
+    z5 = (z3 + z4) * F_1_175;
+    tmp0 *= F_0_298;
+    tmp1 *= F_2_053;
+    tmp2 *= F_3_072;
+    tmp3 *= F_1_501;
+    z1 *= -F_0_899;
+    z2 *= -F_2_562;
+    z3 = z3 * -F_1_961 + z5;
+    z4 = z4 * -F_0_390 + z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    out[0] = (int32_t)((tmp10 + tmp3 + rnd) >> shift);
+    out[7] = (int32_t)((tmp10 - tmp3 + rnd) >> shift);
+    out[1] = (int32_t)((tmp11 + tmp2 + rnd) >> shift);
+    out[6] = (int32_t)((tmp11 - tmp2 + rnd) >> shift);
+    out[2] = (int32_t)((tmp12 + tmp1 + rnd) >> shift);
+    out[5] = (int32_t)((tmp12 - tmp1 + rnd) >> shift);
+    out[3] = (int32_t)((tmp13 + tmp0 + rnd) >> shift);
+    out[4] = (int32_t)((tmp13 - tmp0 + rnd) >> shift);
 }
 
 /* post-IDCT range-limit table lookup (jdmaster.c prepare_range_limit_table), index = v & 1023 */
@@ -742,12 +740,13 @@ static inline uint8_t oj_range_limit(int32_t v)
     return (uint8_t)(i - 896);
 }
 
-static void oj_idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, int out_stride)
+static void oj_idct_block_c(const int16_t* coef, const uint16_t* q, uint8_t* out, int out_stride)
 {
     int32_t ws[64], in[8], o[8];
     int c, r;
     for (c = 0; c < 8; c++) {
-        for (r = 0; r < 8; r++) in[r] = w_mul((int32_t)coef[r * 8 + c], (int32_t)q[r * 8 + c]);
+        /* jidctint.c DEQUANTIZE: ((ISLOW_MULT_TYPE)coef) * quantval with both operands 16-bit (jddctmgr.c stores the table as short) */
+        for (r = 0; r < 8; r++) in[r] = (int32_t)coef[r * 8 + c] * (int32_t)(int16_t)q[r * 8 + c];
         oj_idct1d(in, o, 11); /* CONST_BITS - PASS1_BITS */
         for (r = 0; r < 8; r++) ws[r * 8 + c] = o[r];
     }
@@ -755,6 +754,88 @@ static void oj_idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, 
         oj_idct1d(&ws[r * 8], o, 18); /* CONST_BITS + PASS1_BITS + 3 */
         for (c = 0; c < 8; c++) out[r * out_stride + c] = oj_range_limit(o[c]);
     }
+}
+
+/* ---------------------------------------------------------------- IDCT as libjpeg-turbo's x86-64 SIMD builds compute it
+ * (simd/x86_64/jidctint-sse2.asm / jidctint-avx2.asm, jsimd_idct_islow_*): the function the reference's CPU path actually runs --
+ * extensions/libjpeg_turbo/jpeg_mem.cpp:174-177 selects JDCT_ISLOW and external/build_libjpeg-turbo.sh:36-39 builds the library with
+ * its defaults (WITH_SIMD on).  For every stream an encoder can produce it equals jidctint.c; out of gamut it does not, because it
+ * works on 16-bit lanes:
+ *   - dequantization is pmullw: the low 16 bits of coefficient x quantizer;
+ *   - if rows 1..7 of the (undequantized) block are all zero, pass 1 is skipped: workspace = row 0 << PASS1_BITS in 16 bits (psllw, wraps);
+ *   - in0 +- in4 and the odd part's z3 = in7 + in3, z4 = in5 + in1 are 16-bit additions (paddw / psubw, wrap);
+ *   - all products are pmaddwd on (value, value) x (constant, constant) pairs, exact in 32 bits, sums never leave int32;
+ *   - pass 1 results are packed with signed saturation to int16 (packssdw), pass 2 results saturate to int16, then to int8
+ *     (packsswb) and get +128 (paddb): a true clamp instead of jidctint.c's range-limit table indexed modulo 1024.
+ * Restated from the published algorithm and pinned by vectors from the real library (tests/golden/make_golden_simd_idct.py: Pillow's
+ * libjpeg-turbo 3.1.4.1 in its default AVX2 dispatch and with JSIMD_FORCESSE2=1 -- identical pictures; JSIMD_FORCENONE=1 gives
+ * oj_idct_block_c's). */
+static inline int32_t w16(int32_t v) { return (int32_t)(int16_t)(uint16_t)v; }
+static inline int32_t s16(int32_t v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+static void oj_idct1d_simd(const int32_t in[8], int32_t out[8], int shift)
+{
+    /* inputs are int16 values; every sum below fits int32 (|.| < 1.7e9) */
+    const int32_t rnd = (int32_t)1 << (shift - 1);
+    int32_t tmp3 = in[2] * (F_0_541 + F_0_765) + in[6] * F_0_541;
+    int32_t tmp2 = in[2] * F_0_541 + in[6] * (F_0_541 - F_1_847);
+    int32_t tmp0 = w16(in[0] + in[4]) * 8192;
+    int32_t tmp1 = w16(in[0] - in[4]) * 8192;
+    int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    int32_t z3 = w16(in[7] + in[3]), z4 = w16(in[5] + in[1]);
+    int32_t z3n = z3 * (F_1_175 - F_1_961) + z4 * F_1_175;
+    int32_t z4n = z3 * F_1_175 + z4 * (F_1_175 - F_0_390);
+    int32_t t0 = in[7] * (F_0_298 - F_0_899) + in[1] * -F_0_899 + z3n;
+    int32_t t3 = in[7] * -F_0_899 + in[1] * (F_1_501 - F_0_899) + z4n;
+    int32_t t1 = in[5] * (F_2_053 - F_2_562) + in[3] * -F_2_562 + z4n;
+    int32_t t2 = in[5] * -F_2_562 + in[3] * (F_3_072 - F_2_562) + z3n;
+    out[0] = s16((tmp10 + t3 + rnd) >> shift);
+    out[7] = s16((tmp10 - t3 + rnd) >> shift);
+    out[1] = s16((tmp11 + t2 + rnd) >> shift);
+    out[6] = s16((tmp11 - t2 + rnd) >> shift);
+    out[2] = s16((tmp12 + t1 + rnd) >> shift);
+    out[5] = s16((tmp12 - t1 + rnd) >> shift);
+    out[3] = s16((tmp13 + t0 + rnd) >> shift);
+    out[4] = s16((tmp13 - t0 + rnd) >> shift);
+}
+
+static void oj_idct_block_simd(const int16_t* coef, const uint16_t* q, uint8_t* out, int out_stride)
+{
+    int32_t ws[64], in[8], o[8];
+    int c, r, k, ac_rows = 0;
+    for (k = 8; k < 64; k++) ac_rows |= coef[k];
+    if (!ac_rows) {
+        for (c = 0; c < 8; c++) {
+            int32_t v = w16(w16((int32_t)coef[c] * (int32_t)q[c]) * 4);
+            for (r = 0; r < 8; r++) ws[r * 8 + c] = v;
+        }
+    } else {
+        for (c = 0; c < 8; c++) {
+            for (r = 0; r < 8; r++) in[r] = w16((int32_t)coef[r * 8 + c] * (int32_t)q[r * 8 + c]);
+            oj_idct1d_simd(in, o, 11);
+            for (r = 0; r < 8; r++) ws[r * 8 + c] = o[r];
+        }
+    }
+    for (r = 0; r < 8; r++) {
+        oj_idct1d_simd(&ws[r * 8], o, 18);
+        for (c = 0; c < 8; c++) {
+            int32_t v = o[c] < -128 ? -128 : (o[c] > 127 ? 127 : o[c]);
+            out[r * out_stride + c] = (uint8_t)(v + 128);
+        }
+    }
+}
+
+/* 0 = the SIMD builds' arithmetic (default: what the reference's libjpeg-turbo runs on x86-64), 1 = jidctint.c (JSIMD_FORCENONE=1) */
+static int oj_idct_variant = 0;
+void oj_set_idct_variant(int v) { oj_idct_variant = v; }
+int oj_get_idct_variant(void) { return oj_idct_variant; }
+
+static void oj_idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, int out_stride)
+{
+    if (oj_idct_variant)
+        oj_idct_block_c(coef, q, out, out_stride);
+    else
+        oj_idct_block_simd(coef, q, out, out_stride);
 }
 
 /* IDCT a whole component into a (bw*8) x (bh*8) plane */

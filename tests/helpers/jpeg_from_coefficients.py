@@ -70,17 +70,24 @@ def _magnitude(v):
 
 def write_baseline(width, height, sampling, coefficients, qtables):
     """sampling: [(h, v)] per component; coefficients[c]: int array [blocks_h][blocks_w][64] in natural (row-major) order over the
-    MCU-padded block grid, DC values absolute; qtables[c]: 64 quantizers in natural order (values 1..255).  Component 0 uses the
-    luminance Huffman tables, the others the chrominance ones.  Returns the file as bytes."""
+    MCU-padded block grid, DC values absolute; qtables[c]: 64 quantizers in natural order (values 1..255; any value above 255 in a
+    table makes it a 16-bit table and the frame an extended-sequential one, SOF1).  Component 0 uses the luminance Huffman tables,
+    the others the chrominance ones.  DC values may leave int16 as long as successive differences fit 11 bits: libjpeg keeps the
+    predictor in an int and stores its low 16 bits in the block.  Returns the file as bytes."""
     ncomp = len(sampling)
     hmax, vmax = max(h for h, _ in sampling), max(v for _, v in sampling)
     mcus_x, mcus_y = -(-width // (8 * hmax)), -(-height // (8 * vmax))
     out = bytearray(b"\xff\xd8")
+    wide = False
     for c in range(ncomp):
         q = [int(qtables[c][ZIGZAG[k]]) for k in range(64)]
-        assert all(1 <= x <= 255 for x in q)
-        out += b"\xff\xdb" + (67).to_bytes(2, "big") + bytes([c]) + bytes(q)
-    out += b"\xff\xc0" + (8 + 3 * ncomp).to_bytes(2, "big") + b"\x08" + height.to_bytes(2, "big") + width.to_bytes(2, "big") + bytes([ncomp])
+        assert all(1 <= x <= 65535 for x in q)
+        if max(q) > 255:
+            wide = True
+            out += b"\xff\xdb" + (131).to_bytes(2, "big") + bytes([0x10 | c]) + b"".join(x.to_bytes(2, "big") for x in q)
+        else:
+            out += b"\xff\xdb" + (67).to_bytes(2, "big") + bytes([c]) + bytes(q)
+    out += (b"\xff\xc1" if wide else b"\xff\xc0") + (8 + 3 * ncomp).to_bytes(2, "big") + b"\x08" + height.to_bytes(2, "big") + width.to_bytes(2, "big") + bytes([ncomp])
     for c, (h, v) in enumerate(sampling):
         out += bytes([c + 1, (h << 4) | v, c])
     tables = [(0x00, DC_LUMA), (0x10, AC_LUMA)] + ([(0x01, DC_CHROMA), (0x11, AC_CHROMA)] if ncomp > 1 else [])
@@ -103,7 +110,7 @@ def write_baseline(width, height, sampling, coefficients, qtables):
                         diff = int(blk[0]) - pred[c]
                         pred[c] = int(blk[0])
                         nb, bits = _magnitude(diff)
-                        assert nb <= 11
+                        assert nb <= 11, "DC difference beyond category 11"
                         bw.put(*dc_codes[c][nb])
                         if nb:
                             bw.put(bits, nb)

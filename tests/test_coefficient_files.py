@@ -1,7 +1,6 @@
 """Files written from chosen coefficients (tests/helpers/jpeg_from_coefficients.py): the writer is pinned against the oracle's entropy
 decoder (same coefficients back) and -- where Pillow is importable -- the oracle's pixels against the real libjpeg-turbo on these
-files, whose dequantized values sit at the edges where the GPU kernels change arithmetic (packed int16 pass 1 up to
-|coefficient x quantizer| = 32767, 24-bit multipliers above, 32-bit multipliers beyond 2^21)."""
+files, whose dequantized values sit around the int16 edges of the library's SIMD IDCT."""
 import io
 import os
 import sys
@@ -57,12 +56,15 @@ def test_writer_round_trips_through_the_oracle_entropy_decoder(case):
         assert np.array_equal(qts[c].astype(np.int32), qt[c])
 
 
-@pytest.mark.parametrize("case", IN_GAMUT, ids=[c[0] for c in IN_GAMUT])
+@pytest.mark.parametrize("case", CASES + IN_GAMUT, ids=[c[0] for c in CASES + IN_GAMUT])
 def test_oracle_matches_libjpeg_turbo_on_coefficient_files(case):
-    """Out of gamut (CASES) there is nothing to pin against: libjpeg-turbo's own two IDCTs part ways -- jidctint.c indexes the range-limit
-    table modulo 1024 and keeps 32-bit intermediates, the SIMD builds (what Pillow ships) add coefficients as int16 and pack the
-    workspace with saturation.  The oracle and the kernels follow jidctint.c there; `test_simd_and_c_idct_part_ways_out_of_gamut` records it."""
+    """In gamut libjpeg-turbo's C and SIMD IDCTs agree.  Out of gamut (CASES) they part ways -- jidctint.c indexes the range-limit table
+    modulo 1024 and keeps wide intermediates, the SIMD routines (what Pillow ships and what the reference links on x86-64) multiply and
+    add in 16-bit lanes and saturate the workspace and the result.  The oracle's default variant restates the SIMD routine (round 3;
+    pinned by tests/golden/gamut, tests/test_gamut_golden.py) and must equal the live library on all of them."""
     Image = pytest.importorskip("PIL.Image")
+    if os.environ.get("JSIMD_FORCENONE"):
+        pytest.skip("this process was told to run libjpeg-turbo's C routines")
     data, _, _ = make_case(*case)
     im = Image.open(io.BytesIO(data))
     im.draft = lambda *a, **k: None
@@ -74,12 +76,15 @@ def test_oracle_matches_libjpeg_turbo_on_coefficient_files(case):
 
 
 def test_simd_and_c_idct_part_ways_out_of_gamut():
-    """Documents WHY the out-of-gamut cases are pinned by the oracle alone: on a file whose samples leave the 10-bit range of the
-    range-limit table the SIMD build of libjpeg-turbo (Pillow's) and the jidctint.c restatement give different pictures."""
-    Image = pytest.importorskip("PIL.Image")
+    """The two restatements in the oracle really are different functions on these files (and equal in gamut)."""
     data, _, _ = make_case(*CASES[0])
-    ref = np.asarray(Image.open(io.BytesIO(data)))
-    got = oracle.decode(data, oracle.FMT_GRAY)
-    if np.array_equal(got, ref):
-        pytest.skip("this libjpeg-turbo build runs the C IDCT (no SIMD): the two agree here")
-    assert got.shape == ref.shape
+    simd = oracle.decode(data, oracle.FMT_GRAY)
+    oracle.set_idct_variant(oracle.IDCT_C)
+    try:
+        plain = oracle.decode(data, oracle.FMT_GRAY)
+        data2, _, _ = make_case(*IN_GAMUT[0])
+        plain2 = oracle.decode(data2, oracle.FMT_GRAY)
+    finally:
+        oracle.set_idct_variant(oracle.IDCT_SIMD)
+    assert not np.array_equal(simd, plain)
+    assert np.array_equal(oracle.decode(data2, oracle.FMT_GRAY), plain2)
