@@ -455,11 +455,10 @@ def main():
     dec.transfer()
     torch.cuda.synchronize()
     gst = dec.stats()
-    # which instantiations the batch was given (pass-1 arithmetic of the IDCT: 0 = 24-bit multiplier, 1 = 32-bit, 2 = packed int16)
+    # which instantiation of the fused luma kernel the batch was given (layout: 0 generic, 1 everyday interleaved, 2 everyday planar)
     plane_fl, luma_fl = dec.kernel_flavours()
-    k1_name = "idct_plane_kernel<%d>" % max(range(3), key=lambda e: plane_fl[e])
-    k2_fl = max(range(9), key=lambda e: luma_fl[e])  # = arithmetic x 3 + layout (0 generic, 1 everyday interleaved, 2 everyday planar)
-    k2_name = "luma_color_kernel<%d, 2, 2, %d>" % (k2_fl // 3, k2_fl % 3)
+    k1_name = "idct_plane_kernel"
+    k2_name = "luma_color_kernel<2, 2, %d>" % max(range(3), key=lambda e: luma_fl[e])
     assert gst["gpu_entropy_images"] == BATCH, "the bench batch must take the GPU entropy stage"
 
     def step(ev=None):

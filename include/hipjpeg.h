@@ -114,11 +114,9 @@ HIPJPEG_API int hipjpegTestDoubleReports(void);
 /* Test hook: how many images of the handle's last settled batch the GPU entropy stage handed back to the host entropy decoder
  * (damaged streams, and periodic streams whose corrections would have to travel through the image subsequence by subsequence). */
 HIPJPEG_API int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle);
-/* Test hook: work units of the handle's current batch per kernel flavour -- plane_units[3]: IDCT pass 1 on the 24-bit multiplier,
- * the 32-bit multiplier, packed int16 pairs; luma_units[9]: index = that arithmetic x 3 + layout (0 generic, 1 the everyday interleaved
- * kernel, 2 the everyday planar kernel; csrc/decode_kernels.h PlaneFlavour / luma_flavour).  Tests use it to see that a crafted file took
- * the arithmetic it was crafted for. */
-HIPJPEG_API hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[3], int32_t luma_units[9]);
+/* Test hook: work units of the handle's current batch per kernel -- plane_units[0]: the plane IDCT kernel (K1); luma_units[3]: the fused
+ * luma kernel (K2) by layout (0 generic, 1 the everyday interleaved kernel, 2 the everyday planar kernel; csrc/decode_kernels.h). */
+HIPJPEG_API hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[1], int32_t luma_units[3]);
 
 /* Test hook (host only): the parser's per-chunk counts of the bytes that byte-stuffing removal drops from scan `scan_index` (16,384-byte
  * chunks of the entropy-coded segment; the GPU entropy stage's compact kernel works from them).  Returns the number of chunks, or a

@@ -5,11 +5,11 @@
 // Profiling the first version (one lane per block, ~200 VGPRs, 2 waves/SIMD) showed it VALU-issue bound at ~4 cycles
 // per instruction even with every memory stream ablated, so the design goal here is register economy -> occupancy:
 //   * TWO LANES own one 8x8 block (lane pair 2k, 2k+1; p = lane & 1).  Lane p runs the column pass of columns
-//     4p..4p+3, then the pair swaps half of the workspace with one DPP move per value, and lane p runs the row pass of
-//     four rows.  The ISLOW butterfly is an exact integer-linear map followed by one rounding shift, and negating its
-//     odd-frequency inputs reverses its output order exactly (mod 2^32).  Lane 1 therefore multiplies odd rows by -q in
-//     the dequantizer (a second quant table prepared by the host) and gets its column results in the order 7..0: both
-//     lanes then "keep registers 0..3, send registers 4..7" -- no per-lane selects in the exchange.
+//     4p..4p+3, the pair swaps half of the (int16, packed) workspace with one v_cndmask_b32_dpp per register, and lane p
+//     runs the row pass of four rows (lane 0 rows 0..3, lane 1 rows 7..4).
+//   * the arithmetic is that of libjpeg-turbo's SIMD jpeg_idct_islow (the routine the reference's CPU path runs): values
+//     live as int16 pairs, products are v_dot2_i32_i16 (= pmaddwd), the workspace is packed with saturation
+//     (v_cvt_pk_i16_i32 = packssdw) -- see idct1d_pk.
 //   * coefficient blocks are fetched from HBM with fully coalesced 16 B/lane loads (a wave reads 4 KB contiguous), staged
 //     through LDS at a 144-byte block stride, and each lane pulls its four 16-byte column chunks back out.  The host
 //     stores blocks column-major so one chunk is one IDCT column.
@@ -18,8 +18,8 @@
 //     leave the wave as fully coalesced 16-byte stores.
 //   * work is described by WorkUnit tables so a batch of different-shaped images is ONE launch per kernel.
 //
-// Arithmetic is the integer arithmetic of libjpeg-turbo's jidctint.c / jdsample.c / jdcolor.c, restated; results are
-// compared bit-for-bit with the CPU oracle in tests/.
+// Arithmetic is the integer arithmetic of libjpeg-turbo's jidctint-{sse2,avx2}.asm / jdsample.c / jdcolor.c, restated; results
+// are compared bit-for-bit with the CPU oracle and with vectors from the library itself in tests/.
 #include <hip/hip_runtime.h>
 
 #include "decode_kernels.h"
@@ -48,60 +48,6 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 constexpr int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633;
 constexpr int F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
 
-// EXACT=false: 24-bit multiplier (full rate); exact whenever both operands fit in 24 signed bits, which the host
-// guarantees per image (kFlagExactMul32 otherwise) for pass 1 and which always holds in pass 2 (inputs are int32>>11).
-template <bool EXACT>
-__device__ __forceinline__ int mulc(int a, int c)
-{
-    if constexpr (EXACT)
-        return (int)((unsigned)a * (unsigned)c);
-    else
-        return __mul24(a, c);
-}
-
-__device__ __forceinline__ int shl13(int a) { return (int)((unsigned)a << 13); }
-
-// jidctint.c jpeg_idct_islow, one 1-D pass over d[0..7]; the DESCALE rounding term is folded into the even part.
-template <bool EXACT, int SHIFT>
-__device__ __forceinline__ void idct8(int (&d)[8])
-{
-    constexpr int rnd = 1 << (SHIFT - 1);
-    int z2 = d[2], z3 = d[6];
-    int z1 = mulc<EXACT>(z2 + z3, F_0_541);
-    int tmp2 = z1 + mulc<EXACT>(z3, -F_1_847);
-    int tmp3 = z1 + mulc<EXACT>(z2, F_0_765);
-    int tmp0 = shl13(d[0] + d[4]) + rnd;
-    int tmp1 = shl13(d[0] - d[4]) + rnd;
-    int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-    int t0 = d[7], t1 = d[5], t2 = d[3], t3 = d[1];
-    z1 = t0 + t3;
-    z2 = t1 + t2;
-    z3 = t0 + t2;
-    int z4 = t1 + t3;
-    int z5 = mulc<EXACT>(z3 + z4, F_1_175);
-    t0 = mulc<EXACT>(t0, F_0_298);
-    t1 = mulc<EXACT>(t1, F_2_053);
-    t2 = mulc<EXACT>(t2, F_3_072);
-    t3 = mulc<EXACT>(t3, F_1_501);
-    z1 = mulc<EXACT>(z1, -F_0_899);
-    z2 = mulc<EXACT>(z2, -F_2_562);
-    z3 = mulc<EXACT>(z3, -F_1_961) + z5;
-    z4 = mulc<EXACT>(z4, -F_0_390) + z5;
-    t0 += z1 + z3;
-    t1 += z2 + z4;
-    t2 += z2 + z3;
-    t3 += z1 + z4;
-    d[0] = (tmp10 + t3) >> SHIFT;
-    d[7] = (tmp10 - t3) >> SHIFT;
-    d[1] = (tmp11 + t2) >> SHIFT;
-    d[6] = (tmp11 - t2) >> SHIFT;
-    d[2] = (tmp12 + t1) >> SHIFT;
-    d[5] = (tmp12 - t1) >> SHIFT;
-    d[3] = (tmp13 + t0) >> SHIFT;
-    d[4] = (tmp13 - t0) >> SHIFT;
-}
-
-__device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }  // v_med3_i32
 
 // a * k + c in ONE instruction.  hipcc rewrites __mul24 of provably small operands into a plain 32-bit multiply and then emits
 // v_mul_lo_u32 + v_add (seen in the ISA: 130 of them per lane in the colour stage); there is no 32-bit integer mad, so the
@@ -113,15 +59,6 @@ __device__ __forceinline__ int mad24(int a, int k, int c)
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
     return r;
 }
-
-// libjpeg's post-IDCT range-limit table (jdmaster.c prepare_range_limit_table) as arithmetic:
-// index = v & 1023 read as a signed 10-bit number, +128, clamped to [0,255].
-__device__ __forceinline__ int range_limit(int v)
-{
-    int s = __builtin_amdgcn_sbfe(v, 0, 10);
-    return clamp255(s + 128);
-}
-
 
 // ---- two int16 per register (colour stage)
 using i16x2 = __attribute__((ext_vector_type(2))) short;
@@ -226,56 +163,28 @@ __device__ __forceinline__ void fetch_tile_half_block(const DecodeComponent& cd,
     if (dc_apart && !(lane & 1)) cols[0].x = (cols[0].x & 0xFFFF0000u) | dc;
 }
 
-// Dequantize + column pass of this lane's four columns, exchange with the partner lane, and assemble the row-pass inputs.
-//   q: this lane's 32 quantizers, q[j*8 + r] for column 4p+j, with odd rows negated when p == 1 (DecodeComponent::qpair).
-//   rows[i][c]: pass-1 workspace of image row (p ? 7-i : i), column c -- ready for idct8<false,18>.
-template <bool EXACT>
-__device__ __forceinline__ void column_pass_and_exchange(const u32x4 (&cols)[4], const int* __restrict__ q, bool p, int (&rows)[4][8])
-{
-    int keep[4][4], recv[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const unsigned w[4] = {cols[j].x, cols[j].y, cols[j].z, cols[j].w};
-        const int4 qa = *reinterpret_cast<const int4*>(q + j * 8), qb = *reinterpret_cast<const int4*>(q + j * 8 + 4);
-        const int qq[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        int d[8];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int lo = (int)(short)(w[i] & 0xFFFF), hi = (int)w[i] >> 16;
-            // coefficient (int16) x quantizer (|q| < 2^16): exact in the 24-bit multiplier
-            d[2 * i] = __mul24(lo, qq[2 * i]);
-            d[2 * i + 1] = __mul24(hi, qq[2 * i + 1]);
-        }
-        idct8<EXACT, 11>(d);  // lane 0: d[r] = row r; lane 1 (odd inputs negated): d[r] = row 7-r
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            keep[i][j] = d[i];
-            recv[i][j] = pair_swap(d[7 - i]);  // partner's value for MY row i: its register 7-i
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            rows[i][j] = p ? recv[i][j] : keep[i][j];      // columns 0..3 were computed by lane 0
-            rows[i][4 + j] = p ? keep[i][j] : recv[i][j];  // columns 4..7 by lane 1
-        }
-}
-
-// ---- IDCT pass 1 on int16 pairs (kFlagFitsInt16) -----------------------------------------------------------------------
-// jpeg_idct_islow's column pass multiplies every input by ONE integer constant on its way to an output and only adds
-// otherwise, and the descale comes last -- before the shift it is a linear map with integer coefficients, so (mod 2^32, like
-// the butterflies above) regrouping it is exact: out[k] = (sum_i M[k][i] * d[i] + rnd) >> 11.  With the dequantized inputs
-// as int16 pairs the even part is four and the odd part eight v_dot2_i32_i16 (two products and the accumulate in one
-// instruction), plus the twelve additions of the output butterfly: 40 instructions per column with unpacking and
-// dequantization, 20 of them full-price, where the butterfly form takes 58.  Needs |coefficient x quantizer| <= 32767 for
-// every AC position (the host proves it per image from the Huffman tables or the decoded data); the DC term is added
-// exactly, as a 32-bit value, through the accumulator.
+// ---- dequantize + IDCT of one 8x8 block by a lane pair, on int16 pairs ---------------------------------------------------
+// What is restated: jsimd_idct_islow_sse2 / _avx2 of libjpeg-turbo (simd/x86_64/jidctint-*.asm), the routine behind
+// jpeg_idct_islow in the reference's CPU path (extensions/libjpeg_turbo/jpeg_mem.cpp:174-177; the library is built with its
+// defaults, external/build_libjpeg-turbo.sh:36-39).  It equals jidctint.c on every stream an encoder can write and differs out
+// of gamut because it works on 16-bit lanes; those semantics are kept exactly (oracle/jpeg_oracle.c oj_idct_block_simd, pinned
+// by tests/golden/gamut from the library itself):
+//   pmullw      dequantization keeps the low 16 bits of coefficient x quantizer          -> v_pk_mul_lo_u16
+//   paddw/psubw in0 +- in4, z3 = in7 + in3, z4 = in5 + in1 wrap in 16 bits               -> v_pk_add_u16 / v_pk_sub_u16
+//   pmaddwd     every product pairs two values with two constants, exact in 32 bits     -> v_dot2_i32_i16
+//   packssdw    pass-1 results saturate to int16                                         -> v_cvt_pk_i16_i32
+//   psllw       a block whose rows 1..7 are all zero skips pass 1: row 0 << 2 in 16 bits -> v_pk_lshlrev_b16 (rare branch)
+//   packsswb    the result saturates to int8, + 128                                      -> v_sat_pk_u8_i16 / v_pk_max/min_i16
+// No intermediate leaves int32 (|.| < 1.7e9 for int16 inputs), so the 32-bit sums may be regrouped freely; the 16-bit ones may not.
 constexpr unsigned pk16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | (((unsigned)hi & 0xFFFFu) << 16); }
 using u16x2 = __attribute__((ext_vector_type(2))) unsigned short;
 __device__ __forceinline__ unsigned pk_mul16(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)));
 }
 // a.lo * k.lo + a.hi * k.hi + acc, three-operand form pinned: left alone hipcc picks v_dot2c_i32_i16 (accumulator = destination)
 // and spends a v_mov per product on initialising it
@@ -291,80 +200,159 @@ __device__ __forceinline__ int dot2(unsigned a, unsigned k)
     asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(k));
     return r;
 }
-// even rows (d0,d4), (d2,d6): tmp0/tmp1 = (d0 +- d4) << 13, tmp3 = d2*(F_0_541+F_0_765) + d6*F_0_541, tmp2 = d2*F_0_541 + d6*(F_0_541-F_1_847)
-constexpr unsigned kE0p = pk16(8192, 8192), kE0m = pk16(8192, -8192);
-constexpr unsigned kE3 = pk16(F_0_541 + F_0_765, F_0_541), kE2 = pk16(F_0_541, F_0_541 - F_1_847);
-// odd rows: pairs (d1,d5) = (t3,t1) and (d3,d7) = (t2,t0) in idct8's names; T_k = the odd part's contribution to outputs 3-k / 4+k
-constexpr int kT00 = F_0_298 - F_0_899 - F_1_961 + F_1_175, kT01 = F_1_175, kT02 = F_1_175 - F_1_961, kT03 = F_1_175 - F_0_899;
-constexpr int kT10 = F_1_175, kT11 = F_2_053 - F_2_562 - F_0_390 + F_1_175, kT12 = F_1_175 - F_2_562, kT13 = F_1_175 - F_0_390;
-constexpr int kT20 = F_1_175 - F_1_961, kT21 = F_1_175 - F_2_562, kT22 = F_3_072 - F_2_562 - F_1_961 + F_1_175, kT23 = F_1_175;
-constexpr int kT30 = F_1_175 - F_0_899, kT31 = F_1_175 - F_0_390, kT32 = F_1_175, kT33 = F_1_501 - F_0_899 - F_0_390 + F_1_175;
-constexpr unsigned kOa0 = pk16(kT03, kT01), kOb0 = pk16(kT02, kT00), kOa1 = pk16(kT13, kT11), kOb1 = pk16(kT12, kT10);
-constexpr unsigned kOa2 = pk16(kT23, kT21), kOb2 = pk16(kT22, kT20), kOa3 = pk16(kT33, kT31), kOb3 = pk16(kT32, kT30);
-
-// The packed counterpart of column_pass_and_exchange.  qp: this lane's 16 quantizer pairs (DecodeComponent::qpk[p]).
-__device__ __forceinline__ void column_pass_pk16_and_exchange(const u32x4 (&cols)[4], const unsigned* __restrict__ qp, bool p, int (&rows)[4][8])
+// (int16)a.lo * k + c
+__device__ __forceinline__ int mad_lo16(unsigned a, int k, int c)
 {
-    constexpr int rnd = 1 << 10;
-    int keep[4][4], recv[4][4];
-    // the DC coefficient (lane 0, column 0, row 0) leaves the packed path: its product with the quantizer need not fit int16
-    const unsigned w00 = cols[0].x;
-    const int dcq = p ? 0 : __mul24((int)(short)(w00 & 0xFFFFu), (int)(qp[0] & 0xFFFFu));
-    const int acc_dc = (int)(((unsigned)dcq << 13) + (unsigned)rnd);
+    int r;
+    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+}
+// two int32 -> two int16 with signed saturation (packssdw)
+__device__ __forceinline__ unsigned sat_pk16(int lo, int hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_ashr16_2(unsigned a)
+{
+    return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) >> (short)2));
+}
+__device__ __forceinline__ unsigned pk_shl16_2(unsigned a)
+{
+    return __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, a) << (unsigned short)2));
+}
+
+constexpr unsigned kE10 = pk16(F_0_541 + F_0_765, F_0_541), kE13 = pk16(-(F_0_541 + F_0_765), -F_0_541);
+constexpr unsigned kE11 = pk16(F_0_541, F_0_541 - F_1_847), kE12 = pk16(-F_0_541, F_1_847 - F_0_541);
+constexpr unsigned kZ3 = pk16(F_1_175 - F_1_961, F_1_175), kZ4 = pk16(F_1_175, F_1_175 - F_0_390);
+constexpr unsigned kT0 = pk16(F_0_298 - F_0_899, -F_0_899), kT3 = pk16(-F_0_899, F_1_501 - F_0_899);
+constexpr unsigned kT1 = pk16(F_2_053 - F_2_562, -F_2_562), kT2 = pk16(-F_2_562, F_3_072 - F_2_562);
+
+// One 1-D pass over eight int16 values given as pairs A = (i0,i1), B = (i2,i3), C = (i4,i5), D = (i6,i7); o[k] = output k before the
+// descale shift, rounding term included (rnd lives in a register: a VOP3 instruction takes one scalar operand, and that is the constant).
+__device__ __forceinline__ void idct1d_pk(unsigned A, unsigned B, unsigned C, unsigned D, int rnd, int (&o)[8])
+{
+    const unsigned P = pk_add16(A, C), M = pk_sub16(A, C), Q = pk_add16(B, D);  // (i0+i4, z4), (i0-i4, .), (., z3) in 16 bits
+    const unsigned p26 = lo_pair((int)B, (int)D), pz = hi_pair((int)Q, (int)P), p71 = hi_pair((int)D, (int)A), p53 = hi_pair((int)C, (int)B);
+    const int t0e = mad_lo16(P, 8192, rnd), t1e = mad_lo16(M, 8192, rnd);
+    const int tmp10 = dot2(p26, kE10, t0e), tmp13 = dot2(p26, kE13, t0e), tmp11 = dot2(p26, kE11, t1e), tmp12 = dot2(p26, kE12, t1e);
+    const int z3 = dot2(pz, kZ3), z4 = dot2(pz, kZ4);
+    const int t0 = dot2(p71, kT0, z3), t3 = dot2(p71, kT3, z4), t1 = dot2(p53, kT1, z4), t2 = dot2(p53, kT2, z3);
+    o[0] = tmp10 + t3;
+    o[7] = tmp10 - t3;
+    o[1] = tmp11 + t2;
+    o[6] = tmp11 - t2;
+    o[2] = tmp12 + t1;
+    o[5] = tmp12 - t1;
+    o[3] = tmp13 + t0;
+    o[4] = tmp13 - t0;
+}
+
+// Eight selects between an own register and the partner lane's: r[k] = vcc ? b[k] : a[k] of the pair's EVEN (ODD = false) or ODD lane.
+// v_cndmask_b32_dpp is VOP2: its mask is VCC, which inline asm cannot name as an operand -- hence one block per mask.
+template <bool FROM_ODD>
+__device__ __forceinline__ void pair_select8(unsigned (&r)[8], const unsigned (&a)[8], const unsigned (&b)[8], unsigned long long mask)
+{
+    if constexpr (FROM_ODD)
+        asm("s_mov_b64 vcc, %24\n\t"
+            "v_cndmask_b32_dpp %0, %8, %16, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %1, %9, %17, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %2, %10, %18, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %3, %11, %19, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %4, %12, %20, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %5, %13, %21, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %6, %14, %22, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %7, %15, %23, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+              "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "s"(mask)
+            : "vcc");
+    else
+        asm("s_mov_b64 vcc, %24\n\t"
+            "v_cndmask_b32_dpp %0, %8, %16, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %1, %9, %17, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %2, %10, %18, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %3, %11, %19, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %4, %12, %20, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %5, %13, %21, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %6, %14, %22, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %7, %15, %23, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+              "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "s"(mask)
+            : "vcc");
+}
+
+// The whole transform.  cols[j]: this lane's column 4p+j as stored (row pairs (0,1),(2,3),(4,5),(6,7)); qp: this lane's 16 quantizer
+// pairs in the same layout (DecodeComponent::qpk[p]).  Result: out[i][h] = samples (2h, 2h+1) of image row (p ? 7-i : i) as an int16
+// pair, BEFORE the final clamp to -128..127 and the +128 (|.| < 2^13: the caller's v_sat_pk_u8_i16 / packed min-max finishes the job).
+__device__ __forceinline__ void idct_block_pair(const u32x4 (&cols)[4], const unsigned* __restrict__ qp, bool p, unsigned (&out)[4][4])
+{
+    unsigned dq[4][4];
+    unsigned big = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const u32x4 q4 = *reinterpret_cast<const u32x4*>(qp + j * 4);
-        unsigned w0 = cols[j].x;
-        if (j == 0) w0 = p ? w0 : (w0 & 0xFFFF0000u);
-        const unsigned D0 = pk_mul16(w0, q4.x), D1 = pk_mul16(cols[j].y, q4.y), D2 = pk_mul16(cols[j].z, q4.z), D3 = pk_mul16(cols[j].w, q4.w);
-        const unsigned E0 = lo_pair((int)D0, (int)D2), O0 = hi_pair((int)D0, (int)D2);  // (d0,d4), (d1,d5)
-        const unsigned E1 = lo_pair((int)D1, (int)D3), O1 = hi_pair((int)D1, (int)D3);  // (d2,d6), (d3,d7)
-        const int init = j == 0 ? acc_dc : rnd;
-        const int tmp0 = dot2(E0, kE0p, init), tmp1 = dot2(E0, kE0m, init);
-        const int tmp3 = dot2(E1, kE3), tmp2 = dot2(E1, kE2);
-        const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-        const int T0 = dot2(O1, kOb0, dot2(O0, kOa0)), T1 = dot2(O1, kOb1, dot2(O0, kOa1));
-        const int T2 = dot2(O1, kOb2, dot2(O0, kOa2)), T3 = dot2(O1, kOb3, dot2(O0, kOa3));
-        int d[8];
-        d[0] = (tmp10 + T3) >> 11;
-        d[7] = (tmp10 - T3) >> 11;
-        d[1] = (tmp11 + T2) >> 11;
-        d[6] = (tmp11 - T2) >> 11;
-        d[2] = (tmp12 + T1) >> 11;
-        d[5] = (tmp12 - T1) >> 11;
-        d[3] = (tmp13 + T0) >> 11;
-        d[4] = (tmp13 - T0) >> 11;
+        dq[j][0] = pk_mul16(cols[j].x, q4.x);
+        dq[j][1] = pk_mul16(cols[j].y, q4.y);
+        dq[j][2] = pk_mul16(cols[j].z, q4.z);
+        dq[j][3] = pk_mul16(cols[j].w, q4.w);
+        big |= (dq[j][0] + 0x2000u) & 0xC000u;  // row 0 outside [-8192, 8191]: only then can the shortcut below differ from the full pass
+    }
+    // workspace after pass 1: ws[jj][r] = (column 4p+2jj, column 4p+2jj+1) of row r, saturated to int16
+    unsigned ws[2][8];
+    const int rnd1 = 1 << 10, rnd2 = 1 << 17;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            keep[i][j] = d[i];
-            recv[i][j] = pair_swap(d[7 - i]);
+    for (int jj = 0; jj < 2; jj++) {
+        int oa[8], ob[8];
+        idct1d_pk(dq[2 * jj][0], dq[2 * jj][1], dq[2 * jj][2], dq[2 * jj][3], rnd1, oa);
+        idct1d_pk(dq[2 * jj + 1][0], dq[2 * jj + 1][1], dq[2 * jj + 1][2], dq[2 * jj + 1][3], rnd1, ob);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ws[jj][r] = sat_pk16(oa[r] >> 11, ob[r] >> 11);
+    }
+    if (__builtin_amdgcn_ballot_w64(big != 0) != 0) {
+        // jidctint-*.asm: "AC terms all zero" -- tested on the block as stored (rows 1..7 of all eight columns), then the
+        // workspace is the dequantized row 0 shifted left in 16-bit lanes (psllw wraps where the full pass would saturate)
+        unsigned ac = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) ac |= (cols[j].x & 0xFFFF0000u) | cols[j].y | cols[j].z | cols[j].w;
+        ac |= (unsigned)pair_swap((int)ac);
+        if (ac == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const unsigned v = pk_shl16_2(lo_pair((int)dq[2 * jj][0], (int)dq[2 * jj + 1][0]));
+#pragma unroll
+                for (int r = 0; r < 8; r++) ws[jj][r] = v;
+            }
         }
     }
+    // hand-over: slot i of lane 0 is image row i, of lane 1 row 7-i.  X = columns 0..3 (lane 0's), Y = columns 4..7 (lane 1's).
+    unsigned own_fwd[8], own_rev[8], X[8], Y[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) {
+        own_fwd[i] = ws[0][i];
+        own_fwd[4 + i] = ws[1][i];
+        own_rev[i] = ws[0][7 - i];
+        own_rev[4 + i] = ws[1][7 - i];
+    }
+    // X: even lane keeps its rows i, odd lane takes the even lane's rows 7-i;  Y: odd lane keeps its rows 7-i, even lane takes the odd lane's rows i
+    pair_select8<false>(X, own_rev, own_fwd, 0x5555555555555555ull);
+    pair_select8<true>(Y, own_fwd, own_rev, 0xAAAAAAAAAAAAAAAAull);
+    (void)p;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            rows[i][j] = p ? recv[i][j] : keep[i][j];
-            rows[i][4 + j] = p ? keep[i][j] : recv[i][j];
-        }
-}
-
-// MODE of the pass-1 arithmetic: 24-bit multiplier butterflies, 32-bit multiplier butterflies (kFlagExactMul32), packed int16
-// dot products (kFlagFitsInt16)
-enum Pass1 : int { kPass1Mul24 = 0, kPass1Exact = 1, kPass1Pk16 = 2 };
-template <int MODE>
-__device__ __forceinline__ void column_pass(const u32x4 (&cols)[4], const DecodeComponent& cd, bool p, int (&rows)[4][8])
-{
-    if constexpr (MODE == kPass1Pk16)
-        column_pass_pk16_and_exchange(cols, cd.qpk[p], p, rows);
-    else
-        column_pass_and_exchange<MODE == kPass1Exact>(cols, MODE == kPass1Exact ? cd.qpair_exact[p] : cd.qpair[p], p, rows);
+    for (int i = 0; i < 4; i++) {
+        int o[8];
+        idct1d_pk(X[i], X[4 + i], Y[i], Y[4 + i], rnd2, o);
+        // >> 18 = the high half >> 2
+#pragma unroll
+        for (int h = 0; h < 4; h++) out[i][h] = pk_ashr16_2(hi_pair(o[2 * h], o[2 * h + 1]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // K1: IDCT of 128 consecutive blocks of one component into a u8 plane (internal plane or user output).
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
 __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -376,8 +364,8 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
     fetch_half_block(cd, wave_first, nblocks, lds + wave * kBlocksPerWave * kLdsBlockStride, lane, cols);
     const int b = wave_first + (lane >> 1);
     if (b >= nblocks) return;  // whole pairs leave together
-    int rows[4][8];
-    column_pass<MODE>(cols, cd, p, rows);
+    unsigned rows[4][4];
+    idct_block_pair(cols, cd.qpk[p], p, rows);
 
     const int by = b / bw, bx = b - by * bw;
     const bool to_out = (u.mode & 0xFF) == kToOutput;
@@ -393,15 +381,12 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
     const bool fast = (x0 + 8 <= lim_w) && (((uintptr_t)base | pitch) & 7) == 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        idct8<false, 18>(rows[i]);
         const int r = p ? 7 - i : i;
         if (y0 + r < lim_h) {
-            // range limit (jdmaster.c table as arithmetic, see range_limit) on int16 pairs: + 128, then v_sat_pk_u8_i16 clamps
-            // to 0..255 and packs the bytes
+            // packsswb + paddb 128 of the SIMD routine = saturate (v + 128) to 0..255: v_sat_pk_u8_i16 clamps and packs the bytes
             unsigned pr[4];
 #pragma unroll
-            for (int c = 0; c < 8; c += 2)
-                pr[c >> 1] = pk_add16(lo_pair(__builtin_amdgcn_sbfe(rows[i][c], 0, 10), __builtin_amdgcn_sbfe(rows[i][c + 1], 0, 10)), 0x00800080u);
+            for (int h = 0; h < 4; h++) pr[h] = pk_add16(rows[i][h], 0x00800080u);
             const uint2 px = make_uint2(sat_pk4(pr[0], pr[1]), sat_pk4(pr[2], pr[3]));
             uint8_t* qd = base + __umul24((unsigned)r, pitch);
             if (fast) {
@@ -415,12 +400,11 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
     }
 }
 
-template <int MODE>
 __global__ __launch_bounds__(kThreads, HJ_MIN_WAVES) void idct_plane_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
     __shared__ __attribute__((aligned(16))) char lds[4 * kBlocksPerWave * kLdsBlockStride];
     const WorkUnit u = units[blockIdx.x];
-    idct_plane_body<MODE>(images[u.image], u, lds);
+    idct_plane_body(images[u.image], u, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -526,7 +510,7 @@ constexpr int kNarrowRowBytes = 16 * 24;                // narrow tiles: 16 pixe
 // LAYOUT: 0 = whatever the descriptor says (run-time branches), 1 = COMMON, 2 = COMMON with planar output (P_RGB / P_BGR: what
 // CHW consumers ask for) -- same arithmetic, one set of format flags fixed at compile time each
 enum LumaLayout : int { kLayoutAny = 0, kLayoutInterleaved = 1, kLayoutPlanar = 2 };
-template <int MODE, int HS, int VS, int LAYOUT>
+template <int HS, int VS, int LAYOUT>
 __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -580,8 +564,8 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
             load_chroma_rows<NW>(swap ? plane1 : plane2, swap ? pitch1 : pitch2, dw, dh, wx, first, p, crw);
         }
 
-        int rows[4][8];
-        column_pass<MODE>(cols, im.comp[0], p, rows);
+        unsigned rows[4][4];
+        idct_block_pair(cols, im.comp[0].qpk[p], p, rows);
         // additive constants of the colour conversion (kept in VGPRs: a VOP3 instruction reads one scalar operand at most)
         // (+ 128 << 16: the luma offset, see the packed colour stage below)
         const bool swapped = ycc && bgr;  // crw holds Cb and cbw holds Cr (see the window loads above)
@@ -591,7 +575,6 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
 
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            idct8<false, 18>(rows[i]);
             const int r = p ? 7 - i : i;  // image row inside the block
             if (y0 + r >= H) continue;
             // q: the row's 24 output bytes (interleaved), or q[2k], q[2k+1] = the eight bytes of output plane k (planar)
@@ -609,14 +592,14 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
                     upsample_row<HS, VS>(cbw[near], cbw[far], odd_row, fancy, cb);
                     upsample_row<HS, VS>(crw[near], crw[far], odd_row, fancy, cr);
                     // jdcolor.c ycc_rgb_convert with SCALEBITS = 16, two pixels per register from here on:
-                    //   y = clamp(s + 128, 0, 255) = clamp(s, -128, 127) + 128 with s the 10-bit range-limit index, and the
+                    //   y = clamp(s + 128, 0, 255) = clamp(s, -128, 127) + 128 with s the IDCT's result (packsswb), and the
                     //   +128 as well as the (x - 128) of the chroma terms live in the additive constants, so
                     //   bits 31..16 of one 24-bit mad ARE "chroma term + 128" as an int16 (|.| < 2^9);
                     //   v_sat_pk_u8_i16 is the final clamp to 0..255 and the byte packing in one instruction.
                     unsigned s0[4], s1[4], s2[4];
 #pragma unroll
                     for (int c = 0; c < 8; c += 2) {
-                        const unsigned yp = clamp_s8_pair(lo_pair(__builtin_amdgcn_sbfe(rows[i][c], 0, 10), __builtin_amdgcn_sbfe(rows[i][c + 1], 0, 10)));
+                        const unsigned yp = clamp_s8_pair(rows[i][c >> 1]);
                         // (names as for RGB output; for BGR the windows and constants have traded places: tr is then the blue term)
                         const unsigned tr = hi_pair(mad24(cr[c], mr, kr), mad24(cr[c + 1], mr, kr));
                         const unsigned tb = hi_pair(mad24(cb[c], mb, kb), mad24(cb[c + 1], mb, kb));
@@ -648,9 +631,12 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
             }
             if (!packed_done) {
                 int R[8], G[8], B[8];
+                // the luma samples as bytes (v_sat_pk_u8_i16 of value + 128, as in K1)
+                const uint2 ypx = make_uint2(sat_pk4(pk_add16(rows[i][0], 0x00800080u), pk_add16(rows[i][1], 0x00800080u)),
+                                             sat_pk4(pk_add16(rows[i][2], 0x00800080u), pk_add16(rows[i][3], 0x00800080u)));
                 if constexpr (HS == 0) {
 #pragma unroll
-                    for (int c = 0; c < 8; c++) R[c] = G[c] = B[c] = range_limit(rows[i][c]);
+                    for (int c = 0; c < 8; c++) R[c] = G[c] = B[c] = byte_of(ypx, c);
                 } else {
                     // Adobe RGB JPEG: the three components already are R, G, B (same window rows as above)
                     constexpr int kNear[4] = {1, 1, 2, 2}, kFar[4] = {0, 2, 1, 3};
@@ -659,7 +645,7 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
                     upsample_row<HS, VS>(cbw[near], cbw[far], odd_row, fancy, G);
                     upsample_row<HS, VS>(crw[near], crw[far], odd_row, fancy, B);
 #pragma unroll
-                    for (int c = 0; c < 8; c++) R[c] = range_limit(rows[i][c]);
+                    for (int c = 0; c < 8; c++) R[c] = byte_of(ypx, c);
                 }
                 if (bgr) {
 #pragma unroll
@@ -764,12 +750,12 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     }
 }
 
-template <int MODE, int HS, int VS, int LAYOUT>
+template <int HS, int VS, int LAYOUT>
 __global__ __launch_bounds__(kThreads, HJ_MIN_WAVES_LUMA) void luma_color_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units)
 {
     __shared__ __attribute__((aligned(16))) char lds[4 * kLdsLumaWaveBytes];
     const WorkUnit u = units[blockIdx.x];
-    luma_color_body<MODE, HS, VS, LAYOUT>(images[u.image], u, lds);
+    luma_color_body<HS, VS, LAYOUT>(images[u.image], u, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -978,51 +964,39 @@ __global__ __launch_bounds__(kThreads) void transform_kernel(const TransformImag
 
 }  // namespace
 
-int launch_idct_plane(int pass1, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+int launch_idct_plane(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
 {
     if (nunits <= 0) return 0;
-    if (pass1 == kPlaneExact)
-        hipLaunchKernelGGL(idct_plane_kernel<kPass1Exact>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
-    else if (pass1 == kPlanePk16)
-        hipLaunchKernelGGL(idct_plane_kernel<kPass1Pk16>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
-    else
-        hipLaunchKernelGGL(idct_plane_kernel<kPass1Mul24>, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    hipLaunchKernelGGL(idct_plane_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
     return (int)hipGetLastError();
 }
 
-template <int MODE, int LAYOUT>
+template <int LAYOUT>
 static int launch_luma_color_t(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, hipStream_t s)
 {
     if (hs == 0) {
         if constexpr (LAYOUT != kLayoutAny) return (int)hipErrorInvalidValue;  // gray sources have no colour conversion to specialise
-        else hipLaunchKernelGGL((luma_color_kernel<MODE, 0, 0, kLayoutAny>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        else hipLaunchKernelGGL((luma_color_kernel<0, 0, kLayoutAny>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     } else if (hs == 1 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<MODE, 1, 1, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<1, 1, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 1)
-        hipLaunchKernelGGL((luma_color_kernel<MODE, 2, 1, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<2, 1, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 2 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<MODE, 2, 2, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<2, 2, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else if (hs == 1 && vs == 2)
-        hipLaunchKernelGGL((luma_color_kernel<MODE, 1, 2, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
+        hipLaunchKernelGGL((luma_color_kernel<1, 2, LAYOUT>), dim3(nunits), dim3(kThreads), 0, s, images, units);
     else
         return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
 
-int launch_luma_color(int flavour, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
+int launch_luma_color(int layout, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream)
 {
     if (nunits <= 0) return 0;
-    // flavour = pass-1 arithmetic x 3 + layout (decode_kernels.h luma_flavour)
-    switch (flavour) {
-    case 0: return launch_luma_color_t<kPass1Mul24, kLayoutAny>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case 1: return launch_luma_color_t<kPass1Mul24, kLayoutInterleaved>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case 2: return launch_luma_color_t<kPass1Mul24, kLayoutPlanar>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case 3: return launch_luma_color_t<kPass1Exact, kLayoutAny>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case 4: return launch_luma_color_t<kPass1Exact, kLayoutInterleaved>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case 5: return launch_luma_color_t<kPass1Exact, kLayoutPlanar>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case 6: return launch_luma_color_t<kPass1Pk16, kLayoutAny>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case 7: return launch_luma_color_t<kPass1Pk16, kLayoutInterleaved>(hs, vs, images, units, nunits, (hipStream_t)stream);
-    case 8: return launch_luma_color_t<kPass1Pk16, kLayoutPlanar>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    switch (layout) {
+    case 0: return launch_luma_color_t<kLayoutAny>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 1: return launch_luma_color_t<kLayoutInterleaved>(hs, vs, images, units, nunits, (hipStream_t)stream);
+    case 2: return launch_luma_color_t<kLayoutPlanar>(hs, vs, images, units, nunits, (hipStream_t)stream);
     default: return (int)hipErrorInvalidValue;
     }
 }

@@ -330,9 +330,7 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
             for (int pp = 0; pp < 2; pp++)
                 for (int j = 0; j < 4; j++)
                     for (int r = 0; r < 8; r++) {
-                        const int q = f.qtab[c][r * 8 + 4 * pp + j];
-                        dc.qpair[pp][j * 8 + r] = dc.qpair_exact[pp][j * 8 + r] = (pp && (r & 1)) ? -q : q;
-                        const uint32_t q16 = (uint32_t)((pp && (r & 1)) ? -q : q) & 0xFFFFu;
+                        const uint32_t q16 = (uint32_t)f.qtab[c][r * 8 + 4 * pp + j] & 0xFFFFu;
                         uint32_t& pk = dc.qpk[pp][j * 4 + (r >> 1)];
                         pk = (r & 1) ? (pk | (q16 << 16)) : q16;
                     }
@@ -671,8 +669,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
     fault_point("finalize");
     generic_units_.clear();
     cmyk_units_.clear();
-    for (int e = 0; e < kNumPlaneFlavours; e++) plane_units_[e].clear();
-    for (int e = 0; e < kNumLumaFlavours; e++)
+    plane_units_.clear();
+    for (int e = 0; e < kNumLumaLayouts; e++)
         for (auto& v : luma_units_[e]) v.clear();
     const int n = (int)images_.size();
     for (int i = 0; i < n; i++) {
@@ -681,25 +679,6 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
         const FrameInfo& f = im.frame;
         DecodeImage& d = desc_[i];
-        // 24-bit multipliers in IDCT pass 1 need every dequantized value (and sums of four of them) inside 24 signed bits
-        bool exact32 = false;
-        for (int c = 0; c < f.ncomp; c++) {
-            uint32_t maxq = 0;
-            for (int j = 0; j < 64; j++) maxq = std::max<uint32_t>(maxq, f.qtab[c][j]);
-            if ((uint64_t)im.coef_or[c] * maxq >= (1u << 21)) exact32 = true;
-        }
-        if (exact32) d.flags |= kFlagExactMul32;
-        // packed int16 pass 1 (decode_kernels.hip column_pass_pk16_and_exchange): every dequantized AC value must fit int16,
-        // for the quantizer and for its negation; the DC term is 32-bit arithmetic there
-        static const bool no_pk16 = getenv("HIPJPEG_NO_PK16") != nullptr;  // measurement / test aid: the butterfly flavours for every image
-        bool fits16 = !no_pk16;
-        for (int c = 0; c < f.ncomp; c++) {
-            uint32_t maxq_ac = 0;
-            for (int j = 1; j < 64; j++) maxq_ac = std::max<uint32_t>(maxq_ac, f.qtab[c][j]);
-            if ((uint64_t)im.ac_bound[c] * maxq_ac > 32767u) fits16 = false;
-        }
-        if (fits16) d.flags |= kFlagFitsInt16;
-        const int plane_flavour = fits16 ? kPlanePk16 : exact32 ? kPlaneExact : kPlaneMul24;
         const OutFormat fmt = (OutFormat)d.out_format;
         for (int c = 0; c < f.ncomp; c++) {
             const uint32_t nblk = (uint32_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
@@ -707,7 +686,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             bool to_output = (im.variant == -2) && (fmt == kOutPlanarYUV || c == 0);
             if (needs_plane || to_output) {
                 uint32_t mode = to_output ? (uint32_t)(kToOutput | (c << 8)) : (uint32_t)kToPlane;
-                for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) plane_units_[plane_flavour].push_back(WorkUnit{(uint32_t)i, b, (uint32_t)c, mode});
+                for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) plane_units_.push_back(WorkUnit{(uint32_t)i, b, (uint32_t)c, mode});
             }
         }
         if (im.variant >= 0) {
@@ -723,7 +702,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             const bool everyday = im.variant != kVarGray && d.color_model == 1 && (d.flags & kFlagFancyUpsampling) &&
                                   (im.variant == kVar11 || im.variant == kVar12 || d.comp[1].samp_w > 2);
             const int layout = !everyday ? 0 : (fmt == kOutInterleavedRGB || fmt == kOutInterleavedBGR) ? 1 : (fmt == kOutPlanarRGB || fmt == kOutPlanarBGR) ? 2 : 0;
-            const int flavour = luma_flavour(plane_flavour, layout);
+            const int flavour = layout;
             // a ragged right edge of at most half a tile (1920 pixels = 7.5 tiles) is covered by narrow tiles, 16 x 8 blocks,
             // so that no wave runs half empty
             const uint32_t span = end_col - first_col, ragged = span % kLumaTileW;
@@ -749,8 +728,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         if (!v.empty()) memcpy(base + off, v.data(), v.size() * sizeof(WorkUnit));
         off += v.size() * sizeof(WorkUnit);
     };
-    for (int e = 0; e < kNumPlaneFlavours; e++) put(plane_units_[e], &unit_off_plane_[e]);
-    for (int e = 0; e < kNumLumaFlavours; e++)
+    put(plane_units_, &unit_off_plane_);
+    for (int e = 0; e < kNumLumaLayouts; e++)
         for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[e][k], &unit_off_luma_[e][k]);
     put(generic_units_, &unit_off_generic_);
     put(cmyk_units_, &unit_off_cmyk_);
@@ -1152,11 +1131,11 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
         const uint32_t n = (uint32_t)images_.size();
         for (uint32_t a = 0; a < n && rc == 0; a += (uint32_t)chunk) {
             size_t first = 0;
-            for (int e = 0; e < kNumPlaneFlavours && rc == 0; e++) {
-                const int cnt = slice(plane_units_[e], a, a + chunk, &first);
-                rc = launch_idct_plane(e, dimg, units_at(unit_off_plane_[e]) + first, cnt, stream);
+            {
+                const int cnt = slice(plane_units_, a, a + chunk, &first);
+                rc = launch_idct_plane(dimg, units_at(unit_off_plane_) + first, cnt, stream);
             }
-            for (int e = 0; e < kNumLumaFlavours; e++)
+            for (int e = 0; e < kNumLumaLayouts; e++)
                 for (int k = 0; k < kNumLumaVariants && rc == 0; k++) {
                     const int cnt = slice(luma_units_[e][k], a, a + chunk, &first);
                     rc = launch_luma_color(e, hs[k], vs[k], dimg, units_at(unit_off_luma_[e][k]) + first, cnt, stream);
@@ -1164,11 +1143,11 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
         }
         return rc;
     }
-    for (int e = 0; e < kNumPlaneFlavours && rc == 0 && (which < 0 || which == 0); e++) {
-        rc = launch_idct_plane(e, dimg, units_at(unit_off_plane_[e]), (int)plane_units_[e].size(), stream);
-        check("idct_plane", (int)plane_units_[e].size());
+    if (rc == 0 && (which < 0 || which == 0)) {
+        rc = launch_idct_plane(dimg, units_at(unit_off_plane_), (int)plane_units_.size(), stream);
+        check("idct_plane", (int)plane_units_.size());
     }
-    for (int e = 0; e < kNumLumaFlavours; e++)
+    for (int e = 0; e < kNumLumaLayouts; e++)
         for (int k = 0; k < kNumLumaVariants && rc == 0 && (which < 0 || which == 1); k++) {
             rc = launch_luma_color(e, hs[k], vs[k], dimg, units_at(unit_off_luma_[e][k]), (int)luma_units_[e][k].size(), stream);
             check("luma_color", (int)luma_units_[e][k].size());
@@ -1211,7 +1190,7 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which, void* entropy_strea
                     (void*)d.out[0], d.out_pitch[0]);
         }
         fprintf(stderr, "[hipjpeg] device=%p+%zu planes=%p+%zu unit offs plane=%zu generic=%zu coef_off=%zu staging=%zu\n", (void*)device_.data(),
-                device_.capacity(), (void*)planes_.data(), planes_.capacity(), unit_off_plane_[0], unit_off_generic_, coef_offset_, staging_bytes_);
+                device_.capacity(), (void*)planes_.data(), planes_.capacity(), unit_off_plane_, unit_off_generic_, coef_offset_, staging_bytes_);
         check("transfer", 0);
     }
     last_stream_ = stream;
@@ -1267,10 +1246,9 @@ void DecodeBatch::output_size(int i, int* w, int* h) const
 void DecodeBatch::stats(int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes) const
 {
     if (num_units) {
-        num_units[0] = 0;
-        for (int e = 0; e < kNumPlaneFlavours; e++) num_units[0] += (int32_t)plane_units_[e].size();
+        num_units[0] = (int32_t)plane_units_.size();
         num_units[1] = 0;
-        for (int e = 0; e < kNumLumaFlavours; e++)
+        for (int e = 0; e < kNumLumaLayouts; e++)
             for (const auto& v : luma_units_[e]) num_units[1] += (int32_t)v.size();
         num_units[2] = (int32_t)generic_units_.size();
     }

@@ -132,10 +132,10 @@ public:
     int host_fallback_images() const { return host_fallback_images_; }  // GPU-entropy images the host decoder took over in resolve()
     bool has_progressive() const { return !prog_to_image_.empty(); }
     uint64_t stream_bytes() const { return stream_bytes_total_; }
-    void flavour_units(int32_t plane_units[kNumPlaneFlavours], int32_t luma_units[kNumLumaFlavours]) const
+    void flavour_units(int32_t* plane_units, int32_t luma_units[kNumLumaLayouts]) const
     {
-        for (int e = 0; e < kNumPlaneFlavours; e++) plane_units[e] = (int32_t)plane_units_[e].size();
-        for (int e = 0; e < kNumLumaFlavours; e++) {
+        *plane_units = (int32_t)plane_units_.size();
+        for (int e = 0; e < kNumLumaLayouts; e++) {
             luma_units[e] = 0;
             for (const auto& v : luma_units_[e]) luma_units[e] += (int32_t)v.size();
         }
@@ -153,10 +153,9 @@ private:
     Buffer pinned_, device_, planes_;
     std::vector<PlannedImage> images_;
     std::vector<DecodeImage> desc_;  // host copy (device pointers inside)
-    // index [0] = 24-bit multiplier kernels, [1] = exact 32-bit multiplier kernels
-    std::vector<WorkUnit> plane_units_[kNumPlaneFlavours], luma_units_[kNumLumaFlavours][kNumLumaVariants], generic_units_, cmyk_units_;  // luma: [LumaFlavour]
+    std::vector<WorkUnit> plane_units_, luma_units_[kNumLumaLayouts][kNumLumaVariants], generic_units_, cmyk_units_;  // luma: [layout of K2][sampling]
     size_t desc_offset_ = 0, units_offset_ = 0, coef_offset_ = 0, staging_bytes_ = 0, plane_bytes_ = 0;
-    size_t unit_off_plane_[kNumPlaneFlavours] = {0}, unit_off_luma_[kNumLumaFlavours][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0, unit_off_cmyk_ = 0;
+    size_t unit_off_plane_ = 0, unit_off_luma_[kNumLumaLayouts][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0, unit_off_cmyk_ = 0;
     uint64_t coef_bytes_ = 0, output_bytes_ = 0;
     bool finalized_ = false;
     // ---- GPU entropy stage

@@ -25,9 +25,7 @@ enum OutFormat : uint8_t {
 
 enum ImageFlags : uint8_t {
     kFlagFancyUpsampling = 1,  // libjpeg do_fancy_upsampling
-    kFlagExactMul32 = 2,       // coefficient range too wide for 24-bit multiplies in IDCT pass 1
     kFlagAdobeMarker = 4,      // the file carries an Adobe APP14 segment (selects the reference's CMYK -> RGB formula)
-    kFlagFitsInt16 = 8,        // every dequantized AC coefficient provably fits int16: IDCT pass 1 runs on packed pairs (v_dot2_i32_i16)
 };
 
 // Per-component part of the descriptor.  Kept as one aligned record per component (rather than parallel arrays inside
@@ -45,14 +43,9 @@ struct alignas(16) DecodeComponent {
     // stage: dc[b] in a compact plane of DC values (dc_stride == 1), position 0 of the blocks holds zero.
     const int16_t* dc;
     uint32_t dc_stride, pad0;
-    // Quantizers as the kernels consume them: qpair[p][j*8 + r] = q(row r, column 4p+j), with odd rows NEGATED for p == 1
-    // (lane 1 of a pair runs its column butterflies with negated odd inputs, which reverses their output order exactly).
-    // qpair serves both the 24-bit-multiplier kernels and the exact ones (same values).
-    int32_t qpair[2][32];
-    int32_t qpair_exact[2][32];
-    // The same quantizers as int16 pairs for the packed column pass (kFlagFitsInt16): qpk[p][j*4 + i] = q(row 2i, column 4p+j) in
-    // the low half, q(row 2i+1, column 4p+j) in the high half (negated for p == 1, as above) -- the layout of a block's 16-byte
-    // column chunk, so that ONE v_pk_mul_lo_u16 dequantizes two coefficients.
+    // Quantizers as the kernels consume them, int16 pairs in the layout of a block's 16-byte column chunk, so that ONE
+    // v_pk_mul_lo_u16 dequantizes two coefficients (the low 16 bits of the product, like the SIMD routine's pmullw):
+    // qpk[p][j*4 + i] = q(row 2i, column 4p+j) in the low half, q(row 2i+1, column 4p+j) in the high half.
     uint32_t qpk[2][16];
 };
 

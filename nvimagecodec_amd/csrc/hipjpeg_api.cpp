@@ -432,7 +432,7 @@ int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle)
     return handle ? handle->cur().host_fallback_images() : -1;
 }
 
-hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[3], int32_t luma_units[9])
+hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[1], int32_t luma_units[3])
 {
     return guarded([&]() -> hipjpegStatus_t {
     if (!handle || !plane_units || !luma_units) return HIPJPEG_STATUS_INVALID_ARGUMENT;

@@ -201,9 +201,9 @@ class BatchDecoder:
         return int(N.load().hipjpegTestHostFallbacks(self._h))
 
     def kernel_flavours(self):
-        """(plane_units[3], luma_units[9]) of the current batch: which arithmetic its images were given (hipjpegTestKernelFlavours)."""
+        """(plane_units[1], luma_units[3]) of the current batch: work units of K1 and of K2 per layout (hipjpegTestKernelFlavours)."""
         import ctypes
-        a, b = (ctypes.c_int32 * 3)(), (ctypes.c_int32 * 9)()
+        a, b = (ctypes.c_int32 * 1)(), (ctypes.c_int32 * 3)()
         st = N.load().hipjpegTestKernelFlavours(self._h, a, b)
         if st:
             raise N.HipJpegError(st, "hipjpegTestKernelFlavours")

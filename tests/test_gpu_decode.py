@@ -182,9 +182,9 @@ def test_config4_progressive_444_planar(dec):
         assert np.array_equal(o.cpu().numpy(), ref)
 
 
-def test_extreme_coefficients_take_the_exact_multiplier_path(dec):
-    """Quality 1 tables (quantizers up to 255) on a saturated checkerboard push dequantized values past the 24-bit
-    multiplier's safe range; the host must flag the image and the kernel must still match the oracle bit for bit."""
+def test_extreme_coefficients(dec):
+    """Quality 1 tables (quantizers up to 255) on a saturated checkerboard push dequantized values far beyond what a photograph holds;
+    the kernels must still match the oracle bit for bit."""
     img = np.zeros((64, 64, 3), dtype=np.uint8)
     img[::2, ::2] = 255
     img[1::2, 1::2] = 255
@@ -196,11 +196,10 @@ def test_extreme_coefficients_take_the_exact_multiplier_path(dec):
             assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(j)), (q, sub)
 
 
-def test_coefficient_files_on_each_pass1_arithmetic(dec):
-    """Files written from chosen coefficients (tests/test_coefficient_files.py): dequantized AC values of exactly 32,736 (the packed
-    int16 pass 1 must take them: kernel_flavours says so), one quantizer step further (butterflies), far beyond (24/32-bit multipliers),
-    and in-gamut files pinned by the real libjpeg-turbo -- GPU and host entropy stages, interleaved / planar / gray outputs, bit-exact
-    against the oracle."""
+def test_coefficient_files(dec):
+    """Files written from chosen coefficients (tests/test_coefficient_files.py): dequantized values around and far beyond the int16
+    edges of the IDCT's 16-bit lanes, and in-gamut files -- GPU and host entropy stages, interleaved / planar / gray outputs, bit-exact
+    against the oracle (itself pinned on these very files by the live libjpeg-turbo, tests/test_coefficient_files.py)."""
     from test_coefficient_files import CASES, IN_GAMUT, make_case
     for case in CASES + IN_GAMUT:
         data = make_case(*case)[0]
@@ -208,13 +207,39 @@ def test_coefficient_files_on_each_pass1_arithmetic(dec):
             for fmt in ("rgb", "rgb_planar", "y"):
                 outs, st = dec.decode([data], fmt=fmt, gpu_huffman=gh)
                 _sync()
-                plane, luma = dec.kernel_flavours()
                 got = outs[0].cpu().numpy()
                 ref = oracle.decode(data, oracle.FMT_GRAY if fmt == "y" else oracle.FMT_RGB)
                 if fmt == "rgb_planar":
                     ref = ref.transpose(2, 0, 1)
                 assert np.array_equal(got, ref), (case[0], gh, fmt)
-                if gh and not os.environ.get("HIPJPEG_NO_PK16"):  # the table bound decides for GPU-decoded streams: 1023 x the largest AC quantizer
-                    packed = 1023 * case[2] <= 32767
-                    assert (plane[2] + sum(luma[6:9]) > 0) == packed, (case[0], fmt, plane, luma)
-                    assert (plane[0] + plane[1] + sum(luma[0:6]) > 0) == (not packed), (case[0], fmt, plane, luma)
+
+
+def _gamut_entries():
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return gold, json.load(open(os.path.join(gold, "manifest_gamut.json")))["gamut"]
+
+
+@pytest.mark.parametrize("gpu_huffman", [True, False], ids=["gpu_entropy", "host_entropy"])
+def test_out_of_gamut_vectors_from_libjpeg_turbo(dec, gpu_huffman):
+    """tests/golden/gamut: 43 valid baseline / extended-sequential files whose samples leave the gamut, decoded by the real libjpeg-turbo
+    (SIMD dispatch, what the reference's CPU path runs).  One mixed batch, every output layout the kernels specialise; the golden pixels
+    themselves are the reference here, not the oracle."""
+    gold, entries = _gamut_entries()
+    datas = [open(os.path.join(gold, "gamut", e["name"] + ".jpg"), "rb").read() for e in entries]
+    refs = []
+    for e in entries:
+        pix = np.fromfile(os.path.join(gold, "gamut", e["name"] + ".pix"), dtype=np.uint8)
+        refs.append(pix.reshape((e["height"], e["width"]) if e["mode"] == "L" else (e["height"], e["width"], 3)))
+    colour = [i for i, e in enumerate(entries) if e["mode"] != "L"]
+    gray = [i for i, e in enumerate(entries) if e["mode"] == "L"]
+    # colour files -> interleaved RGB, BGR, planar RGB; gray files -> Y and (replicated) RGB
+    for idx, fmt, conv in ((colour, "rgb", lambda r: r), (colour, "bgr", lambda r: r[:, :, ::-1]), (colour, "rgb_planar", lambda r: r.transpose(2, 0, 1)),
+                           (gray, "y", lambda r: r), (gray, "rgb", lambda r: np.repeat(r[:, :, None], 3, axis=2))):
+        outs, st = dec.decode([datas[i] for i in idx], fmt=fmt, gpu_huffman=gpu_huffman)
+        _sync()
+        assert all(s == 0 for s in st), st
+        for i, o in zip(idx, outs):
+            got = o.cpu().numpy()
+            ref = conv(refs[i])
+            assert np.array_equal(got, ref), (entries[i]["name"], fmt, int((got != ref).sum()))
