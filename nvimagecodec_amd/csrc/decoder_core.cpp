@@ -341,6 +341,36 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     else
         for (int i = 0; i < n; i++) prepare(i);
 
+    // The progressive walk / replay launches are sized for the batch's maxima (largest table x most scans, enqueue_progressive): keep
+    // their dynamic LDS inside the device's workgroup limit by handing the most demanding images to the host entropy stage -- a refused
+    // launch would fail the whole batch.  No golden and no libjpeg-written file comes near the limit.
+    {
+        static const size_t lds_limit = [] {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, 0) != hipSuccess || v <= 0) v = 64 * 1024;
+            if (const char* e = getenv("HIPJPEG_PROG_LDS_LIMIT")) v = atoi(e);  // test aid
+            return (size_t)v;
+        }();
+        for (;;) {
+            ProgLdsShape all;
+            int worst = -1;
+            size_t worst_need = 0;
+            for (int i = 0; i < n; i++) {
+                if (!images_[i].gpu_prog) continue;
+                const ProgLdsShape sh = prog_lds_shape(images_[i].frame);
+                all.merge(sh);
+                const size_t need = std::max(prog_walk_lds_bytes(sh), prog_replay_lds_bytes(sh));
+                if (need > worst_need) {
+                    worst_need = need;
+                    worst = i;
+                }
+            }
+            if (worst < 0 || std::max(prog_walk_lds_bytes(all), prog_replay_lds_bytes(all)) <= lds_limit) break;
+            images_[worst].gpu_entropy = images_[worst].gpu_prog = false;
+            images_[worst].pool_words = 0;
+        }
+    }
+
     for (int i = 0; i < n; i++) {
         PlannedImage& im = images_[i];
         const OutFormat fmt = (OutFormat)(formats && im.status != HIPJPEG_STATUS_INVALID_ARGUMENT ? formats[i] : format);

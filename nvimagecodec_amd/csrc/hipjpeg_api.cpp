@@ -345,14 +345,34 @@ hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* 
     hipjpegStatus_t st = hipjpegDecodeBatchHost(handle, data, lengths, batch_size, outputs, format, flags, nullptr);
     if (st != HIPJPEG_STATUS_SUCCESS) return st;
     DecodeBatch& b = handle->cur();
-    if ((st = b.transfer(handle->copy_stream, true)) != HIPJPEG_STATUS_SUCCESS) return st;
+    // From here on the page may have device work queued (its H2D copy, entropy kernels, pixel kernels) that reads the page's pinned and
+    // device arenas.  If a later step fails or throws, the page is not recorded as submitted and would be reused `pages` Submits later
+    // without anybody having waited for that work: drain the streams it may sit on before the error leaves.
     hipStream_t es = handle->entropy_stream;
-    if (two_streams && b.has_progressive()) {
-        hipStream_t& ps = handle->page_entropy_stream[handle->current];
-        if (!ps && hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
-        es = ps;
+    auto drain = [&]() {
+        if (hipSetDevice(handle->device_id) != hipSuccess) return;
+        (void)hipStreamSynchronize(handle->copy_stream);
+        if (handle->entropy_stream) (void)hipStreamSynchronize(handle->entropy_stream);
+        if (es && es != handle->entropy_stream) (void)hipStreamSynchronize(es);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+    };
+    try {
+        if ((st = b.transfer(handle->copy_stream, true)) == HIPJPEG_STATUS_SUCCESS) {
+            if (two_streams && b.has_progressive()) {
+                hipStream_t& ps = handle->page_entropy_stream[handle->current];
+                if (!ps && hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess) st = HIPJPEG_STATUS_HIP_ERROR;
+                es = ps;
+            }
+            if (st == HIPJPEG_STATUS_SUCCESS) st = b.launch(stream, -1, es);
+        }
+    } catch (...) {
+        drain();
+        throw;
     }
-    if ((st = b.launch(stream, -1, es)) != HIPJPEG_STATUS_SUCCESS) return st;
+    if (st != HIPJPEG_STATUS_SUCCESS) {
+        drain();
+        return st;
+    }
     handle->submitted[handle->num_submitted] = handle->current;
     handle->submitted_stream[handle->num_submitted] = stream;
     handle->num_submitted++;

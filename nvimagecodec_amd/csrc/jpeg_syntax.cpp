@@ -241,11 +241,13 @@ ParseStatus parse_jpeg(const uint8_t* data, size_t size, FrameInfo* f, bool head
                 if (n > 256 || q + n > seg_end) return kParseBadStream;
                 memcpy(t.vals, q, n);
                 q += n;
-                // Kraft check: a length-l code space may not be over-subscribed
+                // jdhuff.c jpeg_make_d_derived_tbl: after the codes of length l "code" must still fit in l bits -- the code space may
+                // not be over-subscribed, and not filled either: no code word is all ones (a complete code would let a decoder parse
+                // the one-bits that pad a stream's end as symbols, for ever)
                 int code = 0;
                 for (int l = 1; l <= 16; l++) {
                     code += t.bits[l];
-                    if (code > (1 << l)) return kParseBadStream;
+                    if (code >= (1 << l) && n > 0) return kParseBadStream;
                     code <<= 1;
                 }
                 t.present = true;

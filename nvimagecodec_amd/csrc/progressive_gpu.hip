@@ -42,6 +42,7 @@ struct WalkShared {
     uint32_t abort_flag;
 };
 typedef unsigned long long WalkRing[kProgRing][kProgGroup];
+static_assert(sizeof(WalkRing) == (size_t)kProgRing * kProgGroup * 8, "progressive_gpu_host.h kProgRingBytes");
 
 // The scalar machine of prog_walk_ac (progressive_gpu_core.h) on one wave.
 struct DevWalker {
@@ -76,6 +77,7 @@ struct DevWalker {
     __device__ __forceinline__ uint32_t fetch_raw(uint32_t base) const
     {
         const uint32_t i = base + lane;
+        if (nwords == 0) return ~0u;  // an empty stream (never queued by the host: gpu_progressive_eligible) reads as ones, not as g[-1]
         return g[i < nwords ? i : nwords - 1];
     }
     __device__ __forceinline__ uint32_t swap(uint32_t raw, uint32_t base) const { return base + lane < nwords ? __builtin_bswap32(raw) : ~0u; }
@@ -322,11 +324,14 @@ __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint
         };
         if (sc.ncomp == 1) {
             const uint32_t c = sc.comps[0], nbx = im.nbx[c], nby = im.nby[c], bw = im.blocks_w[c];
-            for (uint32_t by = 0; by < nby; by++)
+            // (the position is checked once per row: a forged frame size cannot keep the wave walking through imaginary data)
+            for (uint32_t by = 0; by < nby; by++) {
                 for (uint32_t bx = 0; bx < nbx; bx++)
                     if (!one(0, c, by * bw + bx)) return false;
+                if (w.pos() > total_bits) return false;
+            }
         } else {
-            for (uint32_t my = 0; my < im.mcus_y; my++)
+            for (uint32_t my = 0; my < im.mcus_y; my++) {
                 for (uint32_t mx = 0; mx < im.mcus_x; mx++)
                     for (uint32_t i = 0; i < sc.ncomp; i++) {
                         const uint32_t c = sc.comps[i], h = im.comp_h[c], v = im.comp_v[c], bw = im.blocks_w[c];
@@ -334,6 +339,8 @@ __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint
                             for (uint32_t dx = 0; dx < h; dx++)
                                 if (!one(i, c, (my * v + dy) * bw + mx * h + dx)) return false;
                     }
+                if (w.pos() > total_bits) return false;
+            }
         }
         if (w.pos() > total_bits) return false;
         __threadfence_block();
@@ -441,6 +448,7 @@ struct ReplayEnv {
 };
 
 // unit = {image, (component << 28) | first block of the allocation grid}
+static_assert(sizeof(ReplayShared) <= 40 * 1024, "progressive_gpu_host.h kProgReplayStaticLds");
 __global__ __launch_bounds__(kRThreads) void prog_replay_kernel(ProgImage* __restrict__ images, const HuffImage* __restrict__ himgs,
                                                                 const HuffUnit* __restrict__ units, uint32_t slot_words)
 {

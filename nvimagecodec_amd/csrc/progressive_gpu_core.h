@@ -199,6 +199,9 @@ HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t
         }
         w.group_end(g);
         if (!ok) break;
+        // once per 64 blocks (wave-uniform, nearly free): a walk that has left the data stops here instead of decoding the ones behind
+        // the end as symbols for the rest of a forged frame; also keeps the 32-bit position far from kProgInRun's bit
+        if (HJ_UNLIKELY(w.pos() > total_bits)) { ok = false; break; }
     }
     // nothing may be read from behind the data (the host decoder calls that TRUNCATED)
     if (ok && w.pos() > total_bits) ok = false;

@@ -1,6 +1,8 @@
 // progressive_gpu_host.cpp -- see progressive_gpu_host.h
 #include "progressive_gpu_host.h"
 
+#include <algorithm>
+
 #include <cstring>
 
 #include "gpu_huffman_host.h"
@@ -76,6 +78,9 @@ bool gpu_progressive_eligible(const FrameInfo& f)
     for (const ScanHeader& sc : f.scans) {
         if (!sc.plain_stuffing || sc.restart_interval != 0 || !sc.rst_after.empty()) return false;
         if ((sc.data_end - sc.data_begin) >= (1ull << 27)) return false;  // bit positions below 2^30: bit 31 flags end-of-band runs
+        // a scan without a single entropy-coded byte (a file cut right behind an SOS header, a marker directly after one): no destuff
+        // chunk would be queued for it, its stream descriptor would stay empty -- the host decoder names the error (TRUNCATED)
+        if (sc.data_end <= sc.data_begin) return false;
         if (sc.ah != 0 && sc.al != sc.ah - 1) return false;
         for (int i = 0; i < sc.ncomp; i++) {
             const int c = sc.comp_index[i];
@@ -109,6 +114,27 @@ bool gpu_progressive_eligible(const FrameInfo& f)
         if ((size_t)((f.comp[c].samp_w + 7) / 8) * (size_t)((f.comp[c].samp_h + 7) / 8) >= (1u << 24)) return false;
     }
     return true;
+}
+
+ProgLdsShape prog_lds_shape(const FrameInfo& f)
+{
+    ProgLdsShape sh;
+    unsigned per_comp[4] = {0, 0, 0, 0};
+    for (const ScanHeader& sc : f.scans) {
+        if (sc.ss == 0) {
+            if (sc.ah != 0) continue;
+            sh.dc_slots = std::max<unsigned>(sh.dc_slots, (unsigned)sc.ncomp);
+            for (int i = 0; i < sc.ncomp; i++) sh.slot_words = std::max<unsigned>(sh.slot_words, (unsigned)prog_table_words(sc.dc[sc.td[i]]));
+        } else {
+            per_comp[sc.comp_index[0] & 3]++;
+            sh.slot_words = std::max<unsigned>(sh.slot_words, (unsigned)prog_table_words(sc.ac[sc.ta[0]]));
+        }
+    }
+    for (unsigned n : per_comp) {
+        sh.ac_waves += n;
+        sh.rings += n > 0 ? n - 1 : 0;
+    }
+    return sh;
 }
 
 size_t prog_pool_words(const FrameInfo& f)

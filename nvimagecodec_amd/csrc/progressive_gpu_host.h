@@ -17,6 +17,27 @@ namespace hipjpeg {
 // Everything else keeps the host entropy stage.
 bool gpu_progressive_eligible(const FrameInfo& f);
 
+// What a frame asks of the walk / replay launches (they are sized for the batch's maxima, decoder_core.cpp enqueue_progressive): the
+// largest lookup table in uint16 entries, table slots for its DC scans, AC scans (a wave each), hand-over rings; and the dynamic LDS
+// such a launch takes.  The planner keeps the batch's need below the device's workgroup limit by leaving the most demanding
+// images to the host entropy stage (a refused launch would fail the whole batch).
+struct ProgLdsShape {
+    unsigned slot_words = 0, dc_slots = 1, ac_waves = 0, rings = 0;
+    void merge(const ProgLdsShape& o)
+    {
+        slot_words = slot_words > o.slot_words ? slot_words : o.slot_words;
+        dc_slots = dc_slots > o.dc_slots ? dc_slots : o.dc_slots;
+        ac_waves = ac_waves > o.ac_waves ? ac_waves : o.ac_waves;
+        rings = rings > o.rings ? rings : o.rings;
+    }
+};
+ProgLdsShape prog_lds_shape(const FrameInfo& f);
+constexpr size_t kProgRingBytes = (size_t)kProgRing * kProgGroup * 8;   // sizeof(WalkRing), progressive_gpu.hip
+constexpr size_t kProgReplayStaticLds = 40 * 1024;                        // upper bound of prog_replay_kernel's static LDS (ReplayShared)
+inline size_t prog_slot_words(const ProgLdsShape& s) { return ((s.slot_words > 256u ? s.slot_words : 256u) + 63u) & ~(size_t)63; }
+inline size_t prog_walk_lds_bytes(const ProgLdsShape& s) { return (size_t)(s.dc_slots + s.ac_waves) * prog_slot_words(s) * 2 + s.rings * kProgRingBytes; }
+inline size_t prog_replay_lds_bytes(const ProgLdsShape& s) { return kProgReplayStaticLds + prog_slot_words(s) * 2 * kProgMaxStages; }
+
 // uint16 entries of the lookup table for `s` (256 first-level + 256 per 8-bit prefix that continues); 0 = malformed.
 size_t prog_table_words(const HuffSpec& s);
 // Expands `s` at out[0 .. prog_table_words(s)).

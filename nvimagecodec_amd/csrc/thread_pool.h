@@ -61,10 +61,19 @@ public:
     // Runs fn(index, thread_id) for index in [0, n); indices are handed out dynamically.  Blocks until done.
     // An exception thrown by fn on any thread stops the hand-out of further indices and is rethrown here, on the calling
     // thread, once every helper has come back (a throw inside a helper thread would otherwise end the process).
+    // Two threads may call at once (the plugin's completion thread decodes fallback images in resolve() while the caller's thread
+    // plans the next piece on the same pool): the helpers serve one job at a time, so the caller that does not get them runs its
+    // indices itself, with the thread id it would have had as the pool's calling thread -- callers that index per-thread scratch
+    // by that id must not share such scratch between concurrent calls (none does: resolve() and plan() keep theirs on the stack).
     void parallel_for(int n, const std::function<void(int, int)>& fn)
     {
         if (n <= 0) return;
         if (nthreads_ == 1 || n == 1) {
+            for (int i = 0; i < n; i++) fn(i, 0);
+            return;
+        }
+        std::unique_lock<std::mutex> owner(caller_m_, std::try_to_lock);
+        if (!owner.owns_lock()) {
             for (int i = 0; i < n; i++) fn(i, 0);
             return;
         }
@@ -129,7 +138,7 @@ private:
 
     int nthreads_ = 1;
     std::vector<std::thread> workers_;
-    std::mutex m_;
+    std::mutex m_, caller_m_;  // caller_m_: held by the one parallel_for call that has the helpers
     std::condition_variable cv_, done_cv_;
     const std::function<void(int, int)>* job_ = nullptr;
     int job_n_ = 0, pending_ = 0;

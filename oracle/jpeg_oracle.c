@@ -109,7 +109,7 @@ static int oj_build_huff(oj_huff* t)
         } else {
             t->maxcode[l] = -1;
         }
-        if (code > (1 << l)) return OJ_ERR_SYNTAX;
+        if (code >= (1 << l) && code > 0) return OJ_ERR_SYNTAX; /* jdhuff.c: "no code is allowed to be all ones" */
         code <<= 1;
     }
     t->maxcode[17] = 0x7fffffff;

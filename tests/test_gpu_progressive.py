@@ -177,3 +177,40 @@ def test_deeper_pipeline_for_progressive_batches(dec):
     with pytest.raises(N.HipJpegError):
         dec.set_pipeline_depth(9)
     dec.set_pipeline_depth(3)
+
+
+def _sos_offsets(jpeg):
+    """Byte offsets just behind every SOS header of a file (where the scan's entropy-coded bytes begin)."""
+    offs, i, b = [], 2, bytes(jpeg)
+    while i + 4 <= len(b):
+        assert b[i] == 0xFF
+        m = b[i + 1]
+        if m == 0xD9:
+            break
+        L = (b[i + 2] << 8) | b[i + 3]
+        i += 2 + L
+        if m == 0xDA:
+            offs.append(i)
+            while i + 1 < len(b) and not (b[i] == 0xFF and b[i + 1] != 0 and not 0xD0 <= b[i + 1] <= 0xD7):
+                i += 1
+    return offs
+
+
+def test_progressive_scan_without_entropy_coded_bytes(dec):
+    """a progressive file cut right behind an SOS header (its 2nd and its last), or with EOI directly behind one, has a scan
+    of zero bytes.  Such files must not reach the walk kernel (whose reader would look at word -1): the host decoder names the error,
+    the healthy neighbours in the batch decode bit-exactly, and the statuses are those of the host entropy stage."""
+    e = next(e for e in _PROG if e["name"] == "s64x48_444_prog_q90")
+    good, rgb = load_decode_case(e)
+    offs = _sos_offsets(good)
+    assert len(offs) >= 3
+    bad = [good[:offs[1]], good[:offs[-1]], good[:offs[1]] + b"\xff\xd9", good[:offs[-1]] + b"\xff\xd9"]
+    batch = [good, bad[0], good, bad[1], bad[2], good, bad[3]]
+    outs_h, st_h = dec.decode(batch, fmt="rgb", gpu_huffman=False)
+    _sync()
+    outs_g, st_g = dec.decode(batch, fmt="rgb", gpu_huffman=True)
+    _sync()
+    assert list(st_g) == list(st_h)
+    assert all(st_g[i] != 0 for i in (1, 3, 4, 6)) and all(st_g[i] == 0 for i in (0, 2, 5))
+    for i in (0, 2, 5):
+        assert np.array_equal(outs_g[i].cpu().numpy(), rgb if rgb is not None else oracle.decode(good))

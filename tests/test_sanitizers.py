@@ -35,3 +35,20 @@ def test_parser_and_entropy_decoders_are_clean_under_asan_and_ubsan(tmp_path):
     assert "0 coefficient mismatches" in run.stdout
     parsed = int(run.stdout.split("host_fuzz:")[1].split("parsed")[0])
     assert parsed > 1500  # the mutations are not all rejected by the first check
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_fork_join_pool_takes_concurrent_callers_under_tsan(tmp_path):
+    """resolve() on the plugin's completion thread and plan() on the caller's thread use ONE ForkJoinPool at the same time.
+    tests/sanitizers/pool_race.cpp: three threads, 400 parallel_for calls each, every index exactly once, exceptions to their own caller."""
+    exe = str(tmp_path / "pool_race")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I" + SRC, os.path.join(ROOT, "tests", "sanitizers", "pool_race.cpp"),
+                            "-o", exe, "-lpthread"], capture_output=True, text=True, timeout=600)
+    if build.returncode != 0 and "tsan" in build.stderr.lower() and "cannot find" in build.stderr.lower():
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    if "FATAL: ThreadSanitizer" in run.stderr and "unexpected memory mapping" in run.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert run.returncode == 0, (run.stdout + run.stderr)[-4000:]
+    assert "0 violations" in run.stdout
