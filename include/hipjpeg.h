@@ -104,6 +104,8 @@ typedef struct hipjpegHandle* hipjpegHandle_t;
 
 HIPJPEG_API const char* hipjpegStatusString(hipjpegStatus_t status);
 HIPJPEG_API int hipjpegVersion(void);
+/* ---- test hooks.  Every hipjpegTest* entry point answers only in a process started with HIPJPEG_ENABLE_TEST_HOOKS=1 (read once) and
+ * refuses (INVALID_ARGUMENT / -1) anywhere else: a production process cannot have a throw armed inside the library. ---- */
 /* Test hook (fault injection): the `countdown`-th passage of the named host-code site from now on throws a C++ exception
  * inside the library, once; site NULL or "" disarms.  Sites: "plan", "entropy_stage", "finalize", "transfer", "launch",
  * "resolve", "marshal".  The boundary must turn it into a status code / per-sample FAIL; tests/test_gpu_plugin.py relies on it. */
@@ -117,6 +119,9 @@ HIPJPEG_API int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle);
 /* Test hook: work units of the handle's current batch per kernel -- plane_units[0]: the plane IDCT kernel (K1); luma_units[3]: the fused
  * luma kernel (K2) by layout (0 generic, 1 the everyday interleaved kernel, 2 the everyday planar kernel; csrc/decode_kernels.h). */
 HIPJPEG_API hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[1], int32_t luma_units[3]);
+/* Test hook: how many of those work units went to the FUSED kernel builds (blocks Huffman-decoded inside the pixel kernels,
+ * HIPJPEG_FUSED_DECODE=1); negative without a handle. */
+HIPJPEG_API int32_t hipjpegTestFusedUnits(hipjpegHandle_t handle);
 
 /* Test hook (host only): the parser's per-chunk counts of the bytes that byte-stuffing removal drops from scan `scan_index` (16,384-byte
  * chunks of the entropy-coded segment; the GPU entropy stage's compact kernel works from them).  Returns the number of chunks, or a
@@ -175,6 +180,11 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handl
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
                                                      const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags, void* stream);
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size);
+/* With HIPJPEG_FLAG_GPU_HUFFMAN: only images of MORE than `pixels` pixels (width x height) take the GPU entropy stage, smaller ones the
+ * host Huffman decoder -- nvJPEG's switch between its HYBRID and GPU_HYBRID backends (plugin option hybrid_huffman_threshold,
+ * reference extensions/nvjpeg/cuda_decoder.cpp:188-209, 512-521).  0 (default) = every eligible stream on the GPU. */
+HIPJPEG_API hipjpegStatus_t hipjpegSetHybridHuffmanThreshold(hipjpegHandle_t handle, uint64_t pixels);
+
 /* How many batches Submit may have in flight (staging pages in use): 1..8, default 3; only while nothing is in flight.
  * Batches of progressive images keep a small part of the chip busy for a long time (one wave per scan), so their throughput
  * grows with the depth; each page in flight runs its entropy stage on a stream of its own, and the HIP runtime must be

@@ -47,7 +47,20 @@ class Output(ctypes.Structure):
     _fields_ = [("plane", ctypes.c_void_p * 3), ("pitch", ctypes.c_uint32 * 3)]
 
 
+HOST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libhipjpeg_host.so")
 _lib = None
+_host = None
+
+
+def load_host():
+    """libhipjpeg_host.so: the host harness with the application-side nvimgcodec* API (it loads libhipjpeg_ext.so itself, as an extension
+    module).  Opened RTLD_LOCAL -- a process that also holds a real libnvimgcodec must not see these names in its global scope."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} not found: build first (make -C nvimagecodec_amd/csrc)")
+        _host = ctypes.CDLL(HOST_LIB_PATH)
+    return _host
 
 
 def load():
@@ -57,7 +70,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
                           "or make -C nvimagecodec_amd/csrc)")
-    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    L = ctypes.CDLL(LIB_PATH)
     vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     L.hipjpegStatusString.restype = ctypes.c_char_p
     L.hipjpegStatusString.argtypes = [i32]
@@ -79,6 +92,7 @@ def load():
     L.hipjpegDecodeBatchSubmit.argtypes = [vp, vp, vp, i32, vp, i32, ctypes.c_uint, vp]
     L.hipjpegDecodeBatchWait.argtypes = [vp, vp, i32]
     L.hipjpegSetPipelineDepth.argtypes = [vp, i32]
+    L.hipjpegSetHybridHuffmanThreshold.argtypes = [vp, ctypes.c_uint64]
     L.hipjpegTestHostFallbacks.argtypes = [vp]
     L.hipjpegTestHostFallbacks.restype = i32
     L.hipjpegTestScanChunkDrops.argtypes = [vp, ctypes.c_size_t, i32, ctypes.POINTER(ctypes.c_uint32), i32]

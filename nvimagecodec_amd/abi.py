@@ -162,7 +162,8 @@ def init(struct_cls, struct_type, **kw):
 
 
 def bind(lib):
-    """Declare argtypes/restype of the public API functions exported by libhipjpeg_ext.so."""
+    """Declare argtypes/restype of the public API functions `lib` exports (libhipjpeg_host.so: the nvimgcodec* API; libhipjpeg_ext.so:
+    nvimgcodecExtensionModuleEntry)."""
     vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
     P = C.POINTER
     sig = {
@@ -196,7 +197,10 @@ def bind(lib):
         "nvimgcodecEncoderEncode": [vp, P(vp), P(vp), i, P(EncodeParams), P(vp)],
     }
     for name, args in sig.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue
         fn.argtypes = args
         fn.restype = C.c_int
     return lib

@@ -91,7 +91,7 @@ def _api():
     """Process-wide library + instance (the reference module also owns one instance, python/main.cpp:48-85)."""
     global _lib, _instance
     if _lib is None:
-        _lib = A.bind(_native.load())
+        _lib = A.bind(_native.load_host())
     if _instance is None:
         ci = A.init(A.InstanceCreateInfo, A.ST_INSTANCE_CREATE_INFO, load_builtin_modules=1, load_extension_modules=1,
                     create_debug_messenger=1, message_severity=A.SEVERITY_ERROR | A.SEVERITY_FATAL, message_category=A.CATEGORY_ALL)

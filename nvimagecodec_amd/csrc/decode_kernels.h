@@ -13,6 +13,14 @@ int launch_idct_plane(const DecodeImage* images, const WorkUnit* units, int nuni
 // time), 1 = COMMON (YCbCr source, interleaved RGB / BGR, fancy upsampling), 2 = COMMON with planar RGB / BGR output
 constexpr int kNumLumaLayouts = 3;
 int launch_luma_color(int layout, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
+// FUSED builds of K1 / K2 for images of the GPU entropy stage (baseline): the blocks are Huffman-decoded inside the kernel, into the LDS
+// slots the IDCT reads, from the start positions the position pass recorded (HuffImage::block_pos) -- no coefficient block is written
+// to or read from HBM.  himages = the batch's HuffImage array (DecodeImage::huff_index points into it), pool_bytes = dynamic LDS for
+// the largest lookup-table pool of the batch.  Same work units as the plain builds.
+struct HuffImage;
+int launch_idct_plane_fused(const DecodeImage* images, const WorkUnit* units, int nunits, HuffImage* himages, unsigned pool_bytes, void* stream);
+int launch_luma_color_fused(int layout, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, HuffImage* himages, unsigned pool_bytes,
+                            void* stream);
 // K3: per-pixel colour stage from planes (replication upsampling) for uncommon sampling layouts.
 int launch_generic_color(const DecodeImage* images, const WorkUnit* units, int nunits, void* stream);
 // Four-component frames (CMYK / YCCK): upsampling + the reference's CMYK -> RGB step, one WorkUnit per pixel row.

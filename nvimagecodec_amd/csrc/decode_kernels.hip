@@ -24,6 +24,7 @@
 
 #include "decode_kernels.h"
 #include "device_layout.h"
+#include "huffman_gpu_core.h"
 
 namespace hipjpeg {
 
@@ -93,6 +94,111 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- FUSED builds (round 3): the coefficient blocks come straight from the bitstream ------------------------------------------
+// For images whose entropy stage runs on the GPU the block pass of gpu_huffman.hip used to write every coefficient block to HBM
+// (1.6 GB per 256 x 1080p) for these kernels to read back.  The FUSED builds skip that round trip: where the plain builds stage a
+// wave's 32 blocks from HBM into its LDS slots, here 32 lanes of the wave Huffman-decode them into the very same slots
+// (huffman_gpu_core.h decode_block: one lane per block from the start position the position pass recorded; bitstream through the
+// vector cache, lookup tables in LDS), and everything behind the slots -- the two-lane IDCT, upsampling, colour, stores -- is the
+// same code.  DC values come from the compact DC planes as for every GPU-decoded image (the DC pass has run before).
+#define HJ_LDS __attribute__((address_space(3)))
+struct FusedShared {
+    uint32_t tsel[10];
+    uint32_t zz[16];
+};
+struct FusedEnv {
+    const uint32_t* gstream;
+    uint32_t gwords;
+    uint32_t pool, buf;  // LDS byte addresses: lookup tables, this lane's block slot
+    const HJ_LDS uint32_t* tsel;
+    const HJ_LDS uint8_t* zz;
+    static constexpr uint32_t kCursorStep = 1;  // the cursor is the word index
+    __device__ __forceinline__ uint32_t cursor(uint32_t i) const { return i; }
+    __device__ __forceinline__ uint32_t fetch(uint32_t i) const
+    {
+        // unconditional load from a clamped index, selection afterwards (gpu_huffman.hip BlockEnv::word)
+        const uint32_t x = *(const HJ_GLOBAL uint32_t*)((const HJ_GLOBAL char*)gstream + (min(i, gwords - 1) << 2));
+        return i < gwords ? __builtin_bswap32(x) : ~0u;
+    }
+    __device__ __forceinline__ uint32_t tables(int k) const { return tsel[k]; }
+    __device__ __forceinline__ uint32_t lookup1(uint32_t t, uint32_t w) const
+    {
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + t + ((w >> (31 - kHuffFastBits)) & ((2u << kHuffFastBits) - 2)));
+    }
+    __device__ __forceinline__ uint32_t lookup2(uint32_t e, uint32_t w) const
+    {
+        return *(const HJ_LDS uint16_t*)(uintptr_t)(pool + ((e & 0x1FFu) << 7) + ((w >> 15) & ((2u << kHuffSubBits) - 2)));
+    }
+    __device__ __forceinline__ int zigzag(int z) const { return zz[z]; }
+    __device__ __forceinline__ void put(int index, int value) const { *(HJ_LDS int16_t*)(uintptr_t)(buf + index * 2) = (int16_t)value; }
+};
+
+// lookup tables, per-MCU-position table offsets and the zigzag permutation -> LDS; ends with a workgroup barrier
+__device__ __forceinline__ void fused_stage(const HuffImage& hi, HJ_LDS uint16_t* pool, FusedShared& fs)
+{
+    const int t = threadIdx.x;
+    const HJ_GLOBAL u32x4* gp = (const HJ_GLOBAL u32x4*)hi.pool;
+    const uint32_t npool = hi.pool_words >> 3;  // pool_words is a multiple of 64
+    for (uint32_t i = t; i < npool; i += kThreads) {
+        const u32x4 x = gp[i];
+        HJ_LDS uint32_t* lp = reinterpret_cast<HJ_LDS uint32_t*>(pool) + i * 4;
+        lp[0] = x.x;
+        lp[1] = x.y;
+        lp[2] = x.z;
+        lp[3] = x.w;
+    }
+    if (t < 10) fs.tsel[t] = ((uint32_t)hi.k[t].tdc * 2) | ((uint32_t)hi.k[t].tac * 2 << 16);  // byte offsets
+    if (t >= 64 && t < 80) {
+        constexpr uint8_t zz[64] = HJ_ZIGZAG_DEVICE_TABLE;
+        const int i = (t - 64) * 4;
+        fs.zz[t - 64] = (uint32_t)zz[i] | ((uint32_t)zz[i + 1] << 8) | ((uint32_t)zz[i + 2] << 16) | ((uint32_t)zz[i + 3] << 24);
+    }
+    __syncthreads();
+}
+
+// Decodes the wave's 32 blocks into its LDS slots: lane j < 32 takes slot j = block (row, col) of component c's grid (have = the
+// slot holds a block that is needed).  Slots are zeroed first (decode_block stores only the coefficients that are there); the DC
+// position stays zero -- the caller patches the DC value in from the DC plane.
+__device__ __forceinline__ void fused_decode_slots(HuffImage& hi, HJ_LDS uint16_t* pool, FusedShared& fs, int c, bool have, int row, int col, char* lds_wave,
+                                                   int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int g = k * 64 + lane;  // 288 16-byte pieces
+        if (g < kBlocksPerWave * kLdsBlockStride / 16) *reinterpret_cast<u32x4*>(lds_wave + g * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    wave_lds_fence();
+    if (lane < kBlocksPerWave && have) {
+        const uint32_t h = hi.comp_h[c], v = hi.comp_v[c];
+        const uint32_t my = (uint32_t)row / v, mx = (uint32_t)col / h;
+        const uint32_t k = hi.comp_k0[c] + ((uint32_t)row - my * v) * h + ((uint32_t)col - mx * h);
+        const uint32_t b = (my * hi.mcus_x + mx) * hi.blocks_per_mcu + k;
+        if (b < min(hi.total_blocks, hi.decoded_blocks)) {  // (a truncated stream: the scan kernel has flagged the image)
+            const HuffGeom geom = make_geom(hi);
+            FusedEnv env;
+            env.gstream = reinterpret_cast<const uint32_t*>(hi.stream);
+            env.gwords = hi.stream_words;
+            env.pool = (uint32_t)(uintptr_t)pool;
+            env.buf = (uint32_t)(uintptr_t)(HJ_LDS char*)(lds_wave + lane * kLdsBlockStride);
+            env.tsel = (const HJ_LDS uint32_t*)fs.tsel;
+            env.zz = (const HJ_LDS uint8_t*)fs.zz;
+            uint32_t err = 0;
+            (void)decode_block(geom, env, ((const HJ_GLOBAL uint32_t*)hi.block_pos)[b], (int)k, &err);
+            if (err) hi.status = 1;  // benign race: every writer stores the same value
+        }
+    }
+    wave_lds_fence();
+}
+
+// each lane's four 16-byte column chunks out of the wave's slots, DC patched in by lane 0 of the pair
+__device__ __forceinline__ void read_half_block(const char* lds_wave, int lane, unsigned dc, bool dc_apart, u32x4 (&cols)[4])
+{
+    const char* mine = lds_wave + (lane >> 1) * kLdsBlockStride + (lane & 1) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; j++) cols[j] = *reinterpret_cast<const u32x4*>(mine + j * 16);
+    if (dc_apart && !(lane & 1)) cols[0].x = (cols[0].x & 0xFFFF0000u) | dc;
 }
 
 // Coalesced HBM -> LDS staging of the 32 blocks a wave owns (4 KB contiguous), then each lane reads back the four
@@ -353,7 +459,9 @@ __device__ __forceinline__ void idct_block_pair(const u32x4 (&cols)[4], const un
 // ------------------------------------------------------------------------------------------------
 // K1: IDCT of 128 consecutive blocks of one component into a u8 plane (internal plane or user output).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const WorkUnit& u, char* lds)
+template <bool FUSED>
+__device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const WorkUnit& u, char* lds, HuffImage* hi = nullptr, HJ_LDS uint16_t* pool = nullptr,
+                                                FusedShared* fs = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool p = lane & 1;
@@ -361,7 +469,17 @@ __device__ __forceinline__ void idct_plane_body(const DecodeImage& im, const Wor
     const int bw = cd.blocks_w, nblocks = bw * cd.blocks_h;
     const int wave_first = u.block_base + wave * kBlocksPerWave;
     u32x4 cols[4];
-    fetch_half_block(cd, wave_first, nblocks, lds + wave * kBlocksPerWave * kLdsBlockStride, lane, cols);
+    if constexpr (FUSED) {
+        char* lds_wave = lds + wave * kBlocksPerWave * kLdsBlockStride;
+        const int mine = wave_first + (lane >> 1);
+        unsigned dc = 0;
+        if (mine < nblocks) dc = ((const HJ_GLOBAL unsigned short*)cd.dc)[mine];
+        const int jb = wave_first + lane;  // the block lane j < 32 decodes
+        const int jrow = jb / bw, jcol = jb - jrow * bw;
+        fused_decode_slots(*hi, pool, *fs, (int)u.comp, jb < nblocks, jrow, jcol, lds_wave, lane);
+        read_half_block(lds_wave, lane, dc, true, cols);
+    } else
+        fetch_half_block(cd, wave_first, nblocks, lds + wave * kBlocksPerWave * kLdsBlockStride, lane, cols);
     const int b = wave_first + (lane >> 1);
     if (b >= nblocks) return;  // whole pairs leave together
     unsigned rows[4][4];
@@ -404,7 +522,20 @@ __global__ __launch_bounds__(kThreads, HJ_MIN_WAVES) void idct_plane_kernel(cons
 {
     __shared__ __attribute__((aligned(16))) char lds[4 * kBlocksPerWave * kLdsBlockStride];
     const WorkUnit u = units[blockIdx.x];
-    idct_plane_body(images[u.image], u, lds);
+    idct_plane_body<false>(images[u.image], u, lds);
+}
+
+__global__ __launch_bounds__(kThreads, HJ_MIN_WAVES) void idct_plane_fused_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units,
+                                                                                 HuffImage* __restrict__ himages)
+{
+    __shared__ __attribute__((aligned(16))) char lds[4 * kBlocksPerWave * kLdsBlockStride];
+    __shared__ FusedShared fs;
+    extern __shared__ uint16_t dyn_pool[];
+    const WorkUnit u = units[blockIdx.x];
+    const DecodeImage& im = images[u.image];
+    HuffImage& hi = himages[im.huff_index];
+    fused_stage(hi, (HJ_LDS uint16_t*)dyn_pool, fs);
+    idct_plane_body<true>(im, u, lds, &hi, (HJ_LDS uint16_t*)dyn_pool, &fs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -510,8 +641,9 @@ constexpr int kNarrowRowBytes = 16 * 24;                // narrow tiles: 16 pixe
 // LAYOUT: 0 = whatever the descriptor says (run-time branches), 1 = COMMON, 2 = COMMON with planar output (P_RGB / P_BGR: what
 // CHW consumers ask for) -- same arithmetic, one set of format flags fixed at compile time each
 enum LumaLayout : int { kLayoutAny = 0, kLayoutInterleaved = 1, kLayoutPlanar = 2 };
-template <int HS, int VS, int LAYOUT>
-__device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds)
+template <int HS, int VS, int LAYOUT, bool FUSED = false>
+__device__ __forceinline__ void luma_color_body(const DecodeImage& im, const WorkUnit& u, char* lds, HuffImage* hi = nullptr, HJ_LDS uint16_t* pool = nullptr,
+                                                FusedShared* fs = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool p = lane & 1;
@@ -526,10 +658,17 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
     const int bx = bx0 + (blk & col_mask), by = by_wave + (blk >> row_shift);
     char* lds_wave = lds + wave * kLdsLumaWaveBytes;
     u32x4 cols[4];
-    fetch_tile_half_block(im.comp[0], by_wave, bx0, row_shift, col_mask, bw, bh, lds_wave, lane, cols);
     const int x0 = bx * 8, y0 = by * 8;
     const int W = im.width, H = im.height;
     const bool valid = bx < bw && by < bh && x0 < W && y0 < H;  // false: pair idles (block is MCU padding or outside the tile)
+    if constexpr (FUSED) {
+        unsigned dc = 0;
+        if (valid) dc = *(const HJ_GLOBAL unsigned short*)((const HJ_GLOBAL char*)im.comp[0].dc + (unsigned)(by * bw + bx) * 2u);
+        const int jrow = by_wave + (lane >> row_shift), jcol = bx0 + (lane & col_mask);  // the block lane j < 32 decodes
+        fused_decode_slots(*hi, pool, *fs, 0, jrow < bh && jcol < bw && jcol * 8 < W && jrow * 8 < H, jrow, jcol, lds_wave, lane);
+        read_half_block(lds_wave, lane, dc, true, cols);
+    } else
+        fetch_tile_half_block(im.comp[0], by_wave, bx0, row_shift, col_mask, bw, bh, lds_wave, lane, cols);
 
     const int fmt = im.out_format;
     constexpr bool COMMON = LAYOUT != kLayoutAny;
@@ -758,6 +897,23 @@ __global__ __launch_bounds__(kThreads, HJ_MIN_WAVES_LUMA) void luma_color_kernel
     luma_color_body<HS, VS, LAYOUT>(images[u.image], u, lds);
 }
 
+#ifndef HJ_MIN_WAVES_FUSED
+#define HJ_MIN_WAVES_FUSED 4
+#endif
+template <int HS, int VS, int LAYOUT>
+__global__ __launch_bounds__(kThreads, HJ_MIN_WAVES_FUSED) void luma_color_fused_kernel(const DecodeImage* __restrict__ images, const WorkUnit* __restrict__ units,
+                                                                                        HuffImage* __restrict__ himages)
+{
+    __shared__ __attribute__((aligned(16))) char lds[4 * kLdsLumaWaveBytes];
+    __shared__ FusedShared fs;
+    extern __shared__ uint16_t dyn_pool[];
+    const WorkUnit u = units[blockIdx.x];
+    const DecodeImage& im = images[u.image];
+    HuffImage& hi = himages[im.huff_index];
+    fused_stage(hi, (HJ_LDS uint16_t*)dyn_pool, fs);
+    luma_color_body<HS, VS, LAYOUT, true>(im, u, lds, &hi, (HJ_LDS uint16_t*)dyn_pool, &fs);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: generic colour stage for layouts the fused kernel does not cover (4:1:1, 4:1:0, ...): every component is in a
 // plane already; libjpeg upsamples those by plain replication (jdsample.c int_upsample).  One thread = one pixel.
@@ -969,6 +1125,44 @@ int launch_idct_plane(const DecodeImage* images, const WorkUnit* units, int nuni
     if (nunits <= 0) return 0;
     hipLaunchKernelGGL(idct_plane_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
     return (int)hipGetLastError();
+}
+
+int launch_idct_plane_fused(const DecodeImage* images, const WorkUnit* units, int nunits, HuffImage* himages, unsigned pool_bytes, void* stream)
+{
+    if (nunits <= 0) return 0;
+    hipLaunchKernelGGL(idct_plane_fused_kernel, dim3(nunits), dim3(kThreads), pool_bytes, (hipStream_t)stream, images, units, himages);
+    return (int)hipGetLastError();
+}
+
+template <int LAYOUT>
+static int launch_luma_fused_t(int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, HuffImage* himages, unsigned pool_bytes, hipStream_t s)
+{
+    if (hs == 0) {
+        if constexpr (LAYOUT != kLayoutAny) return (int)hipErrorInvalidValue;
+        else hipLaunchKernelGGL((luma_color_fused_kernel<0, 0, kLayoutAny>), dim3(nunits), dim3(kThreads), pool_bytes, s, images, units, himages);
+    } else if (hs == 1 && vs == 1)
+        hipLaunchKernelGGL((luma_color_fused_kernel<1, 1, LAYOUT>), dim3(nunits), dim3(kThreads), pool_bytes, s, images, units, himages);
+    else if (hs == 2 && vs == 1)
+        hipLaunchKernelGGL((luma_color_fused_kernel<2, 1, LAYOUT>), dim3(nunits), dim3(kThreads), pool_bytes, s, images, units, himages);
+    else if (hs == 2 && vs == 2)
+        hipLaunchKernelGGL((luma_color_fused_kernel<2, 2, LAYOUT>), dim3(nunits), dim3(kThreads), pool_bytes, s, images, units, himages);
+    else if (hs == 1 && vs == 2)
+        hipLaunchKernelGGL((luma_color_fused_kernel<1, 2, LAYOUT>), dim3(nunits), dim3(kThreads), pool_bytes, s, images, units, himages);
+    else
+        return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+int launch_luma_color_fused(int layout, int hs, int vs, const DecodeImage* images, const WorkUnit* units, int nunits, HuffImage* himages, unsigned pool_bytes,
+                            void* stream)
+{
+    if (nunits <= 0) return 0;
+    switch (layout) {
+    case 0: return launch_luma_fused_t<kLayoutAny>(hs, vs, images, units, nunits, himages, pool_bytes, (hipStream_t)stream);
+    case 1: return launch_luma_fused_t<kLayoutInterleaved>(hs, vs, images, units, nunits, himages, pool_bytes, (hipStream_t)stream);
+    case 2: return launch_luma_fused_t<kLayoutPlanar>(hs, vs, images, units, nunits, himages, pool_bytes, (hipStream_t)stream);
+    default: return (int)hipErrorInvalidValue;
+    }
 }
 
 template <int LAYOUT>

@@ -32,27 +32,6 @@ hipjpegStatus_t status_from_parse(ParseStatus s)
 }
 
 // Same classification the framework's parser applies (reference src/parsers/jpeg.cpp:70-114).
-hipjpegChromaSubsampling_t classify_subsampling(const FrameInfo& f)
-{
-    if (f.ncomp == 1) return HIPJPEG_CSS_GRAY;
-    if (f.ncomp != 3) return HIPJPEG_CSS_UNKNOWN;
-    int yh = f.comp[0].h, yv = f.comp[0].v, uh = f.comp[1].h, uv = f.comp[1].v, vh = f.comp[2].h, vv = f.comp[2].v;
-    int minh = std::min(yh, std::min(uh, vh)), minv = std::min(yv, std::min(uv, vv));
-    if (minh == 0 || minv == 0) return HIPJPEG_CSS_UNKNOWN;
-    if (yh % minh || uh % minh || vh % minh || yv % minv || uv % minv || vv % minv) return HIPJPEG_CSS_UNKNOWN;
-    yh /= minh; uh /= minh; vh /= minh;
-    yv /= minv; uv /= minv; vv /= minv;
-    if (uh != vh || uv != vv || uh != 1 || uv != 1) return HIPJPEG_CSS_UNKNOWN;
-    if (yh == 1 && yv == 1) return HIPJPEG_CSS_444;
-    if (yh == 2 && yv == 1) return HIPJPEG_CSS_422;
-    if (yh == 2 && yv == 2) return HIPJPEG_CSS_420;
-    if (yh == 1 && yv == 2) return HIPJPEG_CSS_440;
-    if (yh == 4 && yv == 1) return HIPJPEG_CSS_411;
-    if (yh == 4 && yv == 2) return HIPJPEG_CSS_410;
-    if (yh == 2 && yv == 4) return HIPJPEG_CSS_410V;
-    return HIPJPEG_CSS_UNKNOWN;
-}
-
 // ---------------------------------------------------------------- Buffer
 hipjpegStatus_t Buffer::reserve(size_t bytes)
 {
@@ -102,6 +81,7 @@ DecodeBatch::DecodeBatch(int device_id, const MemoryHooks* hooks)
 
 DecodeBatch::~DecodeBatch()
 {
+    if (taken_units_dev_) (void)hipFree(taken_units_dev_);
     if (copied_event_) (void)hipEventDestroy((hipEvent_t)copied_event_);
     if (entropy_event_) (void)hipEventDestroy((hipEvent_t)entropy_event_);
     if (done_event_) {
@@ -296,10 +276,11 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
                     if ((uint64_t)outputs[i].pitch[p] < (uint64_t)ow * bpp) im.status = HIPJPEG_STATUS_INVALID_ARGUMENT;
             }
         }
-        if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && gpu_entropy_eligible(f)) {
+        const bool big_enough = (uint64_t)f.width * (uint64_t)f.height > gpu_entropy_min_pixels_ || gpu_entropy_min_pixels_ == 0;
+        if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && big_enough && gpu_entropy_eligible(f)) {
             im.gpu_entropy = true;
             im.pool_words = gpu_pool_words(f.scans[0]);
-        } else if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && gpu_progressive_eligible(f)) {
+        } else if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && big_enough && gpu_progressive_eligible(f)) {
             im.gpu_entropy = im.gpu_prog = true;
             im.pool_words = prog_pool_words(f);
         }
@@ -700,8 +681,18 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
     generic_units_.clear();
     cmyk_units_.clear();
     plane_units_.clear();
-    for (int e = 0; e < kNumLumaLayouts; e++)
+    fused_plane_units_.clear();
+    host_taken_.clear();
+    for (int e = 0; e < kNumLumaLayouts; e++) {
         for (auto& v : luma_units_[e]) v.clear();
+        for (auto& v : fused_luma_units_[e]) v.clear();
+    }
+    // HIPJPEG_FUSED_DECODE=1: the pixel kernels Huffman-decode the blocks themselves (decode_kernels.hip FUSED builds) instead of reading
+    // coefficient blocks the block pass wrote to HBM.  Measured: HBM traffic of the step falls by more than half,
+    // its TIME rises (2.72 -> 3.20 ms per 256 x 1080p): both halves are bound by instruction issue, and inside the pixel kernels only 32
+    // of a wave's 64 lanes have a block to decode.  Off by default; kept as a switch and covered by the parity tests.
+    static const bool fused_enabled = getenv("HIPJPEG_FUSED_DECODE") != nullptr && atoi(getenv("HIPJPEG_FUSED_DECODE")) != 0;
+    fused_ = fused_enabled;
     const int n = (int)images_.size();
     for (int i = 0; i < n; i++) {
         PlannedImage& im = images_[i];
@@ -710,13 +701,17 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         const FrameInfo& f = im.frame;
         DecodeImage& d = desc_[i];
         const OutFormat fmt = (OutFormat)d.out_format;
+        const bool fused = fused_ && im.gpu_entropy && !im.gpu_prog;
+        d.huff_index = fused ? (uint32_t)im.huff_index : 0u;
+        std::vector<WorkUnit>& plane_list = fused ? fused_plane_units_ : plane_units_;
+        auto& luma_lists = fused ? fused_luma_units_ : luma_units_;
         for (int c = 0; c < f.ncomp; c++) {
             const uint32_t nblk = (uint32_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
             bool needs_plane = (im.variant == -1) || (im.variant == -3) || (im.variant >= kVar11 && c > 0);
             bool to_output = (im.variant == -2) && (fmt == kOutPlanarYUV || c == 0);
             if (needs_plane || to_output) {
                 uint32_t mode = to_output ? (uint32_t)(kToOutput | (c << 8)) : (uint32_t)kToPlane;
-                for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) plane_units_.push_back(WorkUnit{(uint32_t)i, b, (uint32_t)c, mode});
+                for (uint32_t b = 0; b < nblk; b += kBlocksPerUnit) plane_list.push_back(WorkUnit{(uint32_t)i, b, (uint32_t)c, mode});
             }
         }
         if (im.variant >= 0) {
@@ -739,10 +734,10 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             const uint32_t wide_end = (ragged != 0 && ragged <= kLumaTileW / 2) ? end_col - ragged : end_col;
             for (uint32_t by = first_row; by < real_rows; by += kLumaTileH)
                 for (uint32_t bx = first_col; bx < wide_end; bx += kLumaTileW)
-                    luma_units_[flavour][im.variant].push_back(WorkUnit{(uint32_t)i, bx, by, 0u});
+                    luma_lists[flavour][im.variant].push_back(WorkUnit{(uint32_t)i, bx, by, 0u});
             if (wide_end < end_col)
                 for (uint32_t by = first_row; by < real_rows; by += 2 * kLumaTileH)
-                    luma_units_[flavour][im.variant].push_back(WorkUnit{(uint32_t)i, wide_end, by, 1u});
+                    luma_lists[flavour][im.variant].push_back(WorkUnit{(uint32_t)i, wide_end, by, 1u});
         } else if (im.variant == -1) {
             for (int y = 0; y < f.height; y++) generic_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});
         } else if (im.variant == -3) {
@@ -761,6 +756,9 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
     put(plane_units_, &unit_off_plane_);
     for (int e = 0; e < kNumLumaLayouts; e++)
         for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[e][k], &unit_off_luma_[e][k]);
+    put(fused_plane_units_, &unit_off_fused_plane_);
+    for (int e = 0; e < kNumLumaLayouts; e++)
+        for (int k = 0; k < kNumLumaVariants; k++) put(fused_luma_units_[e][k], &unit_off_fused_luma_[e][k]);
     put(generic_units_, &unit_off_generic_);
     put(cmyk_units_, &unit_off_cmyk_);
     // geometry pass
@@ -985,7 +983,7 @@ bool DecodeBatch::entropy_write_passes(const EntropyLaunch& L, void* stream)
 {
     return launch_huff_scan(L.dimg, L.dlist, (int)huff_list_.size(), L.states, L.first_block, stream) == 0 &&
            launch_huff_write(L.dimg, L.dunits, L.nunits, L.dwunits, (int)huff_wunits_.size(), L.states, L.first_block, L.group_sums, L.pool_bytes,
-                             stream) == 0 &&
+                             stream, fused_) == 0 &&
            launch_huff_dc(L.dimg, L.ddc, (int)huff_dc_units_.size(), L.dwunits, (int)huff_wunits_.size(), L.group_sums, stream) == 0;
 }
 
@@ -1055,6 +1053,8 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
         }
         if (hipMemcpyAsync(dimg, himg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
         if (!write_passes()) return HIPJPEG_STATUS_HIP_ERROR;
+        // FUSED builds: the pixel kernels decode the blocks, so their verdicts belong to this read-back
+        if (fused_ && pixels_launched_ && launch_pixel_kernels(stream, -1) != 0) return HIPJPEG_STATUS_HIP_ERROR;
         if (hipMemcpyAsync(himg, dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
         if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
         redo_pixels = true;
@@ -1126,6 +1126,7 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
                     hipMemcpy(work_.data() + work_dc_diff_ + im.dc_plane_offset[c], dc.data(), nblk * 2, hipMemcpyHostToDevice) != hipSuccess)
                     return HIPJPEG_STATUS_HIP_ERROR;
             }
+            if (fused_ && im.gpu_entropy && !im.gpu_prog) host_taken_.push_back(takeover[first + j]);
             redo_pixels = true;
         }
     }
@@ -1134,6 +1135,51 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
         if (launch_pixel_kernels(stream, -1) != 0 || hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     }
     return HIPJPEG_STATUS_SUCCESS;
+}
+
+// The plain K1 / K2 builds for the images in host_taken_: their units are those of the FUSED lists (same geometry), picked out by
+// image, uploaded to a scratch buffer of their own.  Rare path (damaged or periodic streams): blocking copies are fine.
+int DecodeBatch::launch_taken_pixels(void* stream, int which)
+{
+    const DecodeImage* dimg = reinterpret_cast<const DecodeImage*>(device_.data() + desc_offset_);
+    static const int hs[kNumLumaVariants] = {0, 1, 2, 2, 1}, vs[kNumLumaVariants] = {0, 1, 1, 2, 2};
+    std::vector<char> taken(images_.size(), 0);
+    for (int i : host_taken_) taken[(size_t)i] = 1;
+    std::vector<WorkUnit> units;
+    struct Run {
+        int layout, variant;  // layout < 0: K1
+        size_t first, count;
+    };
+    std::vector<Run> runs;
+    auto pick = [&](const std::vector<WorkUnit>& from, int layout, int variant) {
+        const size_t first = units.size();
+        for (const WorkUnit& u : from)
+            if (taken[u.image]) units.push_back(u);
+        if (units.size() > first) runs.push_back(Run{layout, variant, first, units.size() - first});
+    };
+    if (which < 0 || which == 0) pick(fused_plane_units_, -1, 0);
+    if (which < 0 || which == 1)
+        for (int e = 0; e < kNumLumaLayouts; e++)
+            for (int k = 0; k < kNumLumaVariants; k++) pick(fused_luma_units_[e][k], e, k);
+    if (units.empty()) return 0;
+    const size_t bytes = units.size() * sizeof(WorkUnit);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;  // an earlier launch may still read the scratch buffer
+    if (bytes > taken_units_cap_) {
+        if (taken_units_dev_) (void)hipFree(taken_units_dev_);
+        taken_units_dev_ = nullptr;
+        taken_units_cap_ = 0;
+        if (hipMalloc(&taken_units_dev_, bytes * 2) != hipSuccess) return -1;
+        taken_units_cap_ = bytes * 2;
+    }
+    if (hipMemcpy(taken_units_dev_, units.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    const WorkUnit* du = static_cast<const WorkUnit*>(taken_units_dev_);
+    int rc = 0;
+    for (const Run& r : runs) {
+        if (rc != 0) break;
+        rc = r.layout < 0 ? launch_idct_plane(dimg, du + r.first, (int)r.count, stream)
+                          : launch_luma_color(r.layout, hs[r.variant], vs[r.variant], dimg, du + r.first, (int)r.count, stream);
+    }
+    return rc;
 }
 
 int DecodeBatch::launch_pixel_kernels(void* stream, int which)
@@ -1173,15 +1219,25 @@ int DecodeBatch::launch_pixel_kernels(void* stream, int which)
         }
         return rc;
     }
+    HuffImage* himg = reinterpret_cast<HuffImage*>(device_.data() + huff_desc_offset_);
+    const unsigned pool_bytes = (unsigned)align_up(max_pool_words_ * 2, 256);
     if (rc == 0 && (which < 0 || which == 0)) {
         rc = launch_idct_plane(dimg, units_at(unit_off_plane_), (int)plane_units_.size(), stream);
         check("idct_plane", (int)plane_units_.size());
+        if (rc == 0) rc = launch_idct_plane_fused(dimg, units_at(unit_off_fused_plane_), (int)fused_plane_units_.size(), himg, pool_bytes, stream);
+        check("idct_plane_fused", (int)fused_plane_units_.size());
     }
     for (int e = 0; e < kNumLumaLayouts; e++)
         for (int k = 0; k < kNumLumaVariants && rc == 0 && (which < 0 || which == 1); k++) {
             rc = launch_luma_color(e, hs[k], vs[k], dimg, units_at(unit_off_luma_[e][k]), (int)luma_units_[e][k].size(), stream);
             check("luma_color", (int)luma_units_[e][k].size());
+            if (rc == 0)
+                rc = launch_luma_color_fused(e, hs[k], vs[k], dimg, units_at(unit_off_fused_luma_[e][k]), (int)fused_luma_units_[e][k].size(), himg, pool_bytes,
+                                             stream);
+            check("luma_color_fused", (int)fused_luma_units_[e][k].size());
         }
+    // images the host entropy decoder took over: the plain builds, on the coefficients it uploaded
+    if (rc == 0 && !host_taken_.empty() && (which < 0 || which == 0 || which == 1)) rc = launch_taken_pixels(stream, which);
     if (rc == 0 && (which < 0 || which == 2)) {
         rc = launch_generic_color(dimg, units_at(unit_off_generic_), (int)generic_units_.size(), stream);
         check("generic_color", (int)generic_units_.size());
@@ -1250,6 +1306,13 @@ hipjpegStatus_t DecodeBatch::launch(void* stream, int which, void* entropy_strea
     }
     if (which != 6 && launch_pixel_kernels(stream, which) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (which < 0) pixels_launched_ = true;
+    if (fused_ && entropy_pending_ && !huff_units_.empty() && (which < 0 || which == 1)) {
+        // the FUSED pixel kernels are part of the entropy decode: a block they cannot decode flags its image -- the verdicts are
+        // fetched behind them (the copy queued with the entropy stage saw the position pass's verdicts only)
+        EntropyLaunch L = entropy_launch_args();
+        if (hipMemcpyAsync(L.himg, L.dimg, sizeof(HuffImage) * huff_images_.size(), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+            return HIPJPEG_STATUS_HIP_ERROR;
+    }
     if (!done_event_) {
         hipEvent_t ev;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
@@ -1276,10 +1339,12 @@ void DecodeBatch::output_size(int i, int* w, int* h) const
 void DecodeBatch::stats(int32_t num_units[3], uint64_t* coef_bytes, uint64_t* output_bytes) const
 {
     if (num_units) {
-        num_units[0] = (int32_t)plane_units_.size();
+        num_units[0] = (int32_t)(plane_units_.size() + fused_plane_units_.size());
         num_units[1] = 0;
-        for (int e = 0; e < kNumLumaLayouts; e++)
+        for (int e = 0; e < kNumLumaLayouts; e++) {
             for (const auto& v : luma_units_[e]) num_units[1] += (int32_t)v.size();
+            for (const auto& v : fused_luma_units_[e]) num_units[1] += (int32_t)v.size();
+        }
         num_units[2] = (int32_t)generic_units_.size();
     }
     if (coef_bytes) *coef_bytes = coef_bytes_;

@@ -102,6 +102,11 @@ public:
                          hipjpegOutputFormat_t format, unsigned flags, hipjpegStatus_t* statuses,
                          const hipjpegOutputFormat_t* formats = nullptr, ForkJoinPool* pool = nullptr,
                          const hipjpegTransform_t* transforms = nullptr);
+    // GPU entropy stage only for images of MORE than this many pixels (width x height); smaller ones keep the host Huffman decoder.
+    // The reference's nvJPEG plugin has the same switch between its HYBRID and GPU_HYBRID backends (`hybrid_huffman_threshold`,
+    // extensions/nvjpeg/cuda_decoder.cpp:188-209, 512-521; default 1000 x 1000 there).  Default here 0: every eligible stream goes to
+    // the GPU -- measured faster from 224 x 224 upwards.
+    void set_gpu_entropy_threshold(uint64_t pixels) { gpu_entropy_min_pixels_ = pixels; }
     // Between plan() and entropy_stage(): give up image i (e.g. the caller's image descriptor is too small for it).
     void reject(int i, hipjpegStatus_t st)
     {
@@ -134,11 +139,19 @@ public:
     uint64_t stream_bytes() const { return stream_bytes_total_; }
     void flavour_units(int32_t* plane_units, int32_t luma_units[kNumLumaLayouts]) const
     {
-        *plane_units = (int32_t)plane_units_.size();
+        *plane_units = (int32_t)(plane_units_.size() + fused_plane_units_.size());
         for (int e = 0; e < kNumLumaLayouts; e++) {
             luma_units[e] = 0;
             for (const auto& v : luma_units_[e]) luma_units[e] += (int32_t)v.size();
+            for (const auto& v : fused_luma_units_[e]) luma_units[e] += (int32_t)v.size();
         }
+    }
+    int fused_units() const  // work units of the FUSED kernel builds (blocks decoded inside the pixel kernels) in the current batch
+    {
+        size_t n = fused_plane_units_.size();
+        for (int e = 0; e < kNumLumaLayouts; e++)
+            for (const auto& v : fused_luma_units_[e]) n += v.size();
+        return (int)n;
     }
 
     int size() const { return (int)images_.size(); }
@@ -156,6 +169,17 @@ private:
     std::vector<WorkUnit> plane_units_, luma_units_[kNumLumaLayouts][kNumLumaVariants], generic_units_, cmyk_units_;  // luma: [layout of K2][sampling]
     size_t desc_offset_ = 0, units_offset_ = 0, coef_offset_ = 0, staging_bytes_ = 0, plane_bytes_ = 0;
     size_t unit_off_plane_ = 0, unit_off_luma_[kNumLumaLayouts][kNumLumaVariants] = {{0}}, unit_off_generic_ = 0, unit_off_cmyk_ = 0;
+    // Images of the GPU entropy stage (baseline): their K1 / K2 units go to the FUSED kernel builds, which Huffman-decode the blocks
+    // themselves (decode_kernels.hip) -- same unit geometry.  host_taken_: such images the host entropy decoder took over in resolve()
+    // (damaged / periodic streams): their coefficients then lie in HBM and the plain builds run for them (launch_taken_pixels).
+    std::vector<WorkUnit> fused_plane_units_, fused_luma_units_[kNumLumaLayouts][kNumLumaVariants];
+    size_t unit_off_fused_plane_ = 0, unit_off_fused_luma_[kNumLumaLayouts][kNumLumaVariants] = {{0}};
+    bool fused_ = false;
+    uint64_t gpu_entropy_min_pixels_ = 0;
+    std::vector<int> host_taken_;
+    void* taken_units_dev_ = nullptr;
+    size_t taken_units_cap_ = 0;
+    int launch_taken_pixels(void* stream, int which);
     uint64_t coef_bytes_ = 0, output_bytes_ = 0;
     bool finalized_ = false;
     // ---- GPU entropy stage
@@ -214,6 +238,5 @@ private:
 
 // status helpers
 hipjpegStatus_t status_from_parse(ParseStatus s);
-hipjpegChromaSubsampling_t classify_subsampling(const FrameInfo& f);
 
 }  // namespace hipjpeg

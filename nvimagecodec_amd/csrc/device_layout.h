@@ -56,6 +56,7 @@ struct alignas(16) DecodeImage {
     uint32_t width, height;
     uint32_t ncomp, hmax, vmax, color_model;  // color_model: hipjpeg::ColorModel
     uint32_t out_format, flags;
+    uint32_t huff_index, pad1[3];  // GPU entropy stage: index of the image's HuffImage (the FUSED kernels decode from it)
 };
 
 // One workgroup's worth of work: 256 consecutive blocks (raster order) of one component of one image.

@@ -35,8 +35,10 @@ int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages,
 // MCUs each).
 // group_sums: four int32 per block unit -- the sums of the DC differences of its MCUs, per component (what the DC pass needs
 // from the groups in front of a group).
+// dc_only: the pixel kernels decode the blocks themselves (decode_kernels.hip FUSED builds); only the DC differences are read here.
 int launch_huff_write(HuffImage* images, const HuffUnit* sync_units, int nsync_units, const HuffUnit* block_units, int nblock_units,
-                      const unsigned long long* states, const uint32_t* first_block, int32_t* group_sums, unsigned pool_bytes, void* stream);
+                      const unsigned long long* states, const uint32_t* first_block, int32_t* group_sums, unsigned pool_bytes, void* stream,
+                      bool dc_only = false);
 // DC differences -> DC planes.  Images without restart intervals: one workgroup per block unit (its base = the sums of the
 // units in front of it); images with restart intervals: one workgroup per (image, component) in rst_units.
 int launch_huff_dc(const HuffImage* images, const HuffUnit* rst_units, int nrst_units, const HuffUnit* block_units, int nblock_units,

@@ -1081,6 +1081,67 @@ __global__ __launch_bounds__(kBThreads) void huff_blocks_kernel(HuffImage* __res
     if (t < 4) group_sums[(size_t)blockIdx.x * 4 + t] = sh.dc_sum[t];
 }
 
+// ---- fused decode (round 3): the DC differences alone ------------------------------------------------------------------------
+// When the pixel kernels decode the coefficient blocks themselves (decode_kernels.hip, FUSED builds: Huffman decode into the LDS
+// slots the IDCT reads, no coefficient ever reaches HBM), the block pass above is not launched.  What remains of it is this: one
+// lane per block reads the block's FIRST symbol -- its DC difference -- at the recorded start position, so that the DC pass can
+// integrate the predictors before the pixel kernels run.  Table lookups go to memory through the vector cache (one or two per
+// block; staging the tables in LDS would cost more than it saves).  Same work units and group sums as the block pass; also the
+// restart-interval check of the block pass (an interval's first block starts exactly at its boundary).
+__global__ __launch_bounds__(kThreads) void huff_dcdiff_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
+                                                              int32_t* __restrict__ group_sums)
+{
+    __shared__ int32_t s_sum[4];
+    __shared__ uint32_t s_tdc[10], s_comp[10];
+    const HuffUnit u = units[blockIdx.x];  // first = first MCU of the workgroup's kHuffMcusPerWg MCUs
+    HuffImage& im = images[u.image];
+    const HuffGeom geom = make_geom(im);
+    const uint32_t bpm = geom.blocks_per_mcu;
+    const uint32_t nblocks = min(im.total_blocks, im.decoded_blocks);
+    const uint32_t b_first = u.first * bpm;
+    const int t = threadIdx.x;
+    if (t < 4) s_sum[t] = 0;
+    if (t >= 32 && t < 42) {
+        s_tdc[t - 32] = im.k[t - 32].tdc;
+        s_comp[t - 32] = im.k[t - 32].comp & 3;
+    }
+    __syncthreads();
+    if (b_first < nblocks) {
+        const uint32_t mcus = min((uint32_t)kHuffMcusPerWg, geom.mcus_x * geom.mcus_y - u.first);
+        const uint32_t items = mcus * bpm;
+        const HJ_GLOBAL uint32_t* g = (const HJ_GLOBAL uint32_t*)im.stream;
+        const HJ_GLOBAL uint16_t* pool = (const HJ_GLOBAL uint16_t*)im.pool;
+        const uint32_t gwords = im.stream_words;
+        uint32_t err = 0;
+        for (uint32_t item = t; item < items; item += kThreads) {
+            const uint32_t b = b_first + item;
+            if (b >= nblocks) break;
+            const uint32_t k = item % bpm;
+            const uint32_t bpos = im.block_pos[b];
+            if (geom.interval_blocks != 0 && k == 0 && b != 0 && b % geom.interval_blocks == 0 &&
+                bpos != load_boundary(geom.boundaries, geom.num_boundaries, b / geom.interval_blocks - 1))
+                err = 1;
+            const uint32_t i = bpos >> 5, sft = bpos & 31;
+            const uint32_t w0 = i < gwords ? __builtin_bswap32(g[i]) : ~0u, w1 = i + 1 < gwords ? __builtin_bswap32(g[i + 1]) : ~0u;
+            const uint32_t w = sft ? (w0 << sft) | (w1 >> (32 - sft)) : w0;
+            uint32_t e = pool[s_tdc[k] + (w >> (32 - kHuffFastBits))];
+            if ((e >> 9) == kZadvLong) e = pool[((e & 0x1FFu) << 6) + ((w >> (32 - kHuffFastBits - kHuffSubBits)) & ((1u << kHuffSubBits) - 1))];
+            const uint32_t total = e & 31u, nb_raw = (e >> 5) & 15u;
+            const bool bad = nb_raw >= total;
+            const uint32_t nb = bad ? 0u : nb_raw;
+            const uint32_t v = nb ? (w << (total - nb)) >> (32 - nb) : 0u;
+            const uint32_t m = (1u << nb) - 1u;
+            const int dc = (v << 1) <= m ? (int)v - (int)m : (int)v;
+            if (bad || bpos + total > geom.total_bits) err = 1;
+            ((HJ_GLOBAL int16_t*)geom.dc_diff)[b] = (int16_t)dc;
+            atomicAdd(&s_sum[s_comp[k]], (int)(int16_t)dc);
+        }
+        if (err) im.status = 1;  // benign race: every writer stores the same value
+    }
+    __syncthreads();
+    if (t < 4) group_sums[(size_t)blockIdx.x * 4 + t] = s_sum[t];
+}
+
 // ---- DC differences -> DC values ------------------------------------------------------------------------------------------
 // Images without restart intervals: one workgroup per block-pass unit (kHuffMcusPerWg MCUs).  The predictor value a group
 // starts from is the sum of the group sums in front of it (the block pass left them: a few dozen numbers), so every group
@@ -1275,11 +1336,17 @@ int launch_huff_scan(HuffImage* images, const uint32_t* image_list, int nimages,
 }
 
 int launch_huff_write(HuffImage* images, const HuffUnit* sync_units, int nsync_units, const HuffUnit* block_units, int nblock_units,
-                      const unsigned long long* states, const uint32_t* first_block, int32_t* group_sums, unsigned pool_bytes, void* stream)
+                      const unsigned long long* states, const uint32_t* first_block, int32_t* group_sums, unsigned pool_bytes, void* stream,
+                      bool dc_only)
 {
     if (nsync_units <= 0) return 0;
     hipLaunchKernelGGL(huff_pos_kernel, dim3(nsync_units), dim3(kSyncThreads), pool_bytes, (hipStream_t)stream, images, sync_units, states, first_block);
-    if (nblock_units > 0) hipLaunchKernelGGL(huff_blocks_kernel, dim3(nblock_units), dim3(kBThreads), pool_bytes, (hipStream_t)stream, images, block_units, group_sums);
+    if (nblock_units > 0) {
+        if (dc_only)
+            hipLaunchKernelGGL(huff_dcdiff_kernel, dim3(nblock_units), dim3(kThreads), 0, (hipStream_t)stream, images, block_units, group_sums);
+        else
+            hipLaunchKernelGGL(huff_blocks_kernel, dim3(nblock_units), dim3(kBThreads), pool_bytes, (hipStream_t)stream, images, block_units, group_sums);
+    }
     return (int)hipGetLastError();
 }
 

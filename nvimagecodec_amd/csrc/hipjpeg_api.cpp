@@ -101,9 +101,22 @@ const char* hipjpegStatusString(hipjpegStatus_t s)
 
 int hipjpegVersion(void) { return 200; }
 
+// The hipjpegTest* entry points exist for the test suite (fault injection, counters the tests assert on).  They answer only in a
+// process that was started with HIPJPEG_ENABLE_TEST_HOOKS=1 (read once); anywhere else they refuse -- no caller of a production process can
+// arm a throw inside the library.  tests/conftest.py sets the variable; bench.py and the tools do not need the hooks.
+static bool test_hooks_enabled()
+{
+    static const bool on = [] {
+        const char* e = getenv("HIPJPEG_ENABLE_TEST_HOOKS");
+        return e != nullptr && e[0] == '1';
+    }();
+    return on;
+}
+
 hipjpegStatus_t hipjpegTestSetFault(const char* site, int countdown)
 {
     return guarded([&]() -> hipjpegStatus_t {
+        if (!test_hooks_enabled()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
         set_fault(site, countdown);
         return HIPJPEG_STATUS_SUCCESS;
     });
@@ -380,6 +393,16 @@ hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* 
     });
 }
 
+hipjpegStatus_t hipjpegSetHybridHuffmanThreshold(hipjpegHandle_t handle, uint64_t pixels)
+{
+    return guarded([&]() -> hipjpegStatus_t {
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    for (auto& b : handle->batches)
+        if (b) b->set_gpu_entropy_threshold(pixels);
+    return HIPJPEG_STATUS_SUCCESS;
+    });
+}
+
 hipjpegStatus_t hipjpegSetPipelineDepth(hipjpegHandle_t handle, int depth)
 {
     return guarded([&]() -> hipjpegStatus_t {
@@ -436,6 +459,7 @@ hipjpegStatus_t hipjpegDecodeBatchEntropyStats(hipjpegHandle_t handle, int32_t* 
 int32_t hipjpegTestScanChunkDrops(const uint8_t* data, size_t length, int scan_index, uint32_t* drops, int32_t capacity)
 {
     int32_t result = -1;
+    if (!test_hooks_enabled()) return result;
     (void)guarded([&]() -> hipjpegStatus_t {
         hipjpeg::FrameInfo f;
         if (hipjpeg::parse_jpeg(data, length, &f) != hipjpeg::kParseOk || scan_index < 0 || scan_index >= (int)f.scans.size()) return HIPJPEG_STATUS_BAD_JPEG;
@@ -449,17 +473,19 @@ int32_t hipjpegTestScanChunkDrops(const uint8_t* data, size_t length, int scan_i
 
 int32_t hipjpegTestHostFallbacks(hipjpegHandle_t handle)
 {
-    return handle ? handle->cur().host_fallback_images() : -1;
+    return handle && test_hooks_enabled() ? handle->cur().host_fallback_images() : -1;
 }
 
 hipjpegStatus_t hipjpegTestKernelFlavours(hipjpegHandle_t handle, int32_t plane_units[1], int32_t luma_units[3])
 {
     return guarded([&]() -> hipjpegStatus_t {
-    if (!handle || !plane_units || !luma_units) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if (!handle || !plane_units || !luma_units || !test_hooks_enabled()) return HIPJPEG_STATUS_INVALID_ARGUMENT;
     handle->cur().flavour_units(plane_units, luma_units);
     return HIPJPEG_STATUS_SUCCESS;
     });
 }
+
+int32_t hipjpegTestFusedUnits(hipjpegHandle_t handle) { return handle && test_hooks_enabled() ? handle->cur().fused_units() : -1; }
 
 // ---------------------------------------------------------------- encode
 hipjpegStatus_t hipjpegEncodeBatchDevice(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,

@@ -32,7 +32,7 @@
 #include <vector>
 
 #include "../../include/nvimgcodec_abi.h"
-#include "decoder_core.h"
+#include "../../include/hipjpeg.h"
 #include "jpeg_syntax.h"
 
 using namespace hipjpeg;
@@ -375,6 +375,7 @@ struct nvimgcodecInstance {
     std::vector<std::unique_ptr<nvimgcodecExtension>> owned_extensions;
     std::unique_ptr<nvimgcodecDebugMessenger> default_messenger;
     nvimgcodecFrameworkDesc_t fw{};
+    std::string builtin_module;  // path of the extension library loaded from this library's own directory
 
     static nvimgcodecStatus_t log(void* inst, const nvimgcodecDebugMessageSeverity_t sev, const nvimgcodecDebugMessageCategory_t cat,
                                   const nvimgcodecDebugMessageData_t* data)
@@ -528,7 +529,11 @@ struct nvimgcodecImage {
 // Samples reported more than once (the reference's promise throws logic_error on a double set, src/processing_results.cpp:
 // 104-115; here the first result wins and the event is counted so that tests can assert it never happens).
 static std::atomic<int> g_double_reports{0};
-extern "C" __attribute__((visibility("default"))) int hipjpegTestDoubleReports(void) { return g_double_reports.load(); }
+extern "C" __attribute__((visibility("default"))) int hipjpegTestDoubleReports(void)
+{
+    const char* e = getenv("HIPJPEG_ENABLE_TEST_HOOKS");  // like the extension's hipjpegTest* entry points: test processes only
+    return e && e[0] == '1' ? g_double_reports.load() : -1;
+}
 
 struct nvimgcodecFuture {
     explicit nvimgcodecFuture(size_t n) : status(n, NVIMGCODEC_PROCESSING_STATUS_UNKNOWN), remaining((int)n) {}
@@ -962,12 +967,29 @@ nvimgcodecStatus_t nvimgcodecInstanceCreate(nvimgcodecInstance_t* instance, cons
         }
     }
     if (ci->load_extension_modules) {
-        // 1) the extension that lives in this very library
-        nvimgcodecExtensionDesc_t ed;
-        memset(&ed, 0, sizeof ed);
-        ed.struct_type = NVIMGCODEC_STRUCTURE_TYPE_EXTENSION_DESC;
-        ed.struct_size = sizeof ed;
-        if (nvimgcodecExtensionModuleEntry(&ed) == NVIMGCODEC_STATUS_SUCCESS) (void)nvimgcodecExtensionCreate(inst, nullptr, &ed);
+        // 1) the extension that ships with this harness: libhipjpeg_ext.so in the directory this library was loaded from, opened like
+        //    any other extension module (RTLD_LOCAL: the plugin's symbols stay out of the process's global scope, as in the reference's
+        //    loader, src/library_loader.h:33)
+        {
+            Dl_info self;
+            if (dladdr(reinterpret_cast<const void*>(&nvimgcodecInstanceCreate), &self) && self.dli_fname) {
+                std::string path(self.dli_fname);
+                const size_t slash = path.rfind('/');
+                path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libhipjpeg_ext.so";
+                if (void* dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL)) {
+                    auto entry = reinterpret_cast<nvimgcodecExtensionModuleEntryFunc_t>(dlsym(dl, "nvimgcodecExtensionModuleEntry"));
+                    nvimgcodecExtensionDesc_t ed;
+                    memset(&ed, 0, sizeof ed);
+                    ed.struct_type = NVIMGCODEC_STRUCTURE_TYPE_EXTENSION_DESC;
+                    ed.struct_size = sizeof ed;
+                    nvimgcodecExtension_t xh = nullptr;
+                    if (entry && entry(&ed) == NVIMGCODEC_STATUS_SUCCESS && nvimgcodecExtensionCreate(inst, &xh, &ed) == NVIMGCODEC_STATUS_SUCCESS)
+                        inst->builtin_module = path;
+                    else
+                        dlclose(dl);
+                }
+            }
+        }
         // 2) every regular file of the extension directories (reference src/plugin_framework.cpp:107-117,281-351)
         std::string paths = ci->extension_modules_path ? ci->extension_modules_path : "";
         if (paths.empty())
@@ -988,7 +1010,10 @@ nvimgcodecStatus_t nvimgcodecInstanceCreate(nvimgcodecInstance_t* instance, cons
                 void* dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
                 if (!dl) continue;
                 auto entry = reinterpret_cast<nvimgcodecExtensionModuleEntryFunc_t>(dlsym(dl, "nvimgcodecExtensionModuleEntry"));
-                if (!entry || entry == &nvimgcodecExtensionModuleEntry) {
+                char real_a[4096], real_b[4096];
+                const bool same_as_builtin = !inst->builtin_module.empty() && realpath(path.c_str(), real_a) && realpath(inst->builtin_module.c_str(), real_b) &&
+                                             strcmp(real_a, real_b) == 0;
+                if (!entry || same_as_builtin) {
                     dlclose(dl);
                     continue;
                 }

@@ -1,6 +1,8 @@
 // jpeg_syntax.cpp -- see jpeg_syntax.h
 #include "jpeg_syntax.h"
 
+#include <algorithm>
+
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -354,5 +356,28 @@ ParseStatus parse_jpeg(const uint8_t* data, size_t size, FrameInfo* f, bool head
     if (!headers_only && f->scans.empty()) return kParseBadStream;
     return kParseOk;
 }
+
+// The sampling layout as the API names it (the reference's parser does the same from the SOF factors, src/parsers/jpeg.cpp:262-330).
+hipjpegChromaSubsampling_t classify_subsampling(const FrameInfo& f)
+{
+    if (f.ncomp == 1) return HIPJPEG_CSS_GRAY;
+    if (f.ncomp != 3) return HIPJPEG_CSS_UNKNOWN;
+    int yh = f.comp[0].h, yv = f.comp[0].v, uh = f.comp[1].h, uv = f.comp[1].v, vh = f.comp[2].h, vv = f.comp[2].v;
+    int minh = std::min(yh, std::min(uh, vh)), minv = std::min(yv, std::min(uv, vv));
+    if (minh == 0 || minv == 0) return HIPJPEG_CSS_UNKNOWN;
+    if (yh % minh || uh % minh || vh % minh || yv % minv || uv % minv || vv % minv) return HIPJPEG_CSS_UNKNOWN;
+    yh /= minh; uh /= minh; vh /= minh;
+    yv /= minv; uv /= minv; vv /= minv;
+    if (uh != vh || uv != vv || uh != 1 || uv != 1) return HIPJPEG_CSS_UNKNOWN;
+    if (yh == 1 && yv == 1) return HIPJPEG_CSS_444;
+    if (yh == 2 && yv == 1) return HIPJPEG_CSS_422;
+    if (yh == 2 && yv == 2) return HIPJPEG_CSS_420;
+    if (yh == 1 && yv == 2) return HIPJPEG_CSS_440;
+    if (yh == 4 && yv == 1) return HIPJPEG_CSS_411;
+    if (yh == 4 && yv == 2) return HIPJPEG_CSS_410;
+    if (yh == 2 && yv == 4) return HIPJPEG_CSS_410V;
+    return HIPJPEG_CSS_UNKNOWN;
+}
+
 
 }  // namespace hipjpeg

@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "../../include/hipjpeg.h"
+
 namespace hipjpeg {
 
 enum class ColorModel : int { Gray = 0, YCbCr = 1, RGB = 2, CMYK = 3, YCCK = 4 };
@@ -75,5 +77,7 @@ struct FrameInfo {
 ParseStatus parse_jpeg(const uint8_t* data, size_t size, FrameInfo* out, bool headers_only = false);
 
 extern const uint8_t kZigzagNatural[64];  // zigzag index -> natural (row-major) position
+
+hipjpegChromaSubsampling_t classify_subsampling(const FrameInfo& f);
 
 }  // namespace hipjpeg

@@ -2,6 +2,7 @@
 #pragma once
 #include <sstream>
 #include <string>
+#include <vector>
 
 #include "../../include/nvimgcodec_abi.h"
 
@@ -36,7 +37,7 @@ inline void log_message(const nvimgcodecFrameworkDesc_t* fw, const char* codec_i
 // "<module>:<key>=<value> ..." option strings; an empty module applies to every plugin
 // (same grammar as extensions/libjpeg_turbo/libjpeg_turbo_decoder.cpp:250-276).
 template <typename F>
-inline void for_each_option(const char* options, const char* module_name, F&& fn)
+inline void for_each_option(const char* options, const char* module_name, F&& fn, std::vector<std::string>* addressed = nullptr)
 {
     std::istringstream iss(options ? options : "");
     std::string token;
@@ -46,6 +47,7 @@ inline void for_each_option(const char* options, const char* module_name, F&& fn
         if (colon == std::string::npos || equal == std::string::npos || colon > equal) continue;
         std::string module = token.substr(0, colon);
         if (!module.empty() && module != module_name) continue;
+        if (addressed && !module.empty()) addressed->push_back(token.substr(colon + 1, equal - colon - 1));  // named this very module
         fn(token.substr(colon + 1, equal - colon - 1), token.substr(equal + 1));
     }
 }

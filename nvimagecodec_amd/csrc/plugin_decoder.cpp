@@ -128,12 +128,15 @@ private:
     MemoryHooks hooks_;
     bool fancy_ = true;  // same default as the reference plugins (nvjpeg_utils.cpp:46, libjpeg_turbo_decoder.cpp:253)
     bool gpu_huffman_ = true;  // entropy-decode eligible streams on the GPU (the reference's GPU_HYBRID backend analogue)
+    uint64_t hybrid_huffman_threshold_ = 0;  // ... those of more than this many pixels (cuda_decoder.cpp:188-209; 0 = all of them)
+    bool fast_idct_ = false;  // asked for JDCT_FASTEST (libjpeg_turbo_decoder.cpp:250-276): not offered here, see canDecode
     bool ok_ = false;
     int device_ = 0;
     static constexpr int kJobPages = 6;  // batches (or pieces of one) in flight: each has its own page (arenas), stream and event; arenas are sized on first use
     std::unique_ptr<Job> jobs_[kJobPages];
     int next_job_ = 0;
     int pipeline_chunks_ = 0;  // option: pieces a large batch is cut into (0 = choose by size, 1 = never cut)
+    std::vector<std::string> unknown_keys_, addressed_keys_;
     // Header parsing of a batch (a marker walk through every file) runs on these threads inside decode(): the framework's
     // executor only takes per-sample tasks that report through imageReady, and the batch layout needs every header first.
     std::unique_ptr<hipjpeg::ForkJoinPool> parse_pool_;
@@ -154,9 +157,20 @@ HipJpegDecoder::HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgc
     for_each_option(options, kDecoderId, [&](const std::string& key, const std::string& value) {
         std::istringstream v(value);
         if (key == "fancy_upsampling") v >> fancy_;
-        if (key == "gpu_huffman") v >> gpu_huffman_;
-        if (key == "pipeline_chunks") v >> pipeline_chunks_;
-    });
+        else if (key == "gpu_huffman") v >> gpu_huffman_;
+        else if (key == "pipeline_chunks") v >> pipeline_chunks_;
+        else if (key == "hybrid_huffman_threshold") v >> hybrid_huffman_threshold_;
+        else if (key == "fast_idct") v >> fast_idct_;
+        else unknown_keys_.push_back(key);
+    }, &addressed_keys_);
+    // keys addressed to this decoder by name that it does not know: say so (a key without a module name may be meant for another
+    // plugin of the chain and is passed over in silence, as the reference's plugins do)
+    for (const std::string& k : unknown_keys_)
+        if (std::find(addressed_keys_.begin(), addressed_keys_.end(), k) != addressed_keys_.end())
+            HJ_LOG_WARNING(fw_, kDecoderId, "unknown option '" << k << "' ignored (known: fancy_upsampling, gpu_huffman, hybrid_huffman_threshold, pipeline_chunks, fast_idct)");
+    if (fast_idct_)
+        HJ_LOG_WARNING(fw_, kDecoderId, "fast_idct=1: this decoder computes jpeg_idct_islow only (bit-exact with the reference's default); "
+                                        "canDecode hands every sample to the next decoder of the chain");
     {
         int threads = 0;
         if (ep->executor && ep->executor->getNumThreads) threads = ep->executor->getNumThreads(ep->executor->instance);
@@ -184,6 +198,7 @@ HipJpegDecoder::HipJpegDecoder(const nvimgcodecFrameworkDesc_t* fw, const nvimgc
     for (auto& j : jobs_) {
         j.reset(new Job(device_, &hooks_));
         j->owner = this;
+        j->batch.set_gpu_entropy_threshold(hybrid_huffman_threshold_);
         if (hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&j->event, hipEventDisableTiming) != hipSuccess) {
             HJ_LOG_ERROR(fw_, kDecoderId, "could not create a HIP stream on device " << device_);
@@ -261,6 +276,11 @@ void HipJpegDecoder::single_can_decode(nvimgcodecProcessingStatus_t* status, nvi
                                        const nvimgcodecDecodeParams_t* params)
 {
     *status = NVIMGCODEC_PROCESSING_STATUS_SUCCESS;
+    if (fast_idct_) {
+        // JDCT_FASTEST gives other pixels than JDCT_ISLOW; the decoder that implements it (libjpeg_turbo_ext) is next in the chain
+        *status = NVIMGCODEC_PROCESSING_STATUS_BACKEND_UNSUPPORTED;
+        return;
+    }
     nvimgcodecJpegImageInfo_t jpeg_info{NVIMGCODEC_STRUCTURE_TYPE_JPEG_IMAGE_INFO, sizeof(nvimgcodecJpegImageInfo_t), nullptr,
                                         NVIMGCODEC_JPEG_ENCODING_UNKNOWN};
     nvimgcodecImageInfo_t cs_info;

@@ -209,6 +209,16 @@ class BatchDecoder:
             raise N.HipJpegError(st, "hipjpegTestKernelFlavours")
         return list(a), list(b)
 
+    def set_hybrid_huffman_threshold(self, pixels):
+        """gpu_huffman=True then applies to images of more than `pixels` pixels only (nvJPEG's hybrid_huffman_threshold); 0 = all."""
+        st = N.load().hipjpegSetHybridHuffmanThreshold(self._h, ctypes.c_uint64(int(pixels)))
+        if st:
+            raise N.HipJpegError(st, "hipjpegSetHybridHuffmanThreshold")
+
+    def fused_units(self):
+        """Work units of the current batch that went to the FUSED kernel builds (HIPJPEG_FUSED_DECODE=1)."""
+        return int(N.load().hipjpegTestFusedUnits(self._h))
+
     def set_pipeline_depth(self, depth):
         st = N.load().hipjpegSetPipelineDepth(self._h, int(depth))
         if st:

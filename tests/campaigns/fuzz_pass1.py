@@ -5,6 +5,7 @@ libjpeg-turbo restated): EVERY picture against the CPU oracle, bit for bit.
       around the int16 edge of 32,767 and far beyond, 8- and 16-bit quantization tables, blocks whose rows 1..7 are empty.
 usage: python tests/campaigns/fuzz_pass1.py [seed] [rounds]"""
 import os
+os.environ.setdefault("HIPJPEG_ENABLE_TEST_HOOKS", "1")  # kernel_flavours / host_fallbacks are test hooks of the library
 import random
 import sys
 import time

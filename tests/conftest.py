@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# the library's hipjpegTest* entry points (fault injection, counters) answer only in processes started with this (read once at first use;
+# child processes of the tests inherit it)
+os.environ.setdefault("HIPJPEG_ENABLE_TEST_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,6 +1,7 @@
 """Dev tool: flat and striped pictures (periodic bitstreams: a decoder started in the wrong state can stay on a stable wrong trajectory, so
 corrections travel group by group, one launch each) through the GPU entropy stage; prints the number of sync launches."""
 import os
+os.environ.setdefault("HIPJPEG_ENABLE_TEST_HOOKS", "1")
 import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

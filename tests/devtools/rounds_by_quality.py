@@ -1,6 +1,7 @@
 """Dev tool: correction rounds of the GPU entropy stage by quality / sampling (HIPJPEG_DEBUG_TIMING=1 prints them per batch), and whether
 any image was handed to the host decoder."""
 import os
+os.environ.setdefault("HIPJPEG_ENABLE_TEST_HOOKS", "1")
 import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -28,6 +28,36 @@ def main():
             got = hashlib.sha256(np.ascontiguousarray(o.cpu().numpy()).tobytes()).hexdigest()
             assert got == e["rgb_sha256"], (e["name"], gh)
     plane, luma = dec.kernel_flavours()
+    if os.environ.get("HIPJPEG_FUSED_DECODE"):
+        # the pixel kernels decode the blocks themselves: damaged streams are flagged THERE, the host decoder takes them over and the
+        # plain kernels finish them (DecodeBatch::launch_taken_pixels) -- same statuses and pixels as with Huffman decoding on the host
+        small = [j for j in jpegs if len(j) > 3000][:12]
+        outs, st = dec.decode(small, fmt="rgb", gpu_huffman=True)
+        torch.cuda.synchronize()
+        assert dec.fused_units() > 0
+        import random
+        rng = random.Random(7)
+        damaged = []
+        for j in small:
+            b = bytearray(j)
+            sos = bytes(b).rfind(b"\xff\xda")
+            for _ in range(3):
+                k = rng.randrange(sos + 20, len(b) - 2)
+                b[k] ^= 1 << rng.randrange(8)
+                if b[k] == 0xFF:
+                    b[k] = 0xFE
+            damaged.append(bytes(b))
+        batch = [x for pair in zip(small, damaged) for x in pair]
+        outs_h, st_h = dec.decode(batch, fmt="rgb", gpu_huffman=False, check=False)
+        torch.cuda.synchronize()
+        ref = [o.cpu().numpy().copy() for o in outs_h]
+        outs_g, st_g = dec.decode(batch, fmt="rgb", gpu_huffman=True, check=False)
+        torch.cuda.synchronize()
+        assert list(st_g) == list(st_h), (list(st_g), list(st_h))
+        for i, (a, b) in enumerate(zip(outs_g, ref)):
+            if st_h[i] == 0:
+                assert np.array_equal(a.cpu().numpy(), b), i
+        print("fused: damaged neighbours ok,", sum(1 for s in st_h if s), "refused,", dec.host_fallbacks(), "taken over by the host decoder")
     print("goldens ok", len(jpegs), "flavours", plane, luma)
 
 

@@ -18,12 +18,29 @@ def _declared_functions(header):
     return {n for n in names if not n.endswith("_t") and not n.endswith("Func_t") and n != "hipjpegHandle"}
 
 
-def test_library_exports_every_declared_symbol():
-    lib = _native.load()
-    declared = _declared_functions("hipjpeg.h") | _declared_functions("nvimgcodec_abi.h")
-    assert "nvimgcodecExtensionModuleEntry" in declared and "hipjpegDecodeBatch" in declared
-    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
-    assert not missing, f"declared in include/ but not exported: {missing}"
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def test_libraries_export_every_declared_symbol_and_nothing_of_each_others():
+    """The extension module (what a real nvImageCodec loads) exports nvimgcodecExtensionModuleEntry + the hipjpeg* C-ABI and NO other
+    nvimgcodec* name -- loaded next to a real libnvimgcodec it must not interpose the application API.  The application-side
+    API of the test harness lives in libhipjpeg_host.so."""
+    ext, host = _exported(_native.LIB_PATH), _exported(_native.HOST_LIB_PATH)
+    hip_decl, nv_decl = _declared_functions("hipjpeg.h"), _declared_functions("nvimgcodec_abi.h")
+    assert "nvimgcodecExtensionModuleEntry" in nv_decl and "hipjpegDecodeBatch" in hip_decl
+    harness_only = {"hipjpegTestDoubleReports"}  # counted by the harness's future objects
+    missing = [n for n in sorted(hip_decl - harness_only) if n not in ext]
+    assert not missing, f"declared in include/hipjpeg.h but not exported by the extension: {missing}"
+    assert [n for n in ext if re.match(r"nvimgcodec[A-Z]", n)] == ["nvimgcodecExtensionModuleEntry"]
+    missing = [n for n in sorted(nv_decl - {"nvimgcodecExtensionModuleEntry"}) if n not in host]
+    assert not missing, f"declared in include/nvimgcodec_abi.h but not exported by the host harness: {missing}"
+    assert "nvimgcodecExtensionModuleEntry" not in host and harness_only <= host
+    assert not [n for n in host if n.startswith("hipjpeg") and n not in harness_only]
+    _native.load()
+    _native.load_host()
 
 
 def test_ctypes_mirror_matches_reference_layout():

@@ -133,7 +133,7 @@ def _cases():
 
 
 def test_an_undersized_image_descriptor_fails_alone(torch_mod):
-    lib = A.bind(N.load())
+    lib = A.bind(N.load_host())
     inst, dec = _setup(lib)
     cases = _cases()
     st, outs = _decode_batch(torch_mod, lib, inst, dec, cases, shrink=2)
@@ -151,16 +151,16 @@ def test_an_exception_inside_the_library_resolves_every_future(torch_mod, site, 
     """Through nvimgcodecDecoderDecode: the `countdown`-th passage of `site` throws.  Every future resolves (nothing hangs,
     nothing is reported twice -- the host harness throws on a double set like the reference, src/processing_results.cpp:109),
     samples are SUCCESS with correct pixels or a failure status, and the NEXT batch decodes completely."""
-    lib = A.bind(N.load())
+    lib = A.bind(N.load_host())
     inst, dec = _setup(lib)
     cases = _cases()
     st0, _ = _decode_batch(torch_mod, lib, inst, dec, cases)   # warm: pages allocated
     assert all(s == A.PS_SUCCESS for s in st0)
-    assert lib.hipjpegTestSetFault(site.encode(), countdown) == 0
+    assert N.load().hipjpegTestSetFault(site.encode(), countdown) == 0
     try:
         st, outs = _decode_batch(torch_mod, lib, inst, dec, cases)
     finally:
-        lib.hipjpegTestSetFault(None, 0)
+        N.load().hipjpegTestSetFault(None, 0)
     failed = [i for i, s in enumerate(st) if s != A.PS_SUCCESS]
     if site in ("marshal", "entropy_stage"):
         assert len(failed) <= 1        # one sample's trouble stays that sample's

@@ -242,3 +242,28 @@ def test_periodic_streams_are_handed_to_the_host_decoder_not_walked_group_by_gro
     assert s["gpu_entropy_images"] == 4 and s["sync_launches"] <= 6
     assert 1 <= dec.host_fallbacks() <= 2      # the striped pictures; never the flat one or the photograph
     assert elapsed < 0.1, elapsed              # generous: ~25 ms with the host decoder taking the stripes
+
+
+def test_hybrid_huffman_threshold_splits_a_batch_by_area(dec):
+    """hipjpegSetHybridHuffmanThreshold / plugin option hybrid_huffman_threshold (reference extensions/nvjpeg/cuda_decoder.cpp:188-209,
+    512-521): with the GPU entropy stage on, only images of MORE than the threshold's pixels take it, the rest the host decoder -- same
+    pixels either way."""
+    small = oracle.encode(synth_image(64, 48, seed=5), "420", 90)
+    large = oracle.encode(synth_image(320, 240, seed=6), "420", 90)
+    batch = [small, large, small, large, large]
+    try:
+        dec.set_hybrid_huffman_threshold(64 * 48)  # "more than": the 64 x 48 pictures stay on the host
+        outs, st = dec.decode(batch, gpu_huffman=True)
+        _sync()
+        assert dec.stats()["gpu_entropy_images"] == 3
+        for j, o in zip(batch, outs):
+            assert np.array_equal(o.cpu().numpy(), oracle.decode(j))
+        dec.set_hybrid_huffman_threshold(10 ** 9)
+        outs, st = dec.decode(batch, gpu_huffman=True)
+        _sync()
+        assert dec.stats()["gpu_entropy_images"] == 0
+    finally:
+        dec.set_hybrid_huffman_threshold(0)
+    outs, st = dec.decode(batch, gpu_huffman=True)
+    _sync()
+    assert dec.stats()["gpu_entropy_images"] == 5

@@ -92,24 +92,27 @@ def _c_api_decode(lib, inst, dec, jpeg, h, w, fmt, planes, channels, buffer_ptr,
     return st[0]
 
 
-def _setup(lib, extra_plugins=(), device_id=0, backends=None, allocators=None):
+def _setup(lib, extra_plugins=(), device_id=0, backends=None, allocators=None, options=b"", messenger=None):
     ci = A.init(A.InstanceCreateInfo, A.ST_INSTANCE_CREATE_INFO, load_builtin_modules=1, load_extension_modules=1)
     inst = C.c_void_p()
     assert lib.nvimgcodecInstanceCreate(C.byref(inst), C.byref(ci)) == 0
+    if messenger is not None:
+        dm = C.c_void_p()
+        assert lib.nvimgcodecDebugMessengerCreate(inst, C.byref(dm), C.byref(messenger)) == 0
     for p in extra_plugins:
         assert lib.nvimgcodecExtensionCreate(inst, None, C.byref(p.ext_desc)) == 0
     ep = A.init(A.ExecutionParams, A.ST_EXECUTION_PARAMS, device_id=device_id, max_num_cpu_threads=2)
     if allocators:
         ep.device_allocator, ep.pinned_allocator = C.pointer(allocators[0]), C.pointer(allocators[1])
     dec = C.c_void_p()
-    assert lib.nvimgcodecDecoderCreate(inst, C.byref(dec), C.byref(ep), b"") == 0
+    assert lib.nvimgcodecDecoderCreate(inst, C.byref(dec), C.byref(ep), options) == 0
     return inst, dec
 
 
 def test_host_output_buffer_is_bounced(torch_mod):
     """A host output buffer with a GPU backend: the framework decodes into a device bounce buffer and copies back
     (reference src/work.h:144-190)."""
-    lib = A.bind(_native.load())
+    lib = A.bind(_native.load_host())
     inst, dec = _setup(lib)
     jpeg, rgb = _case("s50x37_420_base_q90")
     buf = np.zeros((37, 50, 3), dtype=np.uint8)
@@ -122,7 +125,7 @@ def test_host_output_buffer_is_bounced(torch_mod):
 
 def test_planar_bgr_and_user_stream(torch_mod):
     torch = torch_mod
-    lib = A.bind(_native.load())
+    lib = A.bind(_native.load_host())
     inst, dec = _setup(lib)
     jpeg, rgb = _case("r130x70_420_base_rst7")
     side = torch.cuda.Stream()
@@ -170,7 +173,7 @@ def test_region_of_interest_on_the_device_and_fallback_for_what_is_not_supported
     """A region inside the image is decoded by the HIP decoder (the pixels of the full decode, like the reference CPU path's
     crop, extensions/libjpeg_turbo/jpeg_mem.cpp:206-240).  A region that leaves the image is outside it: canDecode says so
     and the chain moves on, exactly like nvjpeg -> libjpeg_turbo in the reference."""
-    lib = A.bind(_native.load())
+    lib = A.bind(_native.load_host())
     cpu = FakeDecoderPlugin("cpu_fallback", priority=A.PRIORITY_NORMAL, fill=0x42)
     inst, dec = _setup(lib, extra_plugins=[cpu])
     jpeg, rgb = _case("s64x48_420_base_q90")
@@ -210,7 +213,7 @@ def test_exif_orientation_is_applied_like_the_reference_python_decoder(torch_mod
 
 def test_cpu_only_device_is_refused_and_custom_allocators_are_used(torch_mod):
     torch = torch_mod
-    lib = A.bind(_native.load())
+    lib = A.bind(_native.load_host())
     hip = C.CDLL("libamdhip64.so")
     hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
@@ -423,7 +426,7 @@ def test_several_decode_calls_outstanding(torch_mod):
     before the first is waited for.  With an earlier call in flight the plugin sends a batch out whole instead of in pieces (six
     pages); five calls of 120 mixed goldens each outstanding at once -- every sample reports exactly once, every picture bit-exact,
     a corrupt file in one batch fails alone."""
-    lib = _native.load()
+    lib = A.bind(_native.load_host())
     inst, dec = _setup(lib)
     before = lib.hipjpegTestDoubleReports()
     entries = [e for e in _M["decode"] if e["pixels"]][:30]
@@ -476,3 +479,43 @@ def test_several_decode_calls_outstanding(torch_mod):
     assert lib.hipjpegTestDoubleReports() == before
     lib.nvimgcodecDecoderDestroy(dec)
     lib.nvimgcodecInstanceDestroy(inst)
+
+
+def test_decoder_options_like_the_reference_plugins(torch_mod):
+    """Option strings use the reference's grammar (extensions/libjpeg_turbo/libjpeg_turbo_decoder.cpp:250-276).  A key addressed to this
+    decoder BY NAME that it does not know is reported through the framework's log (it was ignored in silence); `fast_idct=1`
+    -- JDCT_FASTEST, other pixels than ISLOW -- is not offered: canDecode passes every sample on to the next decoder of the chain, the way
+    nvjpeg -> libjpeg_turbo hand over; `hybrid_huffman_threshold` is accepted (extensions/nvjpeg/cuda_decoder.cpp:188-209)."""
+    lib = A.bind(_native.load_host())
+    messages = []
+
+    def on_message(severity, category, data, user):
+        messages.append((severity, data.contents.message.decode(errors="replace") if data.contents.message else ""))
+        return 0
+
+    cb = A.DebugCallback(on_message)
+    messenger = A.init(A.DebugMessengerDesc, A.ST_DEBUG_MESSENGER_DESC, message_severity=0xFFFF, message_category=0xFFFF, user_callback=cb)
+    jpeg, rgb = _case("s50x37_420_base_q90")
+
+    # unknown key with this decoder's name: a warning; without a name: silence; known keys: accepted
+    inst, dec = _setup(lib, options=b"hipjpeg_decoder:bogus=1 :other_plugins_key=3 hipjpeg_decoder:hybrid_huffman_threshold=1000000 :fancy_upsampling=1",
+                       messenger=messenger)
+    buf = np.zeros((37, 50, 3), dtype=np.uint8)
+    assert _c_api_decode(lib, inst, dec, jpeg, 37, 50, A.SAMPLEFORMAT_I_RGB, 1, 3, buf.ctypes.data, 150, A.BUFFER_KIND_STRIDED_HOST) == A.PS_SUCCESS
+    assert np.array_equal(buf, rgb)
+    assert any("unknown option 'bogus'" in m for _, m in messages), messages
+    assert not any("other_plugins_key" in m for _, m in messages)
+    lib.nvimgcodecDecoderDestroy(dec)
+    lib.nvimgcodecInstanceDestroy(inst)
+
+    # fast_idct: the HIP decoder steps aside, the next decoder of the chain gets the sample
+    messages.clear()
+    cpu = FakeDecoderPlugin("cpu_fallback", priority=A.PRIORITY_NORMAL, fill=0x42)
+    inst, dec = _setup(lib, extra_plugins=[cpu], options=b":fast_idct=1", messenger=messenger)
+    buf = np.zeros((37, 50, 3), dtype=np.uint8)
+    assert _c_api_decode(lib, inst, dec, jpeg, 37, 50, A.SAMPLEFORMAT_I_RGB, 1, 3, buf.ctypes.data, 150, A.BUFFER_KIND_STRIDED_HOST) == A.PS_SUCCESS
+    assert buf.flat[0] == 0x42 and cpu.count("decode") == 1
+    assert any("fast_idct" in m for _, m in messages), messages
+    lib.nvimgcodecDecoderDestroy(dec)
+    lib.nvimgcodecInstanceDestroy(inst)
+    del cb

@@ -22,7 +22,7 @@ with open(os.path.join(GOLDEN, "manifest.json")) as _f:
 
 @pytest.fixture()
 def lib():
-    return A.bind(_native.load())
+    return A.bind(_native.load_host())
 
 
 def make_instance(lib, load_ext=0):

@@ -20,7 +20,7 @@ with open(os.path.join(GOLDEN, "manifest.json")) as _f:
 
 @pytest.fixture()
 def lib():
-    return A.bind(_native.load())
+    return A.bind(_native.load_host())
 
 
 def _jpeg(name):

@@ -1,6 +1,7 @@
 """Dev tool: K1 + K2 on 256 pictures whose interleaved RGB rows are NOT 16-byte aligned (1918 x 1080, tight pitch 5,754 bytes) -- the
 output configuration that went to the generic luma kernel until round 2's unaligned staged stores; ms per batch and the flavour taken."""
 import os
+os.environ.setdefault("HIPJPEG_ENABLE_TEST_HOOKS", "1")  # kernel_flavours / host_fallbacks are test hooks of the library
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

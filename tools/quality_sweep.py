@@ -2,6 +2,7 @@
 qualities -- which pass-1 arithmetic the host gives the batch, ms per stage, images/s.
 usage: python tools/quality_sweep.py [qualities...]"""
 import os
+os.environ.setdefault("HIPJPEG_ENABLE_TEST_HOOKS", "1")  # kernel_flavours / host_fallbacks are test hooks of the library
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
