@@ -48,10 +48,9 @@ STEADY_PREWARM_STEPS = 40
 REHEARSAL = os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1"
 REDUCE_DEVICE = "cpu" if REHEARSAL else "cuda"  # where the max-over-ranks tensor lives (gloo reduces host tensors)
 PROGRESSIVE_DEPTH = 6             # batches in flight for configs[4] (hipjpegSetPipelineDepth): a progressive batch is one wave per scan
-# every batch in flight runs its entropy stage on a stream of its own; the HIP runtime multiplexes streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue run one after the other.  Read by
-# the runtime when it starts, so it is set before anything touches the GPU (a value already in the environment wins).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+# (every batch in flight runs its entropy stage on a stream of its own; the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES
+# hardware queues, default 4.  The LIBRARY asks for twelve when it is loaded -- csrc/hipjpeg_api.cpp hipjpeg_runtime_defaults -- which
+# works as long as it is loaded before the process's first HIP call: main() loads it before touching torch.cuda.)
 
 
 def make_inputs():
@@ -445,6 +444,9 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     distributed = world > 1
 
+    # the library first: it must be in the process before the first HIP call (it asks the runtime for more hardware queues, see the top)
+    from nvimagecodec_amd import _native
+    _native.load()
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
@@ -551,7 +553,28 @@ def main():
         dec.wait()
         torch.cuda.synchronize()
         t_e2e_gpu = max_over_ranks((time.perf_counter() - t0) / pipe_batches, dist, REDUCE_DEVICE)
-        del ring
+        # (a') the same loop with the files in page-locked memory: the copy engine reads each scan from the caller's buffer, the
+        # staging copy on the host is gone (zero-copy input; one pass over host DRAM per byte instead of three)
+        pinned = {id(s): torch.frombuffer(bytearray(s), dtype=torch.uint8).pin_memory() for s in sources}
+        jpegs_pinned = [pinned[id(j)] for j in jpegs]
+        for k in range(3):
+            dec.submit(jpegs_pinned, ring[k])
+        for k in range(3):
+            dec.wait()
+        zero_copy_images = dec.stats()["zero_copy_images"]
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(pipe_batches):
+            dec.submit(jpegs_pinned, ring[i % 3])
+            if i > 1:
+                dec.wait()
+        dec.wait()
+        dec.wait()
+        torch.cuda.synchronize()
+        t_e2e_zc = max_over_ranks((time.perf_counter() - t0) / pipe_batches, dist, REDUCE_DEVICE)
+        stream_bytes_per_batch = dec.stats()["stream_bytes"]
+        del ring, jpegs_pinned, pinned
         # (b) the north-star split: Huffman on the host cores, coefficients over PCIe, device stage -- through the same Submit/Wait
         # pipeline, three batches in flight (the host stage of batch k+1 runs while batch k's coefficients cross PCIe and batch k-1's
         # kernels run); every page warmed first; per-iteration times kept so that the line carries the median and the spread
@@ -590,6 +613,14 @@ def main():
             "images_per_s": round(BATCH * world / t_e2e_gpu, 1), "mp_per_s": round(BATCH * world / t_e2e_gpu * WIDTH * HEIGHT / 1e6, 1),
             "includes": "host JPEG bytes -> RGB in HBM: header parse + H2D of the bitstreams + GPU entropy stage + device stage, "
                         "three batches in flight (hipjpegDecodeBatchSubmit/Wait)",
+            "zero_copy_input": {"images_per_s": round(BATCH * world / t_e2e_zc, 1), "zero_copy_images_per_batch": zero_copy_images,
+                                "note": "the same loop with the files in pinned host memory: no staging copy, the copy engine reads the caller's buffers"},
+            # what each rank asks of the host's memory system (eight ranks share it): the bitstream bytes it consumes per
+            # second, times the passes over DRAM per byte -- read + non-temporal store into the staging area + the copy engine's read = 3
+            # with pageable inputs, 1 with pinned inputs
+            "host_bitstream_GBps_per_rank": round(stream_bytes_per_batch / t_e2e_gpu / 1e9, 2),
+            "host_dram_GBps_per_rank": {"pageable_inputs_3_passes": round(3 * stream_bytes_per_batch / t_e2e_gpu / 1e9, 2),
+                                        "pinned_inputs_1_pass": round(stream_bytes_per_batch / t_e2e_zc / 1e9, 2)},
             "cpu_huffman_images_per_s": round(BATCH * world / t_e2e_cpu, 1),
             "cpu_huffman_includes": "the north-star split: Huffman on the host cores + H2D of the coefficients + device stage, through "
                                     "hipjpegDecodeBatchSubmit/Wait with three batches in flight, %d timed batches after every page was warmed" % cpu_batches,

@@ -9,6 +9,13 @@
 //   hipimtrans -i <file|dir> [-o <dir>] [-b batch] [-w warmup batches] [-r repeats] [-q quality] [-s 444|422|420|gray]
 //              [-d device] [-t cpu threads] [-p batches in flight (decode only)] [--skip_encode] [--options "<plugin options>"] [-v]
 //              [--jpeg_encoding baseline_dct|progressive_dct] [--optimized_huffman true|false]
+//              [--devices a,b,...] [--checksums file]
+// --devices a,b,... (decode only): ONE process drives several devices -- a decoder instance per entry (nvimgcodecDecoderCreate with that
+// device_id: the reference keys its worker pools by device in the same way, src/default_executor.cpp:45-58), a host thread and a queue
+// per entry; the input list is partitioned over the queues by greedy longest-processing-time on (MCU-padded coefficient bytes +
+// file bytes), visited in decreasing size like the reference's generic decoder sorts a batch (src/image_generic_decoder.cpp:134-178);
+// no device ever talks to another (no collective).  An id may appear twice: two queues on one card (how the mode is tested on a
+// one-GPU box).  --checksums writes "<file name> <FNV-1a of the decoded RGB bytes>" per input for a checker to compare.
 // -p N > 1 uses what the API offers for throughput: nvimgcodecDecoderDecode returns a future as soon as the batch is scheduled
 // (include/nvimgcodec_abi.h; reference nvimgcodec.h:1455-1459), so the caller submits batch n+1 before it waits for batch n.
 #include <dirent.h>
@@ -17,10 +24,13 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/nvimgcodec_abi.h"
@@ -52,7 +62,8 @@ double wtime()
     } while (0)
 
 struct Params {
-    std::string input, output, options;
+    std::string input, output, options, checksums;
+    std::vector<int> devices;
     int batch = 16, warmup = 1, repeats = 1, quality = 90, device = 0, threads = 0, verbose = 0, in_flight = 1;
     std::string subsampling = "420";
     bool progressive = false, optimized_huffman = false;  // nvimtrans --jpeg_encoding / --optimized_huffman (command_line_params.h:195-207)
@@ -96,6 +107,214 @@ bool read_file(const std::string& path, std::vector<unsigned char>* data)
     return ok;
 }
 
+uint64_t fnv1a(const unsigned char* p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+// ---- one process, several devices: a queue, a host thread and a decoder instance per --devices entry
+struct QueueResult {
+    size_t images = 0, failed = 0;
+    double seconds = 0, bytes_in = 0;
+    std::string error;
+};
+
+void run_device_queue(nvimgcodecInstance_t instance, const Params& p, int device, const std::vector<size_t>& mine,
+                      const std::vector<std::vector<unsigned char>>& files, std::vector<uint64_t>* sums, QueueResult* res)
+{
+    auto fail = [&](const std::string& what) { res->error = what; };
+    if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice");
+    nvimgcodecExecutionParams_t ep{};
+    ep.struct_type = NVIMGCODEC_STRUCTURE_TYPE_EXECUTION_PARAMS;
+    ep.struct_size = sizeof ep;
+    ep.device_id = device;
+    ep.max_num_cpu_threads = p.threads;
+    nvimgcodecDecoder_t decoder = nullptr;
+    if (nvimgcodecDecoderCreate(instance, &decoder, &ep, p.options.c_str()) != NVIMGCODEC_STATUS_SUCCESS) return fail("nvimgcodecDecoderCreate");
+    nvimgcodecDecodeParams_t dparams{NVIMGCODEC_STRUCTURE_TYPE_DECODE_PARAMS, sizeof(nvimgcodecDecodeParams_t), nullptr, 1, 0};
+    struct Slot {
+        std::vector<nvimgcodecCodeStream_t> streams;
+        std::vector<nvimgcodecImage_t> images;
+        std::vector<void*> buffers;
+        std::vector<size_t> bytes, sizes, index;
+        nvimgcodecFuture_t future = nullptr;
+        int n = 0;
+    };
+    std::vector<Slot> slots((size_t)p.in_flight);
+    for (auto& sl : slots) {
+        sl.buffers.assign((size_t)p.batch, nullptr);
+        sl.bytes.assign((size_t)p.batch, 0);
+    }
+    std::vector<unsigned char> host;
+    int head = 0, tail = 0, pending = 0;
+    auto retire = [&]() -> bool {
+        Slot& sl = slots[(size_t)tail];
+        if (nvimgcodecFutureWaitForAll(sl.future) != NVIMGCODEC_STATUS_SUCCESS) return false;
+        size_t count = 0;
+        nvimgcodecFutureGetProcessingStatus(sl.future, nullptr, &count);
+        std::vector<nvimgcodecProcessingStatus_t> st(count);
+        nvimgcodecFutureGetProcessingStatus(sl.future, st.data(), &count);
+        for (size_t i = 0; i < count; i++) {
+            if (st[i] != NVIMGCODEC_PROCESSING_STATUS_SUCCESS) {
+                res->failed++;
+                continue;
+            }
+            if (sums) {  // outside what a throughput run measures: asked for by a checker
+                host.resize(sl.sizes[i]);
+                if (hipMemcpy(host.data(), sl.buffers[i], sl.sizes[i], hipMemcpyDeviceToHost) != hipSuccess) return false;
+                (*sums)[sl.index[i]] = fnv1a(host.data(), host.size());
+            }
+        }
+        nvimgcodecFutureDestroy(sl.future);
+        for (auto cs : sl.streams) nvimgcodecCodeStreamDestroy(cs);
+        for (auto im : sl.images) nvimgcodecImageDestroy(im);
+        res->images += (size_t)sl.n;
+        tail = (tail + 1) % p.in_flight;
+        pending--;
+        return true;
+    };
+    const double t0 = wtime();
+    for (int rep = 0; rep < p.repeats && res->error.empty(); rep++) {
+        for (size_t cursor = 0; cursor < mine.size() && res->error.empty();) {
+            if (pending == p.in_flight && !retire()) return fail("waiting for a batch");
+            Slot& sl = slots[(size_t)head];
+            sl.n = (int)std::min<size_t>((size_t)p.batch, mine.size() - cursor);
+            sl.streams.assign((size_t)sl.n, nullptr);
+            sl.images.assign((size_t)sl.n, nullptr);
+            sl.sizes.assign((size_t)sl.n, 0);
+            sl.index.assign((size_t)sl.n, 0);
+            for (int i = 0; i < sl.n; i++) {
+                const size_t fi = mine[cursor + (size_t)i];
+                const std::vector<unsigned char>& file = files[fi];
+                res->bytes_in += (double)file.size();
+                if (nvimgcodecCodeStreamCreateFromHostMem(instance, &sl.streams[(size_t)i], file.data(), file.size()) != NVIMGCODEC_STATUS_SUCCESS)
+                    return fail("nvimgcodecCodeStreamCreateFromHostMem");
+                nvimgcodecImageInfo_t info{};
+                info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+                info.struct_size = sizeof info;
+                if (nvimgcodecCodeStreamGetImageInfo(sl.streams[(size_t)i], &info) != NVIMGCODEC_STATUS_SUCCESS) return fail("nvimgcodecCodeStreamGetImageInfo");
+                const uint32_t w = info.plane_info[0].width, h = info.plane_info[0].height;
+                info.sample_format = NVIMGCODEC_SAMPLEFORMAT_I_RGB;
+                info.color_spec = NVIMGCODEC_COLORSPEC_SRGB;
+                info.chroma_subsampling = NVIMGCODEC_SAMPLING_NONE;
+                info.num_planes = 1;
+                info.plane_info[0].num_channels = 3;
+                info.plane_info[0].row_stride = (size_t)w * 3;
+                info.plane_info[0].sample_type = NVIMGCODEC_SAMPLE_DATA_TYPE_UINT8;
+                info.buffer_size = (size_t)w * 3 * h;
+                info.buffer_kind = NVIMGCODEC_IMAGE_BUFFER_KIND_STRIDED_DEVICE;
+                if (sl.bytes[(size_t)i] < info.buffer_size) {
+                    if (sl.buffers[(size_t)i]) (void)hipFree(sl.buffers[(size_t)i]);
+                    if (hipMalloc(&sl.buffers[(size_t)i], info.buffer_size) != hipSuccess) return fail("hipMalloc");
+                    sl.bytes[(size_t)i] = info.buffer_size;
+                }
+                info.buffer = sl.buffers[(size_t)i];
+                sl.sizes[(size_t)i] = info.buffer_size;
+                sl.index[(size_t)i] = fi;
+                if (nvimgcodecImageCreate(instance, &sl.images[(size_t)i], &info) != NVIMGCODEC_STATUS_SUCCESS) return fail("nvimgcodecImageCreate");
+            }
+            if (nvimgcodecDecoderDecode(decoder, sl.streams.data(), sl.images.data(), sl.n, &dparams, &sl.future) != NVIMGCODEC_STATUS_SUCCESS)
+                return fail("nvimgcodecDecoderDecode");
+            cursor += (size_t)sl.n;
+            head = (head + 1) % p.in_flight;
+            pending++;
+        }
+    }
+    while (pending)
+        if (!retire()) return fail("waiting for a batch");
+    (void)hipDeviceSynchronize();
+    res->seconds = wtime() - t0;
+    for (auto& sl : slots)
+        for (void* b : sl.buffers)
+            if (b) (void)hipFree(b);
+    nvimgcodecDecoderDestroy(decoder);
+}
+
+int run_multi_device(nvimgcodecInstance_t instance, const Params& p, const std::vector<std::string>& names)
+{
+    std::vector<std::vector<unsigned char>> files(names.size());
+    std::vector<uint64_t> cost(names.size(), 0);
+    for (size_t i = 0; i < names.size(); i++) {
+        if (!read_file(names[i], &files[i])) {
+            fprintf(stderr, "cannot read %s\n", names[i].c_str());
+            return EXIT_FAILURE;
+        }
+        // work estimate from the header alone: MCU-padded coefficient bytes (what the device stage touches) + file bytes (what the
+        // entropy stage walks) -- nvimagecodec_amd/sharding.py image_cost
+        nvimgcodecCodeStream_t cs = nullptr;
+        nvimgcodecImageInfo_t info{};
+        info.struct_type = NVIMGCODEC_STRUCTURE_TYPE_IMAGE_INFO;
+        info.struct_size = sizeof info;
+        cost[i] = files[i].size();
+        if (nvimgcodecCodeStreamCreateFromHostMem(instance, &cs, files[i].data(), files[i].size()) == NVIMGCODEC_STATUS_SUCCESS) {
+            if (nvimgcodecCodeStreamGetImageInfo(cs, &info) == NVIMGCODEC_STATUS_SUCCESS) {
+                const uint64_t w = info.plane_info[0].width, h = info.plane_info[0].height;
+                const uint64_t chroma = info.chroma_subsampling == NVIMGCODEC_SAMPLING_GRAY  ? 0
+                                        : info.chroma_subsampling == NVIMGCODEC_SAMPLING_444 ? 2 * w * h
+                                        : info.chroma_subsampling == NVIMGCODEC_SAMPLING_420 ? w * h / 2
+                                                                                             : w * h;
+                cost[i] += 2 * (w * h + chroma);
+            }
+            nvimgcodecCodeStreamDestroy(cs);
+        }
+    }
+    // greedy longest-processing-time partition, items in (cost descending, index ascending) order, ties to the lowest queue
+    const size_t nq = p.devices.size();
+    std::vector<size_t> order(names.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+    std::vector<std::vector<size_t>> queues(nq);
+    std::vector<uint64_t> load(nq, 0);
+    for (size_t i : order) {
+        size_t best = 0;
+        for (size_t q = 1; q < nq; q++)
+            if (load[q] < load[best]) best = q;
+        queues[best].push_back(i);
+        load[best] += cost[i];
+    }
+    std::vector<uint64_t> sums(names.size(), 0);
+    std::vector<QueueResult> results(nq);
+    std::vector<std::thread> threads;
+    const double t0 = wtime();
+    for (size_t q = 0; q < nq; q++)
+        threads.emplace_back(run_device_queue, instance, std::cref(p), p.devices[q], std::cref(queues[q]), std::cref(files),
+                             p.checksums.empty() ? nullptr : &sums, &results[q]);
+    for (auto& t : threads) t.join();
+    const double t = wtime() - t0;
+    size_t images = 0, failed = 0;
+    double bytes_in = 0;
+    for (size_t q = 0; q < nq; q++) {
+        if (!results[q].error.empty()) {
+            fprintf(stderr, "queue %zu (device %d): %s failed\n", q, p.devices[q], results[q].error.c_str());
+            return EXIT_FAILURE;
+        }
+        printf("queue %zu on device %d: %zu images (%zu failed) in %f s = %f images per sec, %.1f MB/s of host bitstream bytes\n", q, p.devices[q],
+               results[q].images, results[q].failed, results[q].seconds, results[q].images / results[q].seconds, results[q].bytes_in / results[q].seconds / 1e6);
+        images += results[q].images;
+        failed += results[q].failed;
+        bytes_in += results[q].bytes_in;
+    }
+    printf("\nTotal images: %zu (failed: %zu) over %zu device queues, batch size %d, %d batches in flight per queue\n", images, failed, nq, p.batch, p.in_flight);
+    printf("Total decoding time (parsing included, files preloaded): %f\n", t);
+    printf("Avg decoding speed  (in images per sec): %f\n", images / t);
+    printf("Host bitstream bytes read per sec (all queues): %.1f MB/s\n", bytes_in / t / 1e6);
+    if (!p.checksums.empty()) {
+        FILE* f = fopen(p.checksums.c_str(), "w");
+        if (!f) return EXIT_FAILURE;
+        for (size_t i = 0; i < names.size(); i++) {
+            const size_t slash = names[i].rfind('/');
+            fprintf(f, "%s %016llx\n", names[i].substr(slash == std::string::npos ? 0 : slash + 1).c_str(), (unsigned long long)sums[i]);
+        }
+        fclose(f);
+    }
+    return failed ? EXIT_FAILURE : EXIT_SUCCESS;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -118,11 +337,20 @@ int main(int argc, char** argv)
         else if (a == "--skip_encode") p.skip_encode = true;
         else if (a == "--jpeg_encoding") p.progressive = std::string(next()) == "progressive_dct";
         else if (a == "--optimized_huffman") p.optimized_huffman = std::string(next()) == "true";
+        else if (a == "--devices") {
+            std::string list = next();
+            for (size_t b = 0; b < list.size();) {
+                size_t e = list.find(',', b);
+                if (e == std::string::npos) e = list.size();
+                p.devices.push_back(atoi(list.substr(b, e - b).c_str()));
+                b = e + 1;
+            }
+        } else if (a == "--checksums") p.checksums = next();
         else if (a == "-v") p.verbose++;
         else {
             fprintf(stderr, "usage: %s -i <file|dir> [-o dir] [-b batch] [-w warmup] [-r repeats] [-q quality] [-s 444|422|420|gray] [-d device] "
                             "[-t threads] [-p batches in flight] [--skip_encode] [--jpeg_encoding baseline_dct|progressive_dct] [--optimized_huffman true|false] "
-                            "[--options str] [-v]\n", argv[0]);
+                            "[--options str] [--devices a,b,...] [--checksums file] [-v]\n", argv[0]);
             return EXIT_FAILURE;
         }
     }
@@ -149,6 +377,12 @@ int main(int argc, char** argv)
                           (p.verbose > 1 ? NVIMGCODEC_DEBUG_MESSAGE_SEVERITY_WARNING : 0);
     ci.message_category = NVIMGCODEC_DEBUG_MESSAGE_CATEGORY_ALL;
     CHECK_API(nvimgcodecInstanceCreate(&instance, &ci));
+
+    if (!p.devices.empty()) {
+        const int rc = run_multi_device(instance, p, names);
+        nvimgcodecInstanceDestroy(instance);
+        return rc;
+    }
 
     nvimgcodecExecutionParams_t ep{};
     ep.struct_type = NVIMGCODEC_STRUCTURE_TYPE_EXECUTION_PARAMS;

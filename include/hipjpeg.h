@@ -180,6 +180,13 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchDeviceKernel(hipjpegHandle_t handl
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchSubmit(hipjpegHandle_t handle, const uint8_t* const* data, const size_t* lengths, int batch_size,
                                                      const hipjpegOutput_t* outputs, hipjpegOutputFormat_t format, unsigned flags, void* stream);
 HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchWait(hipjpegHandle_t handle, hipjpegStatus_t* statuses, int batch_size);
+/* Zero-copy input.  When an image's bitstream lies in page-locked host memory (hipHostMalloc / hipHostRegister, a pinned torch tensor) and
+ * takes the GPU entropy stage, the copy engine reads the scan's bytes from THAT memory -- no staging copy on the host (one pass over host
+ * DRAM per byte instead of three; what matters when eight ranks share a host).  Nothing to call: the library asks the runtime about every
+ * input pointer; HIPJPEG_NO_ZERO_COPY=1 in the environment switches it off.  The caller keeps the memory valid until the batch has been
+ * waited for (as for every Submit).  Returns how many images of the handle's current batch went that way (after Transfer / Submit). */
+HIPJPEG_API int32_t hipjpegDecodeBatchZeroCopyImages(hipjpegHandle_t handle);
+
 /* With HIPJPEG_FLAG_GPU_HUFFMAN: only images of MORE than `pixels` pixels (width x height) take the GPU entropy stage, smaller ones the
  * host Huffman decoder -- nvJPEG's switch between its HYBRID and GPU_HYBRID backends (plugin option hybrid_huffman_threshold,
  * reference extensions/nvjpeg/cuda_decoder.cpp:188-209, 512-521).  0 (default) = every eligible stream on the GPU. */

@@ -93,6 +93,8 @@ def load():
     L.hipjpegDecodeBatchWait.argtypes = [vp, vp, i32]
     L.hipjpegSetPipelineDepth.argtypes = [vp, i32]
     L.hipjpegSetHybridHuffmanThreshold.argtypes = [vp, ctypes.c_uint64]
+    L.hipjpegDecodeBatchZeroCopyImages.argtypes = [vp]
+    L.hipjpegDecodeBatchZeroCopyImages.restype = i32
     L.hipjpegTestHostFallbacks.argtypes = [vp]
     L.hipjpegTestHostFallbacks.restype = i32
     L.hipjpegTestScanChunkDrops.argtypes = [vp, ctypes.c_size_t, i32, ctypes.POINTER(ctypes.c_uint32), i32]

@@ -378,6 +378,65 @@ class Decoder(_ExecMixin):
         return results
 
 
+class MultiDeviceDecoder:
+    """One process, several devices: a `Decoder` per entry of `device_ids` -- the reference keys its worker
+    pools by device the same way (src/default_executor.cpp:45-58) -- and a host thread per entry.  `decode(batch)` partitions the batch
+    over the devices' queues by size (sharding.shard_indices: greedy longest-processing-time over coefficient + bitstream bytes, visited
+    in decreasing size like src/image_generic_decoder.cpp:134-178 sorts a batch), every queue decodes on its own device, and the results
+    come back in input order, each Image on the device that decoded it.  No device talks to another (no collective).  An id may appear
+    more than once: several queues on one card."""
+
+    def __init__(self, device_ids, max_num_cpu_threads=0, backends=None, options=""):
+        self.device_ids = [int(d) for d in device_ids]
+        if not self.device_ids:
+            raise ValueError("device_ids must name at least one device")
+        self._decoders = [Decoder(d, max_num_cpu_threads, backends, options) for d in self.device_ids]
+
+    def close(self):
+        for d in self._decoders:
+            d.close()
+        self._decoders = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def shard(self, data):
+        """Index lists, one per device queue (every index exactly once)."""
+        from . import sharding
+        return sharding.shard_indices([sharding.image_cost(d) for d in data], len(self._decoders))
+
+    def decode(self, data, params=None):
+        import threading
+        import torch
+        dlist = list(data)
+        queues = self.shard(dlist)
+        results = [None] * len(dlist)
+        errors = []
+
+        def run(q):
+            try:
+                dec = self._decoders[q]
+                with torch.cuda.device(dec.device_id):
+                    if queues[q]:
+                        for i, im in zip(queues[q], dec.decode([dlist[i] for i in queues[q]], params)):
+                            results[i] = im
+                        torch.cuda.synchronize(dec.device_id)
+            except Exception as e:  # noqa: BLE001 -- handed to the caller below
+                errors.append(e)
+
+        threads = [threading.Thread(target=run, args=(q,)) for q in range(len(self._decoders))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results
+
+
 class Encoder(_ExecMixin):
     """nvimgcodec.Encoder (python/encoder.cpp:136-179, 292-390) for JPEG output."""
 

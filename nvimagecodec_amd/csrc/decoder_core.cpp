@@ -280,6 +280,17 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
         if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && big_enough && gpu_entropy_eligible(f)) {
             im.gpu_entropy = true;
             im.pool_words = gpu_pool_words(f.scans[0]);
+            // Zero-copy input: page-locked caller memory (hipHostMalloc / hipHostRegister, a pinned torch tensor) can
+            // be read by the copy engine directly, so the scan's bytes skip the staging copy -- per rank one pass over host DRAM instead
+            // of three (read, non-temporal store into the staging area, the engine's read).  HIPJPEG_NO_ZERO_COPY=1 switches it off.
+            static const bool zero_copy = getenv("HIPJPEG_NO_ZERO_COPY") == nullptr;
+            if (zero_copy) {
+                hipPointerAttribute_t attr;
+                if (hipPointerGetAttributes(&attr, im.data) == hipSuccess)
+                    im.input_pinned = attr.type == hipMemoryTypeHost;
+                else
+                    (void)hipGetLastError();  // ordinary pageable memory: the query fails and leaves an error behind
+            }
         } else if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && big_enough && gpu_progressive_eligible(f)) {
             im.gpu_entropy = im.gpu_prog = true;
             im.pool_words = prog_pool_words(f);
@@ -500,6 +511,8 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     const size_t boundaries_base = align_up(tables_base + huff_pool_total, 256);
     const size_t streams_base = align_up(boundaries_base + huff_boundary_total, 256);
     coef_offset_ = align_up(streams_base + huff_raw_total, 256);
+    raw_region_begin_ = streams_base;
+    raw_region_end_ = coef_offset_;
     for (int pass = 0; pass < 2; pass++) {  // host-decoded images first, GPU-decoded ones behind the H2D boundary
         if (pass == 1) {
             h2d_bytes_ = coef_offset_ + coef_total;
@@ -631,8 +644,10 @@ void DecodeBatch::entropy_stage(int i)
         const ScanHeader& sc = im.frame.scans[0];
         im.stream_bytes = (uint32_t)(sc.data_end - sc.data_begin);
         uint8_t* raw = pinned_.data() + im.raw_offset;
-        copy_to_staging(raw, im.data + sc.data_begin, im.stream_bytes);
-        memset(raw + im.stream_bytes, 0x01, align_up((size_t)im.stream_bytes, 16) + 16 - im.stream_bytes);  // neither FF nor 00
+        if (!im.input_pinned) {  // (else: transfer() sends the bytes from where they are)
+            copy_to_staging(raw, im.data + sc.data_begin, im.stream_bytes);
+            memset(raw + im.stream_bytes, 0x01, align_up((size_t)im.stream_bytes, 16) + 16 - im.stream_bytes);  // neither FF nor 00
+        }
         stage_chunk_drops(sc, im.first_chunk);
         HuffImage& h = huff_images_[im.huff_index];
         fill_huff_image(im.frame, im.stream_bytes, &h);
@@ -869,7 +884,37 @@ hipjpegStatus_t DecodeBatch::transfer(void* stream, bool kernels_on_other_stream
     pixels_launched_ = false;
     if (h2d_bytes_ == 0) return HIPJPEG_STATUS_SUCCESS;
     // only descriptors, bitstreams of GPU-decoded images and coefficients of host-decoded images cross PCIe
-    hipError_t e = hipMemcpyAsync(device_.data(), pinned_.data(), h2d_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream);
+    zero_copy_images_ = 0;
+    for (const PlannedImage& im : images_) zero_copy_images_ += (im.status == HIPJPEG_STATUS_SUCCESS && im.gpu_entropy && !im.gpu_prog && im.input_pinned) ? 1 : 0;
+    hipError_t e = hipSuccess;
+    if (zero_copy_images_ == 0) {
+        e = hipMemcpyAsync(device_.data(), pinned_.data(), h2d_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream);
+    } else {
+        // everything but the staged bitstreams in two pieces (in front of and behind their region), the region's padding bytes in one
+        // fill (neither FF nor 00, see entropy_stage), then one copy per scan: from the caller's pinned memory, or from the staging area
+        // for the images of the batch that are not zero-copy
+        hipStream_t s = (hipStream_t)stream;
+        const size_t rb = std::min(raw_region_begin_, h2d_bytes_), re = std::min(raw_region_end_, h2d_bytes_);
+        if (rb > 0) e = hipMemcpyAsync(device_.data(), pinned_.data(), rb, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && re > rb) e = hipMemsetAsync(device_.data() + rb, 0x01, re - rb, s);
+        if (e == hipSuccess && h2d_bytes_ > re) e = hipMemcpyAsync(device_.data() + re, pinned_.data() + re, h2d_bytes_ - re, hipMemcpyHostToDevice, s);
+        for (const PlannedImage& im : images_) {
+            if (e != hipSuccess) break;
+            if (im.status != HIPJPEG_STATUS_SUCCESS || !im.gpu_entropy) continue;
+            if (im.gpu_prog) {
+                for (size_t sidx = 0; sidx < im.frame.scans.size() && e == hipSuccess; sidx++) {
+                    const ScanHeader& sc = im.frame.scans[sidx];
+                    const size_t len = sc.data_end - sc.data_begin;
+                    if (len) e = hipMemcpyAsync(device_.data() + im.prog_raw_offset[sidx], pinned_.data() + im.prog_raw_offset[sidx], align_up(len, 16) + 16, hipMemcpyHostToDevice, s);
+                }
+                continue;
+            }
+            if (im.input_pinned)
+                e = hipMemcpyAsync(device_.data() + im.raw_offset, im.data + im.frame.scans[0].data_begin, im.stream_bytes, hipMemcpyHostToDevice, s);
+            else
+                e = hipMemcpyAsync(device_.data() + im.raw_offset, pinned_.data() + im.raw_offset, align_up((size_t)im.stream_bytes, 16) + 16, hipMemcpyHostToDevice, s);
+        }
+    }
     if (e == hipSuccess && kernels_on_other_stream) {
         if (!copied_event_) {
             hipEvent_t ev;

@@ -83,6 +83,7 @@ struct PlannedImage {
     // progressive scans on the GPU entropy stage (progressive_gpu_core.h): gpu_entropy is set as well (device-only coefficient
     // arena, compact DC planes); every scan has a HuffImage of its own for the destuff kernels
     bool gpu_prog = false;
+    bool input_pinned = false;  // the caller's bitstream memory is page-locked: the scan's bytes are DMAed from there, no staging copy
     int prog_index = -1;               // index into the ProgImage array
     uint32_t prog_huff_first = 0;      // HuffImage index of scan 0, relative to the first progressive one
     size_t prog_raw_offset[kProgMaxScans] = {0};     // staged copy of each scan's entropy-coded bytes (staging area)
@@ -137,6 +138,7 @@ public:
     int host_fallback_images() const { return host_fallback_images_; }  // GPU-entropy images the host decoder took over in resolve()
     bool has_progressive() const { return !prog_to_image_.empty(); }
     uint64_t stream_bytes() const { return stream_bytes_total_; }
+    int zero_copy_images() const { return zero_copy_images_; }  // images of the current batch whose bitstream went to the device from the caller's own (pinned) memory
     void flavour_units(int32_t* plane_units, int32_t luma_units[kNumLumaLayouts]) const
     {
         *plane_units = (int32_t)(plane_units_.size() + fused_plane_units_.size());
@@ -176,6 +178,8 @@ private:
     size_t unit_off_fused_plane_ = 0, unit_off_fused_luma_[kNumLumaLayouts][kNumLumaVariants] = {{0}};
     bool fused_ = false;
     uint64_t gpu_entropy_min_pixels_ = 0;
+    size_t raw_region_begin_ = 0, raw_region_end_ = 0;  // the staged bitstreams inside the H2D part of the staging area
+    int zero_copy_images_ = 0;
     std::vector<int> host_taken_;
     void* taken_units_dev_ = nullptr;
     size_t taken_units_cap_ = 0;

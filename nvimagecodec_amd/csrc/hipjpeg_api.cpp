@@ -101,6 +101,15 @@ const char* hipjpegStatusString(hipjpegStatus_t s)
 
 int hipjpegVersion(void) { return 200; }
 
+// Batches in flight run their entropy stages on streams of their own (decoder pages, plugin jobs); the HIP runtime multiplexes streams
+// onto GPU_MAX_HW_QUEUES hardware queues -- four by default -- and kernels of streams that share a queue run one after the other: with
+// six progressive batches in flight their 80 ms walks queued up behind each other.  The runtime reads the variable when
+// it initialises, i.e. at the process's first HIP call; this library is normally loaded before that (an extension module is opened when
+// the instance is created, the Python package on import), so it asks for twelve queues itself unless the environment already says
+// otherwise.  A process that has initialised HIP earlier keeps its setting: nothing breaks, deep pipelines of progressive batches are
+// slower.  (the figure must not depend on the caller exporting the variable.)
+__attribute__((constructor)) static void hipjpeg_runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "12", /*overwrite=*/0); }
+
 // The hipjpegTest* entry points exist for the test suite (fault injection, counters the tests assert on).  They answer only in a
 // process that was started with HIPJPEG_ENABLE_TEST_HOOKS=1 (read once); anywhere else they refuse -- no caller of a production process can
 // arm a throw inside the library.  tests/conftest.py sets the variable; bench.py and the tools do not need the hooks.
@@ -455,6 +464,8 @@ hipjpegStatus_t hipjpegDecodeBatchEntropyStats(hipjpegHandle_t handle, int32_t* 
     return HIPJPEG_STATUS_SUCCESS;
     });
 }
+
+int32_t hipjpegDecodeBatchZeroCopyImages(hipjpegHandle_t handle) { return handle ? handle->cur().zero_copy_images() : -1; }
 
 int32_t hipjpegTestScanChunkDrops(const uint8_t* data, size_t length, int scan_index, uint32_t* drops, int32_t capacity)
 {

@@ -13,6 +13,8 @@ _FORMATS = {"rgb": N.OUTPUT_RGBI, "bgr": N.OUTPUT_BGRI, "rgb_planar": N.OUTPUT_R
 def _as_u8(data):
     if isinstance(data, np.ndarray):
         return np.ascontiguousarray(data, dtype=np.uint8)
+    if hasattr(data, "data_ptr") and hasattr(data, "numpy"):  # a torch CPU tensor: its memory, no copy
+        return data.numpy()
     return np.frombuffer(bytes(data), dtype=np.uint8)
 
 
@@ -126,9 +128,11 @@ class BatchDecoder:
 
     def _marshal(self, jpegs, outs, fmt):
         n = len(jpegs)
-        arrs = [_as_u8(j) for j in jpegs]
-        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
-        lens = (ctypes.c_size_t * n)(*[a.size for a in arrs])
+        # a torch CPU tensor (uint8, contiguous) is taken where it lies -- in pinned memory (tensor.pin_memory()) the library then sends its
+        # bitstream to the device without a staging copy (zero-copy input); everything else goes through numpy
+        arrs = [j if (hasattr(j, "data_ptr") and hasattr(j, "numel")) else _as_u8(j) for j in jpegs]
+        ptrs = (ctypes.c_void_p * n)(*[(a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data) for a in arrs])
+        lens = (ctypes.c_size_t * n)(*[(a.numel() if hasattr(a, "numel") else a.size) for a in arrs])
         O = (N.Output * n)()
         for i, o in enumerate(outs):
             if o is None:
@@ -275,7 +279,7 @@ class BatchDecoder:
         gi, sl, sb = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_uint64()
         N.load().hipjpegDecodeBatchEntropyStats(self._h, ctypes.byref(gi), ctypes.byref(sl), ctypes.byref(sb))
         return dict(units=list(units), coef_bytes=cb.value, output_bytes=ob.value, gpu_entropy_images=gi.value, sync_launches=sl.value,
-                    stream_bytes=sb.value)
+                    stream_bytes=sb.value, zero_copy_images=int(N.load().hipjpegDecodeBatchZeroCopyImages(self._h)))
 
     def statuses(self, n):
         st = (ctypes.c_int * n)()

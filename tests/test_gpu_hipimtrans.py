@@ -67,3 +67,39 @@ def test_progressive_and_optimized_output(tmp_path):
         assert marker in out[:700]
         got = oracle.decode_coefficients(out)[0]
         assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def _fnv1a(data):
+    h = 1469598103934665603
+    for b in bytes(data):
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_one_process_drives_several_device_queues(tmp_path):
+    """--devices a,b: a decoder instance, a host thread and a queue per entry, the input list partitioned over the queues by size
+    (reference pools keyed by device, src/default_executor.cpp:45-58).  On this one-GPU box both queues sit on device 0; every
+    decoded picture is checked against the oracle through the tool's checksum file, and the report says what each queue did."""
+    src = tmp_path / "in"
+    src.mkdir()
+    shapes = [(640, 480, "420"), (333, 217, "444"), (1280, 720, "422"), (64, 64, "420"), (800, 600, "420"), (1920, 1080, "420"), (100, 75, "gray"),
+              (512, 512, "420"), (17, 13, "444"), (960, 540, "422"), (1024, 768, "420"), (48, 200, "420"), (720, 1280, "420")]
+    want = {}
+    for i, (w, h, sub) in enumerate(shapes):
+        im = synth_image(w, h, seed=900 + i)
+        j = oracle.encode(im if sub != "gray" else im[:, :, 1].copy(), sub, 88)
+        name = "img%02d.jpg" % i
+        (src / name).write_bytes(j)
+        ref = oracle.decode(j)
+        want[name] = _fnv1a(np.ascontiguousarray(ref).tobytes())
+    sums = tmp_path / "sums.txt"
+    p = subprocess.run([TOOL, "-i", str(src), "--devices", "0,0", "-b", "4", "-p", "2", "-r", "2", "--checksums", str(sums)], capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "over 2 device queues" in p.stdout and "Total images: %d (failed: 0)" % (2 * len(shapes)) in p.stdout
+    per_queue = [int(m) for m in re.findall(r"queue \d on device 0: (\d+) images", p.stdout)]
+    assert len(per_queue) == 2 and sum(per_queue) == 2 * len(shapes) and min(per_queue) > 0
+    got = dict(line.split() for line in sums.read_text().splitlines())
+    assert set(got) == set(want)
+    for name in want:
+        assert int(got[name], 16) == want[name], name

@@ -267,3 +267,38 @@ def test_hybrid_huffman_threshold_splits_a_batch_by_area(dec):
     outs, st = dec.decode(batch, gpu_huffman=True)
     _sync()
     assert dec.stats()["gpu_entropy_images"] == 5
+
+
+def test_zero_copy_input_from_pinned_memory(dec):
+    """Bitstreams in page-locked memory (pinned torch tensors) are DMAed from where they lie (hipjpegDecodeBatchZeroCopyImages says how
+    many); a batch may mix them with pageable inputs, with host-decoded and with progressive images -- same pixels as always.  Also through
+    the pipelined Submit/Wait entry points, three batches in flight."""
+    import torch
+    srcs = [oracle.encode(synth_image(320 + 16 * i, 200 + 8 * i, seed=70 + i), "420" if i % 2 else "444", 90) for i in range(6)]
+    entries = [e for e in _M["decode"] if e["progressive"]][:2]
+    prog = [load_decode_case(e)[0] for e in entries]
+    pinned = [torch.frombuffer(bytearray(j), dtype=torch.uint8).pin_memory() for j in srcs]
+    batch = [pinned[0], srcs[1], pinned[2], prog[0], pinned[3], srcs[4], pinned[5], prog[1]]
+    raw = [srcs[0], srcs[1], srcs[2], prog[0], srcs[3], srcs[4], srcs[5], prog[1]]
+    refs = [oracle.decode(j) for j in raw]
+    outs, st = dec.decode(batch, gpu_huffman=True)
+    _sync()
+    assert dec.stats()["zero_copy_images"] == 4
+    for o, r in zip(outs, refs):
+        assert np.array_equal(o.cpu().numpy(), r)
+    outs, st = dec.decode(batch, gpu_huffman=False)   # host Huffman: nothing to DMA from the caller's memory
+    _sync()
+    assert dec.stats()["zero_copy_images"] == 0
+    for o, r in zip(outs, refs):
+        assert np.array_equal(o.cpu().numpy(), r)
+    rings = [dec.allocate_outputs(raw, "rgb") for _ in range(3)]
+    for k in range(5):
+        dec.submit(batch, rings[k % 3], gpu_huffman=True)
+        if k > 1:
+            dec.wait()
+    dec.wait()
+    dec.wait()
+    _sync()
+    for ring in rings:
+        for o, r in zip(ring, refs):
+            assert np.array_equal(o.cpu().numpy(), r)

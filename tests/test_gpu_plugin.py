@@ -519,3 +519,19 @@ def test_decoder_options_like_the_reference_plugins(torch_mod):
     lib.nvimgcodecDecoderDestroy(dec)
     lib.nvimgcodecInstanceDestroy(inst)
     del cb
+
+
+def test_multi_device_decoder_partitions_a_batch_over_device_queues(torch_mod):
+    """api.MultiDeviceDecoder: one process, a Decoder + host thread per device entry, the batch partitioned by size, results in input
+    order.  Two queues on device 0 here (one-GPU box): every picture bit-exact, both queues used, nothing decoded twice."""
+    from nvimagecodec_amd import api
+    entries = [e for e in _M["decode"] if e["pixels"]][:40]
+    cases = [load_decode_case(e) for e in entries]
+    with api.MultiDeviceDecoder([0, 0], max_num_cpu_threads=2) as dec:
+        queues = dec.shard([c[0] for c in cases])
+        assert sorted(i for q in queues for i in q) == list(range(len(cases))) and all(queues)
+        imgs = dec.decode([c[0] for c in cases])
+        torch_mod.cuda.synchronize()
+        for e, (jpeg, rgb), im in zip(entries, cases, imgs):
+            assert im is not None, e["name"]
+            assert np.array_equal(np.asarray(im.cpu()._array), rgb), e["name"]
