@@ -396,8 +396,26 @@ def encode_figures(outs, local_rank, host_threads):
         if i > 1:
             enc.wait(fetch=False)
     enc.wait(fetch=False)
-    _, files = enc.wait(fetch=True)   # the files of the last timed batch, fetched after the timed region
+    enc.wait(fetch=False)
     t_enc_e2e = (time.perf_counter() - t0) / enc_batches
+    files = enc.bitstreams()   # the files of the last timed batch, fetched after the timed region
+    # per-image optimized Huffman tables (nvimgcodecJpegEncodeParams_t::optimized_huffman) through the same pipeline: statistics on the
+    # device, jpeg_gen_optimal_table on the host, coding on the device (round 2: the host coder, ~1.4 k images/s)
+    for _ in range(3):
+        enc.submit(outs, "420", 90, "rgb", gpu_huffman=True, optimized_huffman=True)
+    for _ in range(3):
+        enc.wait(fetch=False)
+    opt_gpu_images = enc.stats()["gpu_entropy_images"]
+    opt_batches = 12
+    t0 = time.perf_counter()
+    for i in range(opt_batches):
+        enc.submit(outs, "420", 90, "rgb", gpu_huffman=True, optimized_huffman=True)
+        if i > 1:
+            enc.wait(fetch=False)
+    enc.wait(fetch=False)
+    enc.wait(fetch=False)
+    t_enc_opt = (time.perf_counter() - t0) / opt_batches
+    opt_files = enc.bitstreams()
     est = enc.stats()
     # parity: every file of that batch against the oracle's encoder on the same pixels (byte for byte; the inputs are the decoded
     # pictures of the decode leg, eight distinct ones)
@@ -416,6 +434,8 @@ def encode_figures(outs, local_rank, host_threads):
             "gpu_huffman_stage_ms": round(t_encg * 1e3, 3), "gpu_huffman_images_per_s": round(BATCH / t_encg, 1),
             "end_to_end_images_per_s": round(BATCH / t_enc_e2e, 1),
             "parity_encode": enc_same, "parity_files_checked": enc_checked,
+            "optimized_huffman_end_to_end_images_per_s": round(BATCH / t_enc_opt, 1), "optimized_huffman_gpu_coded_images": opt_gpu_images,
+            "optimized_huffman_bytes_vs_standard": round(sum(len(f) for f in opt_files) / max(1, sum(len(f) for f in files)), 4),
             "end_to_end_includes": "RGB in HBM -> JPEG files in host memory: forward kernel + GPU entropy coder, files written to pinned host "
                                    "memory by the last kernel; three batches in flight (hipjpegEncodeBatchSubmit/Wait)"}
     enc.close()
@@ -444,10 +464,11 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     distributed = world > 1
 
-    # the library first: it must be in the process before the first HIP call (it asks the runtime for more hardware queues, see the top)
+    # torch's libraries, then ours, then the first HIP call: the library must be in the process before the runtime initialises (it asks
+    # for more hardware queues, see the top) and behind torch's own copy of the HIP runtime (nvimagecodec_amd/_native.py load)
+    import torch
     from nvimagecodec_amd import _native
     _native.load()
-    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
@@ -624,7 +645,7 @@ def main():
             "cpu_huffman_images_per_s": round(BATCH * world / t_e2e_cpu, 1),
             "cpu_huffman_includes": "the north-star split: Huffman on the host cores + H2D of the coefficients + device stage, through "
                                     "hipjpegDecodeBatchSubmit/Wait with three batches in flight, %d timed batches after every page was warmed" % cpu_batches,
-            "cpu_huffman_iteration_ms": {"median": round(cpu_iters[len(cpu_iters) // 2] * 1e3, 2), "min": round(cpu_iters[0] * 1e3, 2),
+            "cpu_huffman_iteration_ms": {"median": round(cpu_iters[len(cpu_iters) // 2] * 1e3, 2), "p10": round(cpu_iters[len(cpu_iters) // 10] * 1e3, 2),
                                          "max": round(cpu_iters[-1] * 1e3, 2), "n": len(cpu_iters)},
             "host_threads_per_gpu": host_threads}
         extras["host_stage"] = {"huffman_images_per_s": round(BATCH / t_host, 1), "threads": host_threads,

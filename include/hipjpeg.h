@@ -259,6 +259,9 @@ HIPJPEG_API hipjpegStatus_t hipjpegEncodeGetBitstream(hipjpegHandle_t handle, in
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeGetCoefficients(hipjpegHandle_t handle, int index, int component, const int16_t** coef,
                                                          int32_t grid[4] /* blocks_w, blocks_h, real_w, real_h */);
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchStats(hipjpegHandle_t handle, int32_t* num_units, uint64_t* pixel_bytes, uint64_t* coef_bytes);
+/* How many images of the handle's last entropy stage the GPU entropy coder took (Annex-K or optimized tables, no restart intervals, baseline);
+ * the others were coded by the host coder. */
+HIPJPEG_API int32_t hipjpegEncodeBatchGpuEntropyImages(hipjpegHandle_t handle);
 /* Host-only: entropy-code given coefficient grids (zigzag order, MCU-padded grids as above) into a JFIF file.
  * Returns HIPJPEG_STATUS_BUFFER_TOO_SMALL with *length = needed size if capacity is insufficient. */
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeFromCoefficientsHost(int32_t width, int32_t height, const hipjpegEncodeParams_t* params,

@@ -2,6 +2,7 @@
 import error says how to build it, and every device entry point reports HIPJPEG_STATUS_NO_DEVICE without a GPU."""
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HIPJPEG_LIB_PATH") or os.path.join(_HERE, "libhipjpeg_ext.so")  # the override is a development aid (A/B builds)
@@ -70,6 +71,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
                           "or make -C nvimagecodec_amd/csrc)")
+    # torch first: it ships its own libamdhip64; were this library opened before it, the process would hold two HIP runtimes (the system's,
+    # through this library, and torch's) and the second to initialise finds no device
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     L.hipjpegStatusString.restype = ctypes.c_char_p
@@ -111,6 +119,8 @@ def load():
     L.hipjpegEncodeGetBitstream.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.hipjpegEncodeGetCoefficients.argtypes = [vp, i32, i32, ctypes.POINTER(vp), vp]
     L.hipjpegEncodeBatchStats.argtypes = [vp, vp, vp, vp]
+    L.hipjpegEncodeBatchGpuEntropyImages.argtypes = [vp]
+    L.hipjpegEncodeBatchGpuEntropyImages.restype = i32
     L.hipjpegEncodeFromCoefficientsHost.argtypes = [i32, i32, ctypes.POINTER(EncodeParams), vp, vp, sz, ctypes.POINTER(sz)]
     _lib = L
     return L

@@ -286,9 +286,10 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
             static const bool zero_copy = getenv("HIPJPEG_NO_ZERO_COPY") == nullptr;
             if (zero_copy) {
                 hipPointerAttribute_t attr;
-                if (hipPointerGetAttributes(&attr, im.data) == hipSuccess)
-                    im.input_pinned = attr.type == hipMemoryTypeHost;
-                else
+                if (hipPointerGetAttributes(&attr, im.data) == hipSuccess) {
+                    im.input_pinned = attr.type == hipMemoryTypeHost && attr.devicePointer != nullptr;
+                    im.input_device_view = static_cast<const uint8_t*>(attr.devicePointer);  // the same bytes as the device addresses them
+                } else
                     (void)hipGetLastError();  // ordinary pageable memory: the query fails and leaves an error behind
             }
         } else if (im.status == HIPJPEG_STATUS_SUCCESS && want_gpu_entropy && big_enough && gpu_progressive_eligible(f)) {
@@ -804,6 +805,7 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         }
         h.stream = work_.data() + work_streams_ + im.stream_offset;
         h.raw = device_.data() + im.raw_offset;
+        h.raw_src = im.input_pinned ? im.input_device_view + im.frame.scans[0].data_begin : nullptr;
         if (h.restart_interval) {
             h.boundaries = reinterpret_cast<const uint32_t*>(device_.data() + im.boundary_offset);
             h.sub_boundary = h.boundaries + h.num_boundaries;
@@ -892,7 +894,7 @@ hipjpegStatus_t DecodeBatch::transfer(void* stream, bool kernels_on_other_stream
     } else {
         // everything but the staged bitstreams in two pieces (in front of and behind their region), the region's padding bytes in one
         // fill (neither FF nor 00, see entropy_stage), then one copy per scan: from the caller's pinned memory, or from the staging area
-        // for the images of the batch that are not zero-copy
+        // for the images of the batch that are not zero-copy; the zero-copy ones are pulled over by ONE kernel (gather_raw_kernel)
         hipStream_t s = (hipStream_t)stream;
         const size_t rb = std::min(raw_region_begin_, h2d_bytes_), re = std::min(raw_region_end_, h2d_bytes_);
         if (rb > 0) e = hipMemcpyAsync(device_.data(), pinned_.data(), rb, hipMemcpyHostToDevice, s);
@@ -909,11 +911,13 @@ hipjpegStatus_t DecodeBatch::transfer(void* stream, bool kernels_on_other_stream
                 }
                 continue;
             }
-            if (im.input_pinned)
-                e = hipMemcpyAsync(device_.data() + im.raw_offset, im.data + im.frame.scans[0].data_begin, im.stream_bytes, hipMemcpyHostToDevice, s);
-            else
+            if (!im.input_pinned)  // (the pinned ones: one kernel for all of them, below)
                 e = hipMemcpyAsync(device_.data() + im.raw_offset, pinned_.data() + im.raw_offset, align_up((size_t)im.stream_bytes, 16) + 16, hipMemcpyHostToDevice, s);
         }
+        if (e == hipSuccess &&
+            launch_gather_raw(reinterpret_cast<const HuffImage*>(device_.data() + huff_desc_offset_),
+                              reinterpret_cast<const HuffUnit*>(device_.data() + huff_chunk_units_offset_), (int)huff_chunk_units_.size(), stream) != 0)
+            e = hipErrorLaunchFailure;
     }
     if (e == hipSuccess && kernels_on_other_stream) {
         if (!copied_event_) {

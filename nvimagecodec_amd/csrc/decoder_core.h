@@ -83,7 +83,8 @@ struct PlannedImage {
     // progressive scans on the GPU entropy stage (progressive_gpu_core.h): gpu_entropy is set as well (device-only coefficient
     // arena, compact DC planes); every scan has a HuffImage of its own for the destuff kernels
     bool gpu_prog = false;
-    bool input_pinned = false;  // the caller's bitstream memory is page-locked: the scan's bytes are DMAed from there, no staging copy
+    bool input_pinned = false;  // the caller's bitstream memory is page-locked: the scan's bytes are fetched from there, no staging copy
+    const uint8_t* input_device_view = nullptr;  // ... `data` as the device addresses it (hipPointerGetAttributes)
     int prog_index = -1;               // index into the ProgImage array
     uint32_t prog_huff_first = 0;      // HuffImage index of scan 0, relative to the first progressive one
     size_t prog_raw_offset[kProgMaxScans] = {0};     // staged copy of each scan's entropy-coded bytes (staging area)

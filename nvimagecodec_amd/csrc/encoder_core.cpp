@@ -221,10 +221,12 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
         im.gpu_bitstream = nullptr;
         im.gpu_bitstream_len = 0;
         if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
-        if (im.params.restart_interval == 0 && !im.params.optimized_huffman && !im.params.progressive)
+        // HIPJPEG_NO_GPU_OPTIMIZED_HUFFMAN=1: per-image tables on the host coder as in round 2 (A/B and cross-check aid)
+        static const bool gpu_optimized = getenv("HIPJPEG_NO_GPU_OPTIMIZED_HUFFMAN") == nullptr;
+        if (im.params.restart_interval == 0 && !im.params.progressive && (gpu_optimized || !im.params.optimized_huffman))
             idx.push_back(i);
         else
-            (*todo)[i] = 1;  // restart markers / per-image tables / progressive scans: the host coder
+            (*todo)[i] = 1;  // restart markers / progressive scans: the host coder
     }
     const int ng = (int)idx.size();
     if (ng == 0) return HIPJPEG_STATUS_SUCCESS;
@@ -255,13 +257,21 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
         for (uint32_t b = 0; b < h.total_blocks; b += 256) units.push_back(HencUnit{(uint32_t)g, b});
         total_blocks += (h.total_blocks + 63) & ~(size_t)63;
     }
+    // images that want tables of their own (optimized_huffman): slot k of the per-image histogram / code-table arrays
+    std::vector<int> opt_slot(ng, -1);
+    int nopt = 0;
+    for (int g = 0; g < ng; g++)
+        if (images_[idx[g]].params.optimized_huffman) opt_slot[g] = nopt++;
+    constexpr size_t kHistBytes = 2 * 2 * 256 * sizeof(uint32_t);
     const size_t o_units = align_up(sizeof(HencImage) * (size_t)ng, 256);
     const size_t o_tables = align_up(o_units + sizeof(HencUnit) * units.size(), 256);
-    const size_t up1 = align_up(o_tables + sizeof(StandardCodeTables), 256);  // uploaded part
+    const size_t o_opt_tables = align_up(o_tables + sizeof(StandardCodeTables), 256);
+    const size_t up1 = align_up(o_opt_tables + sizeof(StandardCodeTables) * (size_t)nopt, 256);  // uploaded part
     const size_t o_bits = up1;
     const size_t o_off = align_up(o_bits + total_blocks * 2, 256);
     const size_t o_total = align_up(o_off + total_blocks * 4, 256);
-    const size_t dev1 = o_total + align_up((size_t)ng * 4, 256);
+    const size_t o_hist = align_up(o_total + (size_t)ng * 4, 256);
+    const size_t dev1 = o_hist + align_up(kHistBytes * (size_t)nopt, 256);
     hipjpegStatus_t st;
     if ((st = henc_dev_.reserve(dev1 + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
     // pinned staging: phase-1 upload | totals | phase-2 upload (descriptors again, chunk units, headers) | lengths, offsets
@@ -271,7 +281,8 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
         write_standard_headers(im.geom, im.qlum, im.qchr, &headers[g]);
     }
     const size_t p_totals = up1;
-    const size_t p_up2 = align_up(p_totals + (size_t)ng * 4, 256);
+    const size_t p_hist = align_up(p_totals + (size_t)ng * 4, 256);
+    const size_t p_up2 = align_up(p_hist + kHistBytes * (size_t)nopt, 256);
     // worst case for the chunk count: sized after the totals are known -> reserve generously from the block count
     // (a block codes to at most 64 * (16 + 15) bits; in practice ~10 bytes) -- the exact size is re-checked below
     if ((st = henc_pinned_.reserve(p_up2 + 256)) != HIPJPEG_STATUS_SUCCESS) return st;
@@ -286,6 +297,29 @@ hipjpegStatus_t EncodeBatch::gpu_entropy_stage(std::vector<char>* todo)
     uint16_t* block_bits = reinterpret_cast<uint16_t*>(dev + o_bits);
     uint32_t* block_off = reinterpret_cast<uint32_t*>(dev + o_off);
     uint32_t* total_bits = reinterpret_cast<uint32_t*>(dev + o_total);
+    if (nopt > 0) {
+        // ---- phase 0: symbol statistics on the device, optimal tables on the host (a few dozen microseconds per image), tables back up.
+        // The coefficients never leave HBM; what crosses PCIe is 4 KB of counts and 1.6 KB of tables per image.
+        for (int g = 0; g < ng; g++)
+            if (opt_slot[g] >= 0) desc[g].hist = reinterpret_cast<uint32_t*>(dev + o_hist + kHistBytes * (size_t)opt_slot[g]);
+        memcpy(pin, desc.data(), sizeof(HencImage) * (size_t)ng);
+        if (hipMemcpyAsync(dev, pin, o_opt_tables, hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipMemsetAsync(dev + o_hist, 0, kHistBytes * (size_t)nopt, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (launch_henc_hist(dimg, dunits, (int)units.size(), stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipMemcpyAsync(pin + p_hist, dev + o_hist, kHistBytes * (size_t)nopt, hipMemcpyDeviceToHost, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        if (hipStreamSynchronize(s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
+        for (int g = 0; g < ng; g++) {
+            if (opt_slot[g] < 0) continue;
+            const PlannedEncode& im = images_[idx[g]];
+            const auto* counts = reinterpret_cast<const uint32_t(*)[2][256]>(pin + p_hist + kHistBytes * (size_t)opt_slot[g]);
+            headers[g].clear();
+            optimal_code_tables(counts, im.geom, im.qlum, im.qchr,
+                                reinterpret_cast<StandardCodeTables*>(pin + o_opt_tables + sizeof(StandardCodeTables) * (size_t)opt_slot[g]), &headers[g]);
+            desc[g].hist = nullptr;
+            desc[g].tables = reinterpret_cast<const StandardCodeTables*>(dev + o_opt_tables + sizeof(StandardCodeTables) * (size_t)opt_slot[g]);
+        }
+        memcpy(pin, desc.data(), sizeof(HencImage) * (size_t)ng);
+    }
     if (hipMemcpyAsync(dev, pin, up1, hipMemcpyHostToDevice, s) != hipSuccess) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_henc_length(dimg, dunits, (int)units.size(), dtables, block_bits, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;
     if (launch_henc_scan(dimg, ng, block_bits, block_off, total_bits, stream_) != 0) return HIPJPEG_STATUS_HIP_ERROR;

@@ -723,6 +723,37 @@ void standard_code_tables(StandardCodeTables* t)
     }
 }
 
+void optimal_code_tables(const uint32_t counts[2][2][256], const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64],
+                         StandardCodeTables* t, std::vector<uint8_t>* headers)
+{
+    HuffTable dc[2], ac[2];
+    dc[0].set(kDcLumBits, kDcVals);
+    dc[1].set(kDcChrBits, kDcVals);
+    ac[0].set(kAcLumBits, kAcLumVals);
+    ac[1].set(kAcChrBits, kAcChrVals);
+    const int ntab = g.ncomp == 3 ? 2 : 1;
+    for (int k = 0; k < ntab; k++) {
+        long freq[257];
+        memset(freq, 0, sizeof freq);
+        for (int i = 0; i < 256; i++) freq[i] = (long)counts[k][0][i];
+        gen_optimal_table(freq, &dc[k]);
+        memset(freq, 0, sizeof freq);
+        for (int i = 0; i < 256; i++) freq[i] = (long)counts[k][1][i];
+        gen_optimal_table(freq, &ac[k]);
+    }
+    for (int k = 0; k < 2; k++) {
+        for (int i = 0; i < 16; i++) {
+            t->dc_code[k][i] = (uint16_t)dc[k].code[i];
+            t->dc_size[k][i] = dc[k].size[i];
+        }
+        for (int i = 0; i < 256; i++) {
+            t->ac_code[k][i] = (uint16_t)ac[k].code[i];
+            t->ac_size[k][i] = ac[k].size[i];
+        }
+    }
+    write_headers(g, qlum, qchr, dc[0], ac[0], dc[1], ac[1], 0, headers);
+}
+
 void encode_jfif(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], const int16_t* const coef[3],
                  const EntropyEncodeOptions& opt, std::vector<uint8_t>* o)
 {

@@ -43,6 +43,11 @@ struct StandardCodeTables {
     uint8_t ac_size[2][256];
 };
 void standard_code_tables(StandardCodeTables* t);
+// Optimized tables for the GPU coder: from symbol counts gathered on the device (counts[t][0][category] for DC table t, counts[t][1][run/size
+// symbol] for AC table t; t = 0 luma, 1 chroma) to the (code, length) tables and the bytes of SOI .. SOS with the matching DHT segments --
+// jchuff.c jpeg_gen_optimal_table, the very routine the host coder's optimized_huffman path uses, so both paths write the same file.
+void optimal_code_tables(const uint32_t counts[2][2][256], const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64],
+                         StandardCodeTables* t, std::vector<uint8_t>* headers);
 void write_standard_headers(const EncodeGeometry& g, const uint16_t qlum[64], const uint16_t qchr[64], std::vector<uint8_t>* out);
 
 }  // namespace hipjpeg

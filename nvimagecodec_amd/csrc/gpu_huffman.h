@@ -16,6 +16,9 @@ struct HuffUnit {
 // Writes HuffImage::stream contents and total_bits / num_subseq / stream_words.
 // count_on_device = false: `drops` already holds the per-chunk counts (from the host's marker walk)
 // counters: 64 words the compact kernel clears (the stage's convergence counters)
+// Zero-copy input: copies the scans of the images whose HuffImage::raw_src is set from the caller's pinned host memory to HuffImage::raw
+// (same chunk units as the destuff kernels; images without raw_src are skipped).
+int launch_gather_raw(const HuffImage* images, const HuffUnit* chunk_units, int nchunks, void* stream);
 int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, bool count_on_device, unsigned int* counters,
                    void* stream);
 

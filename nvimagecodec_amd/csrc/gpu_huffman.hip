@@ -227,6 +227,30 @@ __device__ __forceinline__ int compact_tasks(WgShared& sh, bool has, int value, 
     return n;
 }
 
+// ---- zero-copy input: bitstreams fetched from the caller's pinned host memory ------------------------------------------------
+// One DMA call per image costs the submitting thread 15-20 us (256 of them: 5 ms per batch, measured); one kernel that pulls the bytes
+// over PCIe costs one launch.  Few resident workgroups on purpose -- waves that wait on PCIe reads slow the kernels beside them as
+// long as they occupy wave slots -- each walking the destuff kernels' chunk list (kDestuffChunk raw bytes per item).
+constexpr int kGatherGroups = 64;
+__global__ __launch_bounds__(kThreads) void gather_raw_kernel(const HuffImage* __restrict__ images, const HuffUnit* __restrict__ units, int nunits)
+{
+    for (int ui = blockIdx.x; ui < nunits; ui += gridDim.x) {
+        const HuffUnit u = units[ui];
+        const HuffImage& im = images[u.image];
+        const uint8_t* src = im.raw_src;
+        if (!src) continue;  // staged by the host (uniform per item)
+        const uint32_t begin = u.first * (uint32_t)kDestuffChunk;
+        if (begin >= im.raw_bytes) continue;
+        const uint32_t n = min((uint32_t)kDestuffChunk, im.raw_bytes - begin);
+        const uint8_t* s = src + begin;
+        uint8_t* d = const_cast<uint8_t*>(im.raw) + begin;  // 16-byte aligned: raw offsets and kDestuffChunk are multiples of 16
+        typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;  // the caller's buffer starts at any byte
+        for (uint32_t i = threadIdx.x * 16u; i + 16u <= n; i += kThreads * 16u) *(HJ_GLOBAL u32x4*)(d + i) = *(const HJ_GLOBAL u32x4_unaligned*)(s + i);
+        const uint32_t tail = n & ~15u;
+        if (threadIdx.x < (n & 15u)) d[tail + threadIdx.x] = s[tail + threadIdx.x];
+    }
+}
+
 // ---- byte-stuffing removal ------------------------------------------------------------------------------------------
 // The file's entropy-coded segment escapes every 0xFF data byte as FF 00.  Two kernels turn it into the plain bitstream the
 // decoders read: the first counts the stuffed bytes of every 16 KB chunk, the second compacts each chunk to its final
@@ -1289,6 +1313,13 @@ __global__ __launch_bounds__(kThreads) void huff_dc_kernel(const HuffImage* __re
 }
 
 }  // namespace
+
+int launch_gather_raw(const HuffImage* images, const HuffUnit* chunk_units, int nchunks, void* stream)
+{
+    if (nchunks <= 0) return 0;
+    hipLaunchKernelGGL(gather_raw_kernel, dim3(min(nchunks, kGatherGroups)), dim3(kThreads), 0, (hipStream_t)stream, images, chunk_units, nchunks);
+    return (int)hipGetLastError();
+}
 
 int launch_destuff(HuffImage* images, const HuffUnit* chunk_units, int nchunks, uint32_t* drops, bool count_on_device, unsigned int* counters,
                    void* stream)

@@ -36,6 +36,12 @@ struct alignas(16) HencImage {
     uint32_t raw_bytes, header_bytes;
     uint32_t first_chunk;    // index of the image's first chunk in the batch-wide per-chunk arrays
     uint32_t num_chunks;
+    // optimized Huffman tables (nvimgcodecJpegEncodeParams_t::optimized_huffman, reference extensions/nvjpeg/cuda_encoder.cpp:348-357):
+    // hist = where the histogram kernel adds this image's symbol counts ([2][2][256] uint32: table, DC / AC, symbol), null for images
+    // coded with the Annex-K tables; tables = the image's own code tables once the host has built them from the counts (null: the
+    // batch's standard tables)
+    uint32_t* hist;
+    const StandardCodeTables* tables;
 };
 
 struct HencUnit {
@@ -43,6 +49,9 @@ struct HencUnit {
 };
 
 // stream = hipStream_t as void*; all launches are asynchronous
+// Symbol statistics of the images that want their own tables (jchuff.c's gather-statistics pass, one lane per block): same units as the
+// length kernel; images without HencImage::hist are skipped.
+int launch_henc_hist(const HencImage* images, const HencUnit* units, int nunits, void* stream);
 int launch_henc_length(const HencImage* images, const HencUnit* units, int nunits, const StandardCodeTables* tables, uint16_t* block_bits, void* stream);
 int launch_henc_scan(const HencImage* images, int nimages, const uint16_t* block_bits, uint32_t* block_off, uint32_t* total_bits, void* stream);
 int launch_henc_write(const HencImage* images, const HencUnit* units, int nunits, const StandardCodeTables* tables, const uint32_t* block_off,

@@ -195,6 +195,35 @@ __device__ __forceinline__ uint32_t code_block(const uint4 (&q)[8], bool real, i
     return len;
 }
 
+// The symbols of one block, counted instead of coded (jchuff.c htest_one_block): hist[0][category] for the DC difference, hist[1][run/size]
+// for the coefficients, ZRL and EOB included -- the same walk as code_block.
+__device__ __forceinline__ void count_block(const uint4 (&q)[8], bool real, int diff, HJ_LDS uint32_t (*hist)[256])
+{
+    __hip_atomic_fetch_add(&hist[0][bit_length((unsigned)(diff < 0 ? -diff : diff))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!real) {
+        __hip_atomic_fetch_add(&hist[1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    const uint32_t w[32] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w,
+                            q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w};
+    int run = 0;
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        const int v = (k & 1) ? ((int)w[k >> 1] >> 16) : ((int)(w[k >> 1] << 16) >> 16);
+        if (v == 0) {
+            run++;
+            continue;
+        }
+        while (run > 15) {
+            __hip_atomic_fetch_add(&hist[1][0xF0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            run -= 16;
+        }
+        __hip_atomic_fetch_add(&hist[1][(run << 4) + bit_length((unsigned)(v < 0 ? -v : v))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        run = 0;
+    }
+    if (run > 0) __hip_atomic_fetch_add(&hist[1][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // Loads what code_block needs for block s.
 __device__ __forceinline__ void fetch_block(const HencImage& im, uint32_t s, uint4 (&q)[8], bool* real, int* diff, int* ti)
 {
@@ -216,14 +245,37 @@ __device__ __forceinline__ void fetch_block(const HencImage& im, uint32_t s, uin
     *diff = dc - pred;
 }
 
+__global__ __launch_bounds__(kThreads) void henc_hist_kernel(const HencImage* __restrict__ images, const HencUnit* __restrict__ units)
+{
+    __shared__ uint32_t hist[2][2][256];
+    const HencUnit u = units[blockIdx.x];
+    const HencImage& im = images[u.image];
+    if (!im.hist) return;  // uniform: this image is coded with the standard tables
+    for (int i = threadIdx.x; i < 1024; i += kThreads) (&hist[0][0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t s = u.first + threadIdx.x;
+    if (s < im.total_blocks) {
+        uint4 q[8];
+        bool real;
+        int diff, ti;
+        fetch_block(im, s, q, &real, &diff, &ti);
+        count_block(q, real, diff, (HJ_LDS uint32_t(*)[256])hist[ti]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += kThreads) {
+        const uint32_t v = (&hist[0][0][0])[i];
+        if (v) atomicAdd(&im.hist[i], v);
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void henc_length_kernel(const HencImage* __restrict__ images, const HencUnit* __restrict__ units,
                                                                const StandardCodeTables* __restrict__ tables, uint16_t* __restrict__ block_bits)
 {
     __shared__ LdsTables T;
-    load_tables(&T, tables);
-    __syncthreads();
     const HencUnit u = units[blockIdx.x];
     const HencImage& im = images[u.image];
+    load_tables(&T, im.tables ? im.tables : tables);
+    __syncthreads();
     const uint32_t s = u.first + threadIdx.x;
     if (s >= im.total_blocks) return;
     uint4 q[8];
@@ -289,9 +341,9 @@ __global__ __launch_bounds__(kThreads) void henc_write_kernel(const HencImage* _
     __shared__ LdsTables T;
     __shared__ uint32_t window[kWindowWords];
     __shared__ uint32_t span[2];  // first word of the workgroup's range, number of words (0: does not fit the window)
-    load_tables(&T, tables);
     const HencUnit u = units[blockIdx.x];
     const HencImage& im = images[u.image];
+    load_tables(&T, im.tables ? im.tables : tables);
     const int t = threadIdx.x;
     const uint32_t s = u.first + t;
     const bool live = s < im.total_blocks;
@@ -498,6 +550,13 @@ __global__ __launch_bounds__(kThreads) void henc_expand_kernel(const HencImage* 
 }  // namespace
 
 constexpr int kExpandGrid = 64;  // resident workgroups of the expand kernel: enough stores in flight for PCIe (swept 32..1024 on MI355X)
+
+int launch_henc_hist(const HencImage* images, const HencUnit* units, int nunits, void* stream)
+{
+    if (nunits <= 0) return 0;
+    hipLaunchKernelGGL(henc_hist_kernel, dim3(nunits), dim3(kThreads), 0, (hipStream_t)stream, images, units);
+    return (int)hipGetLastError();
+}
 
 int launch_henc_length(const HencImage* images, const HencUnit* units, int nunits, const StandardCodeTables* tables, uint16_t* block_bits, void* stream)
 {

@@ -655,6 +655,11 @@ hipjpegStatus_t hipjpegEncodeBatchStats(hipjpegHandle_t handle, int32_t* num_uni
     });
 }
 
+int32_t hipjpegEncodeBatchGpuEntropyImages(hipjpegHandle_t handle)
+{
+    return handle && handle->encode_view ? (int32_t)handle->encode_view->gpu_entropy_images() : -1;
+}
+
 hipjpegStatus_t hipjpegEncodeFromCoefficientsHost(int32_t width, int32_t height, const hipjpegEncodeParams_t* params, const int16_t* const coef[3],
                                                   uint8_t* out, size_t capacity, size_t* length)
 {

@@ -117,6 +117,10 @@ struct alignas(16) HuffImage {
     // the image exceeded its round budget; moved_pass = number of the last ripple launch in which a group's own last end state
     // still changed.  The host hands such images to the host entropy decoder instead of launching on (decoder_core.cpp resolve).
     uint32_t gave_up, moved_pass;
+    // zero-copy input: the scan's bytes in the CALLER's page-locked host memory, as the device sees it (null: staged like everything else).
+    // gather_raw_kernel copies them to `raw` in place of a DMA from the staging area.
+    const uint8_t* raw_src;
+    uint64_t pad2;
     HuffK k[10];
     uint32_t blocks_w[4];
     uint8_t comp_h[4], comp_v[4], comp_k0[4], pad1[4];  // comp_k0 = first position k of the component inside the MCU

@@ -463,4 +463,4 @@ class BatchEncoder:
         u = ctypes.c_int32()
         pb, cb = ctypes.c_uint64(), ctypes.c_uint64()
         N.load().hipjpegEncodeBatchStats(self._h, ctypes.byref(u), ctypes.byref(pb), ctypes.byref(cb))
-        return dict(units=u.value, pixel_bytes=pb.value, coef_bytes=cb.value)
+        return dict(units=u.value, pixel_bytes=pb.value, coef_bytes=cb.value, gpu_entropy_images=int(N.load().hipjpegEncodeBatchGpuEntropyImages(self._h)))

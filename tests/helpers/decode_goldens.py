@@ -50,12 +50,12 @@ def main():
         batch = [x for pair in zip(small, damaged) for x in pair]
         outs_h, st_h = dec.decode(batch, fmt="rgb", gpu_huffman=False, check=False)
         torch.cuda.synchronize()
-        ref = [o.cpu().numpy().copy() for o in outs_h]
+        ref = [o.cpu().numpy().copy() if o is not None else None for o in outs_h]
         outs_g, st_g = dec.decode(batch, fmt="rgb", gpu_huffman=True, check=False)
         torch.cuda.synchronize()
         assert list(st_g) == list(st_h), (list(st_g), list(st_h))
         for i, (a, b) in enumerate(zip(outs_g, ref)):
-            if st_h[i] == 0:
+            if st_h[i] == 0 and b is not None:
                 assert np.array_equal(a.cpu().numpy(), b), i
         print("fused: damaged neighbours ok,", sum(1 for s in st_h if s), "refused,", dec.host_fallbacks(), "taken over by the host decoder")
     print("goldens ok", len(jpegs), "flavours", plane, luma)

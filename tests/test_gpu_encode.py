@@ -316,3 +316,39 @@ def test_pair_kernel_planar_input(enc, torch_mod, fmt):
             del os.environ["HIPJPEG_ENCODE_ONE_LANE_KERNEL"]
         for (w, h), s, e in zip(sizes, streams, expected):
             assert s == e, f"one-lane kernel {w}x{h} {sub} {fmt}"
+
+
+def test_optimized_huffman_on_the_gpu_coder_equals_the_host_coder(torch_mod):
+    """optimized_huffman (nvimgcodecJpegEncodeParams_t, reference extensions/nvjpeg/cuda_encoder.cpp:348-357) on the GPU entropy coder: symbol
+    statistics on the device, jpeg_gen_optimal_table on the host, coding with the image's own tables on the device.  Files byte-identical
+    to the host coder's (itself pinned to libjpeg-turbo's optimized output through the decode goldens' tables and the progressive files),
+    every sampling, gray, odd sizes, mixed in one batch with Annex-K images; and the files decode to the same coefficients as the plain ones."""
+    torch = torch_mod
+    from nvimagecodec_amd.lowlevel import BatchEncoder
+    shapes = [(96, 64, "420"), (333, 217, "444"), (640, 480, "422"), (17, 13, "420"), (250, 250, "gray"), (1280, 720, "420"), (64, 200, "440")]
+    imgs, subs = [], []
+    for i, (w, h, sub) in enumerate(shapes):
+        im = synth_image(w, h, seed=300 + i)
+        if i % 3 == 2:  # noise: long codes, every run/size symbol in use
+            im = np.random.default_rng(i).integers(0, 256, size=im.shape, dtype=np.uint8)
+        imgs.append(np.ascontiguousarray(im[:, :, 1]) if sub == "gray" else im)
+        subs.append(sub)
+    host = BatchEncoder(0, num_threads=4, gpu_huffman=False)
+    gpu = BatchEncoder(0, num_threads=4, gpu_huffman=True)
+    try:
+        for fmt, idx in (("rgb", [i for i, s in enumerate(subs) if s != "gray"]), ("gray", [i for i, s in enumerate(subs) if s == "gray"])):
+            feed = [torch.from_numpy(imgs[i]).cuda() for i in idx]
+            ssub = [subs[i] for i in idx]
+            for q in (35, 90, 100):
+                want = host.encode(feed, ssub, q, input_format=fmt, optimized_huffman=True)
+                got = gpu.encode(feed, ssub, q, input_format=fmt, optimized_huffman=True)
+                assert gpu.stats()["gpu_entropy_images"] == len(feed)   # coded on the device, none handed to the host coder
+                plain = gpu.encode(feed, ssub, q, input_format=fmt)
+                for k, (a, b, c) in enumerate(zip(want, got, plain)):
+                    assert a == b, (fmt, q, idx[k])
+                    assert len(b) <= len(c)
+                    ca, cb = oracle.decode_coefficients(b)[0], oracle.decode_coefficients(c)[0]
+                    assert all(np.array_equal(x, y) for x, y in zip(ca, cb))
+    finally:
+        host.close()
+        gpu.close()
