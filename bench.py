@@ -110,14 +110,16 @@ def kernel_source_hash():
 
 def measured_traffic():
     """HBM bytes per step of the roofline kernels from a PMC pass (tools/round_profile.sh) -- only if it was taken on this tree."""
-    p = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    try:
-        with open(p) as f:
-            t = json.load(f)
-        if t.get("source_sha") == kernel_source_hash():
-            return t.get("roofline_kernels_bytes_per_step")
-    except Exception:
-        pass
+    import glob
+    sha = kernel_source_hash()
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(p) as f:
+                t = json.load(f)
+            if t.get("source_sha") == sha:
+                return t.get("roofline_kernels_bytes_per_step")
+        except Exception:
+            pass
     return None
 
 

@@ -23,7 +23,7 @@ for k, d in agg.items():
     name = k.replace("(anonymous namespace)::", "").split("(")[0].strip()
     out["kernels"][name] = {"fetch_bytes": int(fetch), "write_bytes": int(write), "launches_seen": len(d["FETCH_SIZE"])}
     out["all_kernels_bytes_per_step"] += int(fetch + write)   # NB: huff_sync_kernel runs twice per step, counted once here
-    if "idct_plane_kernel" in name or "luma_color_kernel" in name:
+    if "idct_plane_kernel" in name or "luma_color_kernel" in name or "idct_plane_fused_kernel" in name or "luma_color_fused_kernel" in name:
         out["roofline_kernels_bytes_per_step"] += int(fetch + write)
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
