@@ -651,7 +651,10 @@ def main():
                                          "max": round(cpu_iters[-1] * 1e3, 2), "n": len(cpu_iters)},
             "host_threads_per_gpu": host_threads}
         extras["host_stage"] = {"huffman_images_per_s": round(BATCH / t_host, 1), "threads": host_threads,
-                                "h2d_GBps": round(hst["coef_bytes"] / t_h2d / 1e9, 1)}
+                                "h2d_GBps": round(hst["h2d_bytes"] / t_h2d / 1e9, 1), "h2d_ms": round(t_h2d * 1e3, 2),
+                                # zero-run-compressed staging: what the host entropy stage puts on PCIe against the dense int16 blocks
+                                "h2d_bytes_per_batch": hst["h2d_bytes"], "dense_coefficient_bytes_per_batch": hst["coef_bytes"],
+                                "sparse_images": hst["sparse_images"]}
         if rank == 0:
             try:
                 extras["device_stage_flavours"] = device_stage_flavours(dec, jpegs)

@@ -137,6 +137,14 @@ HIPJPEG_API hipjpegStatus_t hipjpegGetImageInfo(const uint8_t* data, size_t leng
 HIPJPEG_API hipjpegStatus_t hipjpegEntropyDecodeHost(const uint8_t* data, size_t length, int16_t* coef, size_t coef_capacity_bytes,
                                                      uint64_t comp_offsets[4], uint16_t qtables[256]);
 
+/* The host entropy stage's zero-run-compressed output (what crosses PCIe for host-decoded pictures since round 3; csrc/entropy_decode.h):
+ * per-block offset tables (uint32 per block of each component's MCU-padded raster grid, the tables back to back; table_offsets[c] = index of
+ * component c's first entry; 0 = block never coded) followed by the records [n : u8][DC : i16 LE] n x {position : u8, value : i16 LE}, position =
+ * index into the device-layout block (column-major).  UNSUPPORTED for frames the format does not cover (progressive, several scans): those
+ * stay dense.  capacity_bytes >= 200 bytes per block is always enough. */
+HIPJPEG_API hipjpegStatus_t hipjpegEntropyDecodeHostSparse(const uint8_t* data, size_t length, uint8_t* stream, size_t capacity_bytes, size_t* stream_bytes,
+                                                           uint64_t table_offsets[4]);
+
 /* The GPU entropy decoder's algorithm (self-synchronizing subsequence decoding, csrc/huffman_gpu_core.h) executed on the
  * host, lane by lane, with the very code the kernels run: lets the algorithm be verified without a GPU.  Same output
  * layout as hipjpegEntropyDecodeHost; returns HIPJPEG_STATUS_UNSUPPORTED for streams the GPU entropy path does not take
@@ -186,6 +194,9 @@ HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchWait(hipjpegHandle_t handle, hipjp
  * input pointer; HIPJPEG_NO_ZERO_COPY=1 in the environment switches it off.  The caller keeps the memory valid until the batch has been
  * waited for (as for every Submit).  Returns how many images of the handle's current batch went that way (after Transfer / Submit). */
 HIPJPEG_API int32_t hipjpegDecodeBatchZeroCopyImages(hipjpegHandle_t handle);
+/* What the current batch's transfer puts on PCIe (descriptors, tables, bitstreams of GPU-decoded pictures, coefficients of host-decoded ones)
+ * and how many host-decoded pictures went as zero-run-compressed streams rather than dense blocks (HIPJPEG_DENSE_STAGING=1 switches that off). */
+HIPJPEG_API hipjpegStatus_t hipjpegDecodeBatchTransferStats(hipjpegHandle_t handle, uint64_t* h2d_bytes, int32_t* sparse_images);
 
 /* With HIPJPEG_FLAG_GPU_HUFFMAN: only images of MORE than `pixels` pixels (width x height) take the GPU entropy stage, smaller ones the
  * host Huffman decoder -- nvJPEG's switch between its HYBRID and GPU_HYBRID backends (plugin option hybrid_huffman_threshold,

@@ -101,6 +101,8 @@ def load():
     L.hipjpegDecodeBatchWait.argtypes = [vp, vp, i32]
     L.hipjpegSetPipelineDepth.argtypes = [vp, i32]
     L.hipjpegSetHybridHuffmanThreshold.argtypes = [vp, ctypes.c_uint64]
+    L.hipjpegDecodeBatchTransferStats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int32)]
+    L.hipjpegEntropyDecodeHostSparse.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), vp]
     L.hipjpegDecodeBatchZeroCopyImages.argtypes = [vp]
     L.hipjpegDecodeBatchZeroCopyImages.restype = i32
     L.hipjpegTestHostFallbacks.argtypes = [vp]

@@ -201,6 +201,37 @@ __device__ __forceinline__ void read_half_block(const char* lds_wave, int lane, 
     if (dc_apart && !(lane & 1)) cols[0].x = (cols[0].x & 0xFFFF0000u) | dc;
 }
 
+// ---- zero-run-compressed staging (host entropy stage, entropy_decode.h) -------------------------------------------------------
+// The picture came over PCIe as a SPARSE stream: per block a record [n][DC lo hi] n x {position, value lo, value hi}, found through
+// a table of byte offsets.  The lane pair of a block expands its record into the block's LDS slot (zeroed first): lane 0 the DC value and
+// the even entries, lane 1 the odd ones -- one unaligned 4-byte load and one 2-byte LDS store per coefficient, ~6 per lane for a q90
+// photograph.  have = this pair's slot holds a block of the grid; bidx = its raster index.
+__device__ __forceinline__ void sparse_expand_slots(const DecodeComponent& cd, bool have, unsigned bidx, char* lds_wave, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int g = k * 64 + lane;  // 288 16-byte pieces
+        if (g < kBlocksPerWave * kLdsBlockStride / 16) *reinterpret_cast<u32x4*>(lds_wave + g * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    wave_lds_fence();
+    if (have) {
+        const unsigned off = ((const HJ_GLOBAL unsigned*)cd.block_off)[bidx];
+        if (off) {
+            const HJ_GLOBAL unsigned char* rec = (const HJ_GLOBAL unsigned char*)cd.coef + off;
+            typedef unsigned __attribute__((aligned(1))) u32_unaligned;
+            const unsigned head = *(const HJ_GLOBAL u32_unaligned*)rec;  // n, DC lo, DC hi, (first entry's position)
+            const int n = (int)(head & 255u), p = lane & 1;
+            HJ_LDS unsigned short* slot = (HJ_LDS unsigned short*)(lds_wave + (lane >> 1) * kLdsBlockStride);
+            if (!p) slot[0] = (unsigned short)(head >> 8);
+            for (int e = p; e < n; e += 2) {
+                const unsigned v = *(const HJ_GLOBAL u32_unaligned*)(rec + 3 + 3 * e);  // position, value lo, value hi, (one byte of the next entry)
+                slot[v & 63u] = (unsigned short)(v >> 8);
+            }
+        }
+    }
+    wave_lds_fence();
+}
+
 // Coalesced HBM -> LDS staging of the 32 blocks a wave owns (4 KB contiguous), then each lane reads back the four
 // 16-byte column chunks of its half block: columns 4p .. 4p+3 of block lane>>1.
 // The DC coefficient comes from cd.dc (see DecodeComponent): lane 0 of each pair patches it into column 0, row 0.
@@ -208,6 +239,12 @@ __device__ __forceinline__ void fetch_half_block(const DecodeComponent& cd, int 
                                                  u32x4 (&cols)[4])
 {
     const int16_t* __restrict__ comp_coef = cd.coef;
+    if (cd.block_off) {  // (wave-uniform: a property of the picture)
+        const int mine = wave_first_block + (lane >> 1);
+        sparse_expand_slots(cd, mine < block_limit, (unsigned)mine, lds_wave, lane);
+        read_half_block(lds_wave, lane, 0u, false, cols);
+        return;
+    }
     const u32x4* src = reinterpret_cast<const u32x4*>(comp_coef) + (size_t)wave_first_block * 8;
     const int nchunks = min(kBlocksPerWave, block_limit - wave_first_block) * 8;  // valid 16-byte chunks (may be <= 0)
     const int my_block = wave_first_block + (lane >> 1);
@@ -241,6 +278,12 @@ __device__ __forceinline__ void fetch_half_block(const DecodeComponent& cd, int 
 __device__ __forceinline__ void fetch_tile_half_block(const DecodeComponent& cd, int row0, int col0, int row_shift, int col_mask, int bw, int bh,
                                                       char* lds_wave, int lane, u32x4 (&cols)[4])
 {
+    if (cd.block_off) {  // (wave-uniform: a property of the picture)
+        const int j = lane >> 1, row = row0 + (j >> row_shift), col = col0 + (j & col_mask);
+        sparse_expand_slots(cd, row < bh && col < bw, (unsigned)(row * bw + col), lds_wave, lane);
+        read_half_block(lds_wave, lane, 0u, false, cols);
+        return;
+    }
     const u32x4* src = reinterpret_cast<const u32x4*>(cd.coef);
     const bool dc_apart = cd.dc_stride != 64;  // wave-uniform: host-decoded images carry the DC inside the block already
     unsigned dc = 0;

@@ -514,6 +514,14 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
     coef_offset_ = align_up(streams_base + huff_raw_total, 256);
     raw_region_begin_ = streams_base;
     raw_region_end_ = coef_offset_;
+    // HIPJPEG_DENSE_STAGING=1: dense int16 blocks for every host-decoded picture as in rounds 1-2 (A/B and cross-check aid)
+    static const bool sparse_enabled = getenv("HIPJPEG_DENSE_STAGING") == nullptr;
+    sparse_mode_ = sparse_enabled;
+    host_coef_used_.store(0);
+    for (int i = 0; i < n; i++) {
+        images_[i].sparse = false;
+        images_[i].host_coef_bytes = 0;
+    }
     for (int pass = 0; pass < 2; pass++) {  // host-decoded images first, GPU-decoded ones behind the H2D boundary
         if (pass == 1) {
             h2d_bytes_ = coef_offset_ + coef_total;
@@ -523,6 +531,7 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
         for (int i = 0; i < n; i++) {
             PlannedImage& im = images_[i];
             if (im.status != HIPJPEG_STATUS_SUCCESS || (int)im.gpu_entropy != pass) continue;
+            if (pass == 0 && sparse_mode_) coef_total += 256;  // (host-decoded pictures are placed while they are decoded: room for alignment)
             for (int c = 0; c < im.frame.ncomp; c++) {
                 im.coef_offset[c] = coef_total;
                 coef_total += (size_t)im.frame.comp[c].blocks_w * im.frame.comp[c].blocks_h * 128;
@@ -594,6 +603,7 @@ hipjpegStatus_t DecodeBatch::plan_once(const uint8_t* const* data, const size_t*
             }
         }
     }
+    h2d_used_ = h2d_bytes_;
     if (statuses)
         for (int i = 0; i < n; i++) statuses[i] = images_[i].status;
     return HIPJPEG_STATUS_SUCCESS;
@@ -679,9 +689,47 @@ void DecodeBatch::entropy_stage(int i)
         }
         return;
     }
-    int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (int c = 0; c < im.frame.ncomp; c++) coef[c] = reinterpret_cast<int16_t*>(pinned_.data() + im.coef_offset[c]);
-    EntropyStatus es = decode_coefficients(im.data, im.size, im.frame, coef, im.coef_or);
+    EntropyStatus es;
+    size_t dense_bytes = 0;
+    for (int c = 0; c < im.frame.ncomp; c++) dense_bytes += (size_t)im.frame.comp[c].blocks_w * im.frame.comp[c].blocks_h * 128;
+    if (sparse_mode_) {
+        // Zero-run-compressed staging: the picture is decoded into this thread's scratch as a sparse stream (a record of the non-zero
+        // coefficients per block), then given the next free bytes of the host-decoded region -- what crosses PCIe is the stream, a third
+        // of the dense blocks for a q90 photograph.  Frames the format does not cover (progressive, several scans), and the odd picture
+        // whose stream would be larger than its dense blocks, are placed the same way as dense blocks.
+        static thread_local std::vector<uint8_t> scratch;
+        size_t bytes = 0;
+        bool sparse = sparse_staging_applies(im.frame);
+        es = kEntropyOk;
+        if (sparse) {
+            scratch.resize(sparse_stream_capacity(im.frame));
+            es = decode_coefficients_sparse(im.data, im.size, im.frame, scratch.data(), &bytes);
+            if (es == kEntropyOk && bytes > dense_bytes) sparse = false;
+        }
+        if (es == kEntropyOk) {
+            const size_t need = align_up(sparse ? bytes : dense_bytes, 256);
+            const size_t at = coef_offset_ + host_coef_used_.fetch_add(need);
+            im.host_coef_offset = at;
+            im.host_coef_bytes = need;
+            im.sparse = sparse;
+            if (sparse) {
+                copy_to_staging(pinned_.data() + at, scratch.data(), bytes);
+            } else {
+                int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
+                size_t off = at;
+                for (int c = 0; c < im.frame.ncomp; c++) {
+                    im.coef_offset[c] = off;
+                    coef[c] = reinterpret_cast<int16_t*>(pinned_.data() + off);
+                    off += (size_t)im.frame.comp[c].blocks_w * im.frame.comp[c].blocks_h * 128;
+                }
+                es = decode_coefficients(im.data, im.size, im.frame, coef, im.coef_or);
+            }
+        }
+    } else {
+        int16_t* coef[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int c = 0; c < im.frame.ncomp; c++) coef[c] = reinterpret_cast<int16_t*>(pinned_.data() + im.coef_offset[c]);
+        es = decode_coefficients(im.data, im.size, im.frame, coef, im.coef_or);
+    }
     for (int c = 0; c < 4; c++) im.ac_bound[c] = im.coef_or[c];  // the OR covers the DC values too: an upper bound all the same
     switch (es) {
     case kEntropyOk: break;
@@ -716,6 +764,23 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         if (im.status != HIPJPEG_STATUS_SUCCESS) continue;
         const FrameInfo& f = im.frame;
         DecodeImage& d = desc_[i];
+        if (sparse_mode_ && !im.gpu_entropy) {
+            // placed while it was decoded (entropy_stage): point the descriptor at where the picture landed
+            size_t blocks_before = 0;
+            for (int c = 0; c < f.ncomp; c++) {
+                DecodeComponent& dc = d.comp[c];
+                if (im.sparse) {
+                    dc.coef = reinterpret_cast<const int16_t*>(device_.data() + im.host_coef_offset);
+                    dc.block_off = reinterpret_cast<const uint32_t*>(device_.data() + im.host_coef_offset) + blocks_before;
+                    blocks_before += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+                } else {
+                    dc.coef = reinterpret_cast<const int16_t*>(device_.data() + im.coef_offset[c]);
+                    dc.block_off = nullptr;
+                }
+                dc.dc = dc.coef;
+                dc.dc_stride = 64;
+            }
+        }
         const OutFormat fmt = (OutFormat)d.out_format;
         const bool fused = fused_ && im.gpu_entropy && !im.gpu_prog;
         d.huff_index = fused ? (uint32_t)im.huff_index : 0u;
@@ -760,6 +825,8 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
             for (int y = 0; y < f.height; y++) cmyk_units_.push_back(WorkUnit{(uint32_t)i, (uint32_t)y, 0u, 0u});
         }
     }
+    // what transfer() has to copy: in sparse mode the host-decoded region ends where the last picture was placed
+    h2d_used_ = sparse_mode_ ? std::min(h2d_bytes_, align_up(coef_offset_ + host_coef_used_.load(), 256)) : h2d_bytes_;
     // write descriptors + unit tables into the staging area
     uint8_t* base = pinned_.data();
     if (n) memcpy(base + desc_offset_, desc_.data(), sizeof(DecodeImage) * (size_t)n);
@@ -884,22 +951,22 @@ hipjpegStatus_t DecodeBatch::transfer(void* stream, bool kernels_on_other_stream
     fault_point("transfer");
     entropy_done_ = false;
     pixels_launched_ = false;
-    if (h2d_bytes_ == 0) return HIPJPEG_STATUS_SUCCESS;
+    if (h2d_used_ == 0) return HIPJPEG_STATUS_SUCCESS;
     // only descriptors, bitstreams of GPU-decoded images and coefficients of host-decoded images cross PCIe
     zero_copy_images_ = 0;
     for (const PlannedImage& im : images_) zero_copy_images_ += (im.status == HIPJPEG_STATUS_SUCCESS && im.gpu_entropy && !im.gpu_prog && im.input_pinned) ? 1 : 0;
     hipError_t e = hipSuccess;
     if (zero_copy_images_ == 0) {
-        e = hipMemcpyAsync(device_.data(), pinned_.data(), h2d_bytes_, hipMemcpyHostToDevice, (hipStream_t)stream);
+        e = hipMemcpyAsync(device_.data(), pinned_.data(), h2d_used_, hipMemcpyHostToDevice, (hipStream_t)stream);
     } else {
         // everything but the staged bitstreams in two pieces (in front of and behind their region), the region's padding bytes in one
         // fill (neither FF nor 00, see entropy_stage), then one copy per scan: from the caller's pinned memory, or from the staging area
         // for the images of the batch that are not zero-copy; the zero-copy ones are pulled over by ONE kernel (gather_raw_kernel)
         hipStream_t s = (hipStream_t)stream;
-        const size_t rb = std::min(raw_region_begin_, h2d_bytes_), re = std::min(raw_region_end_, h2d_bytes_);
+        const size_t rb = std::min(raw_region_begin_, h2d_used_), re = std::min(raw_region_end_, h2d_used_);
         if (rb > 0) e = hipMemcpyAsync(device_.data(), pinned_.data(), rb, hipMemcpyHostToDevice, s);
         if (e == hipSuccess && re > rb) e = hipMemsetAsync(device_.data() + rb, 0x01, re - rb, s);
-        if (e == hipSuccess && h2d_bytes_ > re) e = hipMemcpyAsync(device_.data() + re, pinned_.data() + re, h2d_bytes_ - re, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && h2d_used_ > re) e = hipMemcpyAsync(device_.data() + re, pinned_.data() + re, h2d_used_ - re, hipMemcpyHostToDevice, s);
         for (const PlannedImage& im : images_) {
             if (e != hipSuccess) break;
             if (im.status != HIPJPEG_STATUS_SUCCESS || !im.gpu_entropy) continue;
@@ -1125,8 +1192,8 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
     if (debug_stats && !prog_to_image_.empty()) {
         const ProgImage& q0 = hprog[0];
         for (uint32_t k = 0; k < q0.num_scans; k++)
-            fprintf(stderr, "[hipjpeg] progressive image 0 scan %u (ss %u se %u ah %u al %u): walk %.3f ms\n", k, q0.scan[k].ss, q0.scan[k].se, q0.scan[k].ah,
-                    q0.scan[k].al, q0.scan[k].walk_ticks * 1e-5);
+            fprintf(stderr, "[hipjpeg] progressive image 0 scan %u (ss %u se %u ah %u al %u): walk %.3f ms, of which waiting for neighbours %.3f ms\n", k,
+                    q0.scan[k].ss, q0.scan[k].se, q0.scan[k].ah, q0.scan[k].al, q0.scan[k].walk_ticks * 1e-5, q0.scan[k].wait_ticks * 1e-5);
     }
     for (size_t q = 0; q < prog_to_image_.size(); q++) {
         const PlannedImage& im = images_[prog_to_image_[q]];

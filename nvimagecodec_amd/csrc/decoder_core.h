@@ -83,6 +83,8 @@ struct PlannedImage {
     // progressive scans on the GPU entropy stage (progressive_gpu_core.h): gpu_entropy is set as well (device-only coefficient
     // arena, compact DC planes); every scan has a HuffImage of its own for the destuff kernels
     bool gpu_prog = false;
+    bool sparse = false;        // host entropy stage wrote the picture's zero-run-compressed stream (entropy_decode.h) instead of dense blocks
+    size_t host_coef_offset = 0, host_coef_bytes = 0;  // where this picture's host-decoded coefficients (sparse stream or dense blocks) landed
     bool input_pinned = false;  // the caller's bitstream memory is page-locked: the scan's bytes are fetched from there, no staging copy
     const uint8_t* input_device_view = nullptr;  // ... `data` as the device addresses it (hipPointerGetAttributes)
     int prog_index = -1;               // index into the ProgImage array
@@ -139,7 +141,14 @@ public:
     int host_fallback_images() const { return host_fallback_images_; }  // GPU-entropy images the host decoder took over in resolve()
     bool has_progressive() const { return !prog_to_image_.empty(); }
     uint64_t stream_bytes() const { return stream_bytes_total_; }
-    int zero_copy_images() const { return zero_copy_images_; }  // images of the current batch whose bitstream went to the device from the caller's own (pinned) memory
+    int zero_copy_images() const { return zero_copy_images_; }
+    uint64_t h2d_bytes() const { return h2d_used_; }  // bytes the current batch's transfer() copies to the device
+    int sparse_images() const
+    {
+        int n = 0;
+        for (const PlannedImage& im : images_) n += im.sparse ? 1 : 0;
+        return n;
+    }  // images of the current batch whose bitstream went to the device from the caller's own (pinned) memory
     void flavour_units(int32_t* plane_units, int32_t luma_units[kNumLumaLayouts]) const
     {
         *plane_units = (int32_t)(plane_units_.size() + fused_plane_units_.size());
@@ -180,6 +189,11 @@ private:
     bool fused_ = false;
     uint64_t gpu_entropy_min_pixels_ = 0;
     size_t raw_region_begin_ = 0, raw_region_end_ = 0;  // the staged bitstreams inside the H2D part of the staging area
+    // Host-decoded coefficients are handed out of their region [coef_offset_, h2d_bytes_) first come first served while the pool threads
+    // decode (a sparse stream's size is known only then): h2d_used_ = what transfer() actually has to copy.
+    bool sparse_mode_ = false;
+    std::atomic<size_t> host_coef_used_{0};
+    size_t h2d_used_ = 0;
     int zero_copy_images_ = 0;
     std::vector<int> host_taken_;
     void* taken_units_dev_ = nullptr;

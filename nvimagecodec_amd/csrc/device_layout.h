@@ -43,6 +43,10 @@ struct alignas(16) DecodeComponent {
     // stage: dc[b] in a compact plane of DC values (dc_stride == 1), position 0 of the blocks holds zero.
     const int16_t* dc;
     uint32_t dc_stride, pad0;
+    // Zero-run-compressed staging (host entropy stage, entropy_decode.h): non-null = `coef` is the start of the picture's SPARSE stream and
+    // block_off[b] the byte offset of block b's record in it (0 = all-zero block); null = dense blocks at coef + 64 b.
+    const uint32_t* block_off;
+    uint64_t pad2;
     // Quantizers as the kernels consume them, int16 pairs in the layout of a block's 16-byte column chunk, so that ONE
     // v_pk_mul_lo_u16 dequantizes two coefficients (the low 16 bits of the product, like the SIMD routine's pmullw):
     // qpk[p][j*4 + i] = q(row 2i, column 4p+j) in the low half, q(row 2i+1, column 4p+j) in the high half.

@@ -211,6 +211,53 @@ inline EntropyStatus decode_block_sequential(BitReader& br, const DecodeTable& d
     return kEntropyOk;
 }
 
+// The same block as a sparse record (entropy_decode.h): w = where the record goes; returns the byte behind it.
+inline EntropyStatus decode_block_sequential_sparse(BitReader& br, const DecodeTable& dct, const DecodeTable& act, int& pred, uint8_t*& w)
+{
+    uint8_t* rec = w;
+    w += 3;
+    br.refill();
+    int s = decode_symbol(br, dct);
+    if (s < 0 || s > 15) return kEntropyCorrupt;
+    int diff = 0;
+    if (s) diff = extend((int)br.get(s), s);
+    pred += diff;
+    rec[1] = (uint8_t)(pred & 255);
+    rec[2] = (uint8_t)((pred >> 8) & 255);
+    int n = 0;
+    for (int k = 1; k < 64;) {
+        br.refill();
+        int v;
+        int f = act.fast_ac[br.peek(kLook)];
+        if (f) {
+            k += (f >> 4) & 15;
+            if (k > 63) return kEntropyCorrupt;
+            br.skip(f & 15);
+            v = f >> 8;
+        } else {
+            int rs = decode_symbol(br, act);
+            if (rs < 0) return kEntropyCorrupt;
+            int r = rs >> 4;
+            s = rs & 15;
+            if (!s) {
+                if (r != 15) break;
+                k += 16;
+                continue;
+            }
+            k += r;
+            if (k > 63) return kEntropyCorrupt;
+            v = extend((int)br.get(s), s);
+        }
+        w[0] = kZigzagDevice[k++];
+        w[1] = (uint8_t)(v & 255);
+        w[2] = (uint8_t)((v >> 8) & 255);
+        w += 3;
+        n++;
+    }
+    rec[0] = (uint8_t)n;
+    return kEntropyOk;
+}
+
 // ---- progressive pieces (T.81 G.1.2) ----
 inline EntropyStatus decode_dc_first(BitReader& br, const DecodeTable& dct, int& pred, int16_t* blk, int al)
 {
@@ -418,6 +465,82 @@ EntropyStatus decode_scan(const uint8_t* data, const FrameInfo& f, const ScanHea
 }
 
 }  // namespace
+
+bool sparse_staging_applies(const FrameInfo& f)
+{
+    if (f.progressive() || f.scans.size() != 1 || f.ncomp < 1 || f.ncomp > 4) return false;
+    return f.scans[0].ncomp == f.ncomp;  // every block is coded once, by this scan
+}
+
+size_t sparse_stream_capacity(const FrameInfo& f)
+{
+    size_t blocks = 0;
+    for (int c = 0; c < f.ncomp; c++) blocks += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+    return blocks * (4 + 3 + 63 * 3) + 64;
+}
+
+EntropyStatus decode_coefficients_sparse(const uint8_t* data, size_t size, const FrameInfo& f, uint8_t* out, size_t* out_size)
+{
+    (void)size;
+    const ScanHeader& sc = f.scans[0];
+    ScanTables tabs;
+    for (int i = 0; i < sc.ncomp; i++) {
+        if (!sc.dc[sc.td[i]].present || !sc.ac[sc.ta[i]].present) return kEntropyMissingTable;
+        if (!tabs.dc[sc.td[i]].present) build_table(sc.dc[sc.td[i]], &tabs.dc[sc.td[i]], false);
+        if (!tabs.ac[sc.ta[i]].present) build_table(sc.ac[sc.ta[i]], &tabs.ac[sc.ta[i]], true);
+    }
+    // offset tables first (zero = never coded), records behind them
+    uint32_t* table[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t blocks = 0;
+    for (int c = 0; c < f.ncomp; c++) {
+        table[c] = reinterpret_cast<uint32_t*>(out) + blocks;
+        blocks += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+    }
+    memset(out, 0, blocks * 4);
+    uint8_t* w = out + blocks * 4;
+    BitReader br(data + sc.data_begin, data + sc.data_end);
+    int pred[4] = {0, 0, 0, 0};
+    int until_restart = sc.restart_interval, next_rst = 0;
+    EntropyStatus st;
+    if (sc.ncomp == 1) {
+        const int ci = sc.comp_index[0];
+        const Component& k = f.comp[ci];
+        const int nbx = (k.samp_w + 7) / 8, nby = (k.samp_h + 7) / 8;
+        for (int by = 0; by < nby; by++)
+            for (int bx = 0; bx < nbx; bx++) {
+                if (sc.restart_interval && until_restart == 0) {
+                    if ((st = take_restart(br, next_rst)) != kEntropyOk) return st;
+                    pred[0] = 0;
+                    until_restart = sc.restart_interval;
+                }
+                table[ci][(size_t)by * k.blocks_w + bx] = (uint32_t)(w - out);
+                if ((st = decode_block_sequential_sparse(br, tabs.dc[sc.td[0]], tabs.ac[sc.ta[0]], pred[0], w)) != kEntropyOk) return st;
+                until_restart--;
+            }
+    } else {
+        for (int my = 0; my < f.mcus_y; my++)
+            for (int mx = 0; mx < f.mcus_x; mx++) {
+                if (sc.restart_interval && until_restart == 0) {
+                    if ((st = take_restart(br, next_rst)) != kEntropyOk) return st;
+                    pred[0] = pred[1] = pred[2] = pred[3] = 0;
+                    until_restart = sc.restart_interval;
+                }
+                for (int i = 0; i < sc.ncomp; i++) {
+                    const int ci = sc.comp_index[i];
+                    const Component& k = f.comp[ci];
+                    for (int v = 0; v < k.v; v++)
+                        for (int hh = 0; hh < k.h; hh++) {
+                            table[ci][(size_t)(my * k.v + v) * k.blocks_w + (size_t)mx * k.h + hh] = (uint32_t)(w - out);
+                            if ((st = decode_block_sequential_sparse(br, tabs.dc[sc.td[i]], tabs.ac[sc.ta[i]], pred[i], w)) != kEntropyOk) return st;
+                        }
+                }
+                until_restart--;
+            }
+    }
+    if (br.overran()) return kEntropyTruncated;
+    *out_size = (size_t)(w - out);
+    return kEntropyOk;
+}
 
 EntropyStatus decode_coefficients(const uint8_t* data, size_t size, const FrameInfo& f, int16_t* const coef[4], uint32_t coef_or[4])
 {

@@ -187,6 +187,30 @@ hipjpegStatus_t hipjpegEntropyDecodeHost(const uint8_t* data, size_t length, int
     });
 }
 
+hipjpegStatus_t hipjpegEntropyDecodeHostSparse(const uint8_t* data, size_t length, uint8_t* stream, size_t capacity_bytes, size_t* stream_bytes,
+                                               uint64_t table_offsets[4])
+{
+    return guarded([&]() -> hipjpegStatus_t {
+    if (!data || !stream || !stream_bytes) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    FrameInfo f;
+    ParseStatus ps = parse_jpeg(data, length, &f);
+    if (ps != kParseOk) return status_from_parse(ps);
+    if (!sparse_staging_applies(f)) return HIPJPEG_STATUS_UNSUPPORTED;
+    if (sparse_stream_capacity(f) > capacity_bytes) return HIPJPEG_STATUS_BUFFER_TOO_SMALL;
+    size_t blocks = 0;
+    for (int c = 0; c < f.ncomp; c++) {
+        if (table_offsets) table_offsets[c] = blocks;
+        blocks += (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+    }
+    switch (decode_coefficients_sparse(data, length, f, stream, stream_bytes)) {
+    case kEntropyOk: return HIPJPEG_STATUS_SUCCESS;
+    case kEntropyTruncated: return HIPJPEG_STATUS_TRUNCATED;
+    case kEntropyMissingTable: return HIPJPEG_STATUS_BAD_JPEG;
+    default: return HIPJPEG_STATUS_CORRUPT;
+    }
+    });
+}
+
 hipjpegStatus_t hipjpegEntropyDecodeGpuAlgorithmHost(const uint8_t* data, size_t length, int16_t* coef, size_t coef_capacity_bytes,
                                                      uint64_t comp_offsets[4], int32_t* sync_passes)
 {
@@ -466,6 +490,16 @@ hipjpegStatus_t hipjpegDecodeBatchEntropyStats(hipjpegHandle_t handle, int32_t* 
 }
 
 int32_t hipjpegDecodeBatchZeroCopyImages(hipjpegHandle_t handle) { return handle ? handle->cur().zero_copy_images() : -1; }
+
+hipjpegStatus_t hipjpegDecodeBatchTransferStats(hipjpegHandle_t handle, uint64_t* h2d_bytes, int32_t* sparse_images)
+{
+    return guarded([&]() -> hipjpegStatus_t {
+    if (!handle) return HIPJPEG_STATUS_INVALID_ARGUMENT;
+    if (h2d_bytes) *h2d_bytes = handle->cur().h2d_bytes();
+    if (sparse_images) *sparse_images = handle->cur().sparse_images();
+    return HIPJPEG_STATUS_SUCCESS;
+    });
+}
 
 int32_t hipjpegTestScanChunkDrops(const uint8_t* data, size_t length, int scan_index, uint32_t* drops, int32_t capacity)
 {

@@ -71,6 +71,7 @@ struct DevWalker {
     uint32_t* block_pos;
     uint32_t nblocks;
     bool aborted;
+    uint32_t waited;                         // 10 ns ticks spent in wait_for (profiling aid)
 
     // 64 words from word `base` on, as they lie in memory (the address is clamped instead of branched around, so that the
     // load needs no exec mask and nothing waits for it here); swap() turns them MSB first and fills in ones behind the end
@@ -155,13 +156,20 @@ struct DevWalker {
     }
     __device__ __forceinline__ bool wait_for(const uint32_t* counter, uint32_t above)
     {
+        unsigned long long w0 = 0;
+        bool slept = false;
         while (uni(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= above) {
             if (uni(__hip_atomic_load(&sh->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
                 aborted = true;
                 return false;
             }
+            if (!slept) {
+                slept = true;
+                w0 = wall_clock64();
+            }
             __builtin_amdgcn_s_sleep(2);
         }
+        if (slept) waited += (uint32_t)(wall_clock64() - w0);
         return true;
     }
     __device__ __forceinline__ void group_begin(uint32_t gi)
@@ -272,6 +280,7 @@ __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint
     DevWalker w;
     w.lane = lane;
     w.aborted = false;
+    w.waited = 0;
     for (int d = 0; d < (int)im.dc_len; d++) {
         const ProgScan& sc = im.scan[im.dc_chain[d]];
         const HuffImage& hi = himgs[sc.huff_image];
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         w.block_pos = sc.block_pos;
         w.nblocks = sc.nblocks;
         w.aborted = false;
+        w.waited = 0;
         w.nz = 0;
         w.zpos = 0;
         w.table = slot;
@@ -406,7 +416,10 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         w.predecode();
         const unsigned long long t0 = wall_clock64();
         ok = prog_walk_ac(w, (int)sc.ss, (int)sc.se, (int)sc.ah, sc.nblocks, hi.total_bits);
-        if (lane == 0) im.scan[im.chain[c][a]].walk_ticks = (uint32_t)(wall_clock64() - t0);
+        if (lane == 0) {
+            im.scan[im.chain[c][a]].walk_ticks = (uint32_t)(wall_clock64() - t0);
+            im.scan[im.chain[c][a]].wait_ticks = w.waited;
+        }
         if (w.aborted) ok = false;
         if (!ok && lane == 0) __hip_atomic_store(&sh.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }

@@ -63,6 +63,8 @@ struct alignas(16) ProgScan {
     uint32_t ss, se, ah, al;
     uint32_t stage;           // AC scans: position in the component's chain (0 = first)
     uint32_t walk_ticks;      // written by the walk kernel: how long this scan's walk took, in 10 ns ticks (profiling aid)
+    uint32_t wait_ticks;      // ... of which the wave spent waiting for its pipeline neighbours (history ring full / empty)
+    uint32_t pad_ticks[3];
 };
 
 struct alignas(16) ProgImage {

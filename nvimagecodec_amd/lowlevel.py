@@ -18,6 +18,38 @@ def _as_u8(data):
     return np.frombuffer(bytes(data), dtype=np.uint8)
 
 
+def entropy_decode_host_sparse(data):
+    """The host entropy stage's zero-run-compressed stream of a picture, expanded again: per component int16 [blocks_h, blocks_w, 64] in
+    NATURAL (row-major) order like entropy_decode_host + the stream's size in bytes.  Raises HipJpegError(UNSUPPORTED) for frames the format
+    does not cover (progressive, several scans)."""
+    a = _as_u8(data)
+    info = get_image_info(data)
+    nblocks = [bh * bw for bh, bw in zip(info["blocks_h"], info["blocks_w"])]
+    cap = sum(nblocks) * 200 + 64
+    buf = np.zeros(cap, dtype=np.uint8)
+    n = ctypes.c_size_t()
+    toff = (ctypes.c_uint64 * 4)()
+    st = N.load().hipjpegEntropyDecodeHostSparse(a.ctypes.data, a.size, buf.ctypes.data, cap, ctypes.byref(n), toff)
+    if st:
+        raise N.HipJpegError(st, "hipjpegEntropyDecodeHostSparse")
+    tables = buf[: sum(nblocks) * 4].view(np.uint32)
+    out = []
+    for c, nb in enumerate(nblocks):
+        blocks = np.zeros((nb, 64), dtype=np.int16)
+        for b in range(nb):
+            off = int(tables[int(toff[c]) + b])
+            if off == 0:
+                continue
+            k = int(buf[off])
+            blocks[b, 0] = np.frombuffer(buf[off + 1:off + 3].tobytes(), dtype="<i2")[0]
+            for e in range(k):
+                r = off + 3 + 3 * e
+                blocks[b, int(buf[r])] = np.frombuffer(buf[r + 1:r + 3].tobytes(), dtype="<i2")[0]
+        blk = blocks.reshape(info["blocks_h"][c], info["blocks_w"][c], 8, 8)  # device layout: [column][row]
+        out.append(np.ascontiguousarray(blk.transpose(0, 1, 3, 2)).reshape(info["blocks_h"][c], info["blocks_w"][c], 64))
+    return out, int(n.value)
+
+
 def get_image_info(data):
     a = _as_u8(data)
     info = N.ImageInfo()
@@ -278,8 +310,11 @@ class BatchDecoder:
         N.load().hipjpegDecodeBatchStats(self._h, ctypes.addressof(units), ctypes.byref(cb), ctypes.byref(ob))
         gi, sl, sb = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_uint64()
         N.load().hipjpegDecodeBatchEntropyStats(self._h, ctypes.byref(gi), ctypes.byref(sl), ctypes.byref(sb))
+        h2d, sp = ctypes.c_uint64(), ctypes.c_int32()
+        N.load().hipjpegDecodeBatchTransferStats(self._h, ctypes.byref(h2d), ctypes.byref(sp))
         return dict(units=list(units), coef_bytes=cb.value, output_bytes=ob.value, gpu_entropy_images=gi.value, sync_launches=sl.value,
-                    stream_bytes=sb.value, zero_copy_images=int(N.load().hipjpegDecodeBatchZeroCopyImages(self._h)))
+                    stream_bytes=sb.value, zero_copy_images=int(N.load().hipjpegDecodeBatchZeroCopyImages(self._h)), h2d_bytes=h2d.value,
+                    sparse_images=sp.value)
 
     def statuses(self, n):
         st = (ctypes.c_int * n)()

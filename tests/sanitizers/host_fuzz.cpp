@@ -41,6 +41,44 @@ static void run_one(const std::vector<uint8_t>& bytes)
     }
     const int host = decode_coefficients(data, length, f, pa);
     g_decoded += host == kEntropyOk;
+    if (sparse_staging_applies(f)) {
+        // the zero-run-compressed writer (what crosses PCIe for host-decoded pictures): same verdict as the dense decoder, and a stream
+        // that expands to the dense blocks -- under the sanitizers, on mutated input
+        std::vector<uint8_t> stream(sparse_stream_capacity(f));
+        size_t bytes = 0;
+        const int sp = decode_coefficients_sparse(data, length, f, stream.data(), &bytes);
+        if ((sp == kEntropyOk) != (host == kEntropyOk)) {
+            g_mismatch++;
+            fprintf(stderr, "sparse and dense host decoders disagree on the verdict (%d vs %d)\n", sp, host);
+        } else if (sp == kEntropyOk) {
+            if (bytes > stream.size()) abort();
+            const uint32_t* table = reinterpret_cast<const uint32_t*>(stream.data());
+            size_t first = 0;
+            for (int c = 0; c < f.ncomp; c++) {
+                const size_t nb = (size_t)f.comp[c].blocks_w * f.comp[c].blocks_h;
+                for (size_t b2 = 0; b2 < nb; b2++) {
+                    int16_t blk[64] = {0};
+                    const uint32_t off = table[first + b2];
+                    if (off) {
+                        if (off + 3 > bytes) abort();
+                        const uint8_t* rec = stream.data() + off;
+                        const int k = rec[0];
+                        if (off + 3 + 3 * (size_t)k > bytes) abort();
+                        blk[0] = (int16_t)(rec[1] | (rec[2] << 8));
+                        for (int e = 0; e < k; e++) blk[rec[3 + 3 * e] & 63] = (int16_t)(rec[4 + 3 * e] | (rec[5 + 3 * e] << 8));
+                    }
+                    const size_t by = b2 / f.comp[c].blocks_w, bx = b2 % f.comp[c].blocks_w;
+                    const bool coded = off != 0 || (by < (size_t)(f.comp[c].samp_h + 7) / 8 && bx < (size_t)(f.comp[c].samp_w + 7) / 8);
+                    if (coded && memcmp(blk, pa[c] + b2 * 64, 128) != 0) {
+                        g_mismatch++;
+                        fprintf(stderr, "sparse stream differs from the dense blocks (component %d block %zu)\n", c, b2);
+                        break;
+                    }
+                }
+                first += nb;
+            }
+        }
+    }
     const bool prog = gpu_progressive_eligible(f);
     if (!prog && !gpu_entropy_eligible(f)) return;
     int passes = 0;

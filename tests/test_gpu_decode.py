@@ -243,3 +243,36 @@ def test_out_of_gamut_vectors_from_libjpeg_turbo(dec, gpu_huffman):
             got = o.cpu().numpy()
             ref = conv(refs[i])
             assert np.array_equal(got, ref), (entries[i]["name"], fmt, int((got != ref).sum()))
+
+
+def test_zero_run_compressed_staging_of_host_decoded_pictures(dec):
+    """Host Huffman decoding (the north-star split): sequential pictures cross PCIe as sparse streams (csrc/entropy_decode.h) that the pixel
+    kernels expand in LDS; progressive and multi-scan pictures stay dense; both kinds in one batch with GPU-decoded neighbours.  Every golden,
+    every output layout the kernels specialise, bit-exact; the transfer shrinks to a fraction of the dense blocks."""
+    import json
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        entries = json.load(f)["decode"]
+    cases = [load_decode_case(e) for e in entries]
+    jpegs = [c[0] for c in cases]
+    for fmt in ("rgb", "rgb_planar", "yuv_planar"):
+        outs, st = dec.decode(jpegs, fmt=fmt, gpu_huffman=False)
+        _sync()
+        stats = dec.stats()
+        n_seq = sum(1 for e in entries if not e["progressive"])
+        assert 0 < stats["sparse_images"] <= n_seq and stats["sparse_images"] >= n_seq - 20
+        for e, (jpeg, rgb), o in zip(entries, cases, outs):
+            if fmt == "yuv_planar":
+                for a, b in zip(o, oracle.decode_planes(jpeg)):
+                    assert np.array_equal(a.cpu().numpy(), b), e["name"]
+                continue
+            ref = rgb if rgb is not None else oracle.decode(jpeg)
+            if fmt == "rgb_planar":
+                ref = ref.transpose(2, 0, 1)
+            assert np.array_equal(o.cpu().numpy(), ref), (e["name"], fmt)
+    big = [oracle.encode(synth_image(1920, 1080, seed=11 + k), "420", 90) for k in range(2)] + [oracle.encode(synth_image(1001, 701, seed=3), "422", 75)]
+    outs, st = dec.decode(big, gpu_huffman=False)
+    _sync()
+    stats = dec.stats()
+    assert stats["sparse_images"] == 3 and stats["h2d_bytes"] < 0.45 * stats["coef_bytes"], stats
+    for j, o in zip(big, outs):
+        assert np.array_equal(o.cpu().numpy(), oracle.decode(j))

@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 HELPER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "decode_goldens.py")
 
 
-@pytest.mark.parametrize("switches", [{"HIPJPEG_DEVICE_DESTUFF_COUNT": "1"}, {"HIPJPEG_TAIL_AFTER": "1"}, {"HIPJPEG_FUSED_DECODE": "1"},
+@pytest.mark.parametrize("switches", [{"HIPJPEG_DEVICE_DESTUFF_COUNT": "1"}, {"HIPJPEG_TAIL_AFTER": "1"}, {"HIPJPEG_FUSED_DECODE": "1"}, {"HIPJPEG_DENSE_STAGING": "1"},
                                       {"HIPJPEG_DEVICE_DESTUFF_COUNT": "1", "HIPJPEG_TAIL_AFTER": "3", "HIPJPEG_FUSED_DECODE": "1"}],
-                         ids=["device_destuff_count", "tail_after_1", "fused_decode", "all"])
+                         ids=["device_destuff_count", "tail_after_1", "fused_decode", "dense_staging", "all"])
 def test_goldens_under_switch(switches):
     env = dict(os.environ)
     env.update(switches)

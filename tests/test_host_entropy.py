@@ -109,3 +109,37 @@ def test_marker_walk_at_every_alignment_with_restart_markers_fill_bytes_and_trai
         for cut in range(len(base) - 40, len(base) - 2, 3):
             with pytest.raises(N.HipJpegError):
                 lowlevel.entropy_decode_host(base[:cut])
+
+
+_SPARSE = [e for e in _M["decode"] if not e["progressive"] and e["width"] * e["height"] <= 130 * 70]
+
+
+@pytest.mark.parametrize("entry", _SPARSE, ids=lambda e: e["name"])
+def test_sparse_stream_expands_to_the_dense_blocks(entry):
+    """Zero-run-compressed staging (round 3; csrc/entropy_decode.h): for host-decoded sequential pictures the stream of per-block records the
+    device receives must hold exactly the coefficients of the dense decode -- restart intervals, every sampling, gray, odd sizes, MCU padding."""
+    jpeg, _ = load_decode_case(entry)
+    try:
+        sparse, nbytes = lowlevel.entropy_decode_host_sparse(jpeg)
+    except N.HipJpegError as e:
+        assert "UNSUPPORTED" in str(e)   # several scans: stays dense
+        return
+    dense, _ = lowlevel.entropy_decode_host(jpeg)
+    for c, (a, b) in enumerate(zip(sparse, dense)):
+        assert np.array_equal(a, b), f"component {c}"
+    assert nbytes < lowlevel.get_image_info(jpeg)["coef_bytes"] * 1.6
+
+
+def test_sparse_stream_is_a_fraction_of_the_dense_blocks():
+    from nvimagecodec_amd.synth import synth_image
+    jpeg = oracle.encode(synth_image(640, 480, seed=3), "420", 90)
+    _, nbytes = lowlevel.entropy_decode_host_sparse(jpeg)
+    dense = lowlevel.get_image_info(jpeg)["coef_bytes"]
+    assert nbytes < 0.45 * dense, (nbytes, dense)
+    # progressive: the format does not apply
+    prog = load_decode_case(next(e for e in _M["decode"] if e["progressive"]))[0]
+    with pytest.raises(N.HipJpegError):
+        lowlevel.entropy_decode_host_sparse(prog)
+    # a truncated stream is named as such
+    with pytest.raises(N.HipJpegError):
+        lowlevel.entropy_decode_host_sparse(jpeg[: len(jpeg) // 2])
