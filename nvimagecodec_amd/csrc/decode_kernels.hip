@@ -708,7 +708,9 @@ __device__ __forceinline__ void luma_color_body(const DecodeImage& im, const Wor
         unsigned dc = 0;
         if (valid) dc = *(const HJ_GLOBAL unsigned short*)((const HJ_GLOBAL char*)im.comp[0].dc + (unsigned)(by * bw + bx) * 2u);
         const int jrow = by_wave + (lane >> row_shift), jcol = bx0 + (lane & col_mask);  // the block lane j < 32 decodes
-        fused_decode_slots(*hi, pool, *fs, 0, jrow < bh && jcol < bw && jcol * 8 < W && jrow * 8 < H, jrow, jcol, lds_wave, lane);
+        // every block of the grid inside the tile, visible or not: the decode is also the stream's CHECK (the block pass decoded them all),
+        // and damage that sits in the MCU padding must flag the image like damage anywhere else
+        fused_decode_slots(*hi, pool, *fs, 0, jrow < bh && jcol < bw, jrow, jcol, lds_wave, lane);
         read_half_block(lds_wave, lane, dc, true, cols);
     } else
         fetch_tile_half_block(im.comp[0], by_wave, bx0, row_shift, col_mask, bw, bh, lds_wave, lane, cols);

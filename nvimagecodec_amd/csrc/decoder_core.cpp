@@ -758,6 +758,13 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
     static const bool fused_enabled = getenv("HIPJPEG_FUSED_DECODE") != nullptr && atoi(getenv("HIPJPEG_FUSED_DECODE")) != 0;
     fused_ = fused_enabled;
     const int n = (int)images_.size();
+    // all or nothing per batch: with fused_ set the block pass is not launched at all, so every GPU-decoded baseline picture must be one the
+    // FUSED builds cover completely -- a region of interest launches only the tiles that touch it, the other blocks would go undecoded and
+    // unchecked
+    for (int i = 0; i < n && fused_; i++) {
+        const PlannedImage& im = images_[i];
+        if (im.status == HIPJPEG_STATUS_SUCCESS && im.gpu_entropy && !im.gpu_prog && im.has_transform) fused_ = false;
+    }
     for (int i = 0; i < n; i++) {
         PlannedImage& im = images_[i];
         if (statuses) statuses[i] = im.status;

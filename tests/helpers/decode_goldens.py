@@ -57,6 +57,14 @@ def main():
         for i, (a, b) in enumerate(zip(outs_g, ref)):
             if st_h[i] == 0 and b is not None:
                 assert np.array_equal(a.cpu().numpy(), b), i
+        # found by tests/campaigns/fuzz_damage.py under this switch (round 3): damage that sits in a block of the MCU padding, which the FUSED
+        # luma kernel did not decode at first -- the stream's check must cover every block, visible or not
+        pad = open(os.path.join(GOLDEN, "damaged", "padding_block_damage.jpg"), "rb").read()
+        trio = [small[0], pad, small[1]]
+        _, st_h3 = dec.decode(trio, fmt="rgb", gpu_huffman=False, check=False)
+        _, st_g3 = dec.decode(trio, fmt="rgb", gpu_huffman=True, check=False)
+        torch.cuda.synchronize()
+        assert list(st_g3) == list(st_h3) and st_h3[1] != 0, (list(st_g3), list(st_h3))
         print("fused: damaged neighbours ok,", sum(1 for s in st_h if s), "refused,", dec.host_fallbacks(), "taken over by the host decoder")
     print("goldens ok", len(jpegs), "flavours", plane, luma)
 
