@@ -44,34 +44,13 @@ struct WalkShared {
 typedef unsigned long long WalkRing[kProgRing][kProgGroup];
 static_assert(sizeof(WalkRing) == (size_t)kProgRing * kProgGroup * 8, "progressive_gpu_host.h kProgRingBytes");
 
-// The scalar machine of prog_walk_ac (progressive_gpu_core.h) on one wave.
-struct DevWalker {
-    // stream: the only state of the reader is the bit position p.  Words vbase .. vbase + 63 sit in W (lane j = word vbase + j,
-    // MSB first), W1 holds the same shifted by one lane (lane j = word vbase + j + 1), so a 64-bit window is two readlanes at
-    // ONE index.  X = the following 64 words (needed for W1's last lane), Y = the 64 words after those, as loaded, still in
-    // flight: requested 4096 bits before they are used.
+// The words of one scan's stream, 192 of them at a time in three VGPRs.
+struct WordStream {
     const HJ_GLOBAL uint32_t* g;
     uint32_t nwords;
     uint32_t lane;
-    uint32_t W, W1, X, Y;
-    uint32_t vbase;
-    uint32_t p;
-    // table
-    uint32_t pre, pbase;            // symbols decoded ahead: per lane, for the bit offsets pbase + lane
-    const HJ_LDS uint16_t* table;   // the scan's full lookup table
-    // per group
-    uint32_t hlo, hhi, pos_out;     // per lane: block 64 g + lane
-    uint32_t zpos;                  // per lane i: position of the i-th zero-history coefficient of the current block
-    int nz;
-    // pipeline
-    WalkShared* sh;
-    bool has_prev, has_next;                 // the scan refines what another scan of the component left / is refined by another
-    HJ_LDS WalkRing* ring_in;                // history from the predecessor; ring_in + 1 = ring to the successor
-    int self;                                // this wave's index into done[] / taken[] (predecessor self - 1, successor self + 1)
-    uint32_t* block_pos;
-    uint32_t nblocks;
-    bool aborted;
-    uint32_t waited;                         // 10 ns ticks spent in wait_for (profiling aid)
+    uint32_t W, X, Y;  // W: words vbase .. vbase + 63 (lane j = word vbase + j, MSB first), X: the 64 after those, Y: the 64 after X, as
+    uint32_t vbase;    // loaded, still in flight -- requested 4096 bits before they are used
 
     // 64 words from word `base` on, as they lie in memory (the address is clamped instead of branched around, so that the
     // load needs no exec mask and nothing waits for it here); swap() turns them MSB first and fills in ones behind the end
@@ -82,42 +61,56 @@ struct DevWalker {
         return g[i < nwords ? i : nwords - 1];
     }
     __device__ __forceinline__ uint32_t swap(uint32_t raw, uint32_t base) const { return base + lane < nwords ? __builtin_bswap32(raw) : ~0u; }
+    __device__ __forceinline__ void open(const uint32_t* stream, uint32_t stream_words)
+    {
+        g = (const HJ_GLOBAL uint32_t*)stream;
+        nwords = stream_words;
+        load(0);
+    }
+    __device__ __forceinline__ void load(uint32_t base)
+    {
+        vbase = base;
+        W = swap(fetch_raw(base), base);
+        X = swap(fetch_raw(base + 64), base + 64);
+        Y = fetch_raw(base + 128);
+    }
+    // word `index` (>= vbase + 64) becomes one of W's: the usual step (the next 64 words become the current ones) or a long skip
+    __device__ __forceinline__ void seek(uint32_t index)
+    {
+        if (index - vbase < 128u) {
+            vbase += 64;
+            W = X;
+            X = swap(Y, vbase + 64);
+            Y = fetch_raw(vbase + 128);
+        } else {
+            load(index & ~63u);
+        }
+    }
+};
+
+// Bit reader of the DC first scans: the only state is the bit position p.  W1 holds W shifted by one lane (lane j = word vbase + j + 1),
+// so a 64-bit window is two readlanes at ONE index.
+struct DcReader : WordStream {
+    uint32_t W1;
+    uint32_t p;
     __device__ __forceinline__ void make_shifted()
     {
         const uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 1) & 63u) * 4u), (int)W);  // lane j <- lane j + 1
         const uint32_t first_of_next = lane_read(X, 0);
         W1 = lane == 63 ? first_of_next : up;
     }
-    __device__ __forceinline__ void reposition(uint32_t word_index)
-    {
-        if (word_index - vbase < 128u) {  // the usual step: the next 64 words become the current ones
-            vbase += 64;
-            W = X;
-            X = swap(Y, vbase + 64);
-        } else {                          // a long skip
-            vbase = word_index & ~63u;
-            W = swap(fetch_raw(vbase), vbase);
-            X = swap(fetch_raw(vbase + 64), vbase + 64);
-        }
-        Y = fetch_raw(vbase + 128);
-        make_shifted();
-    }
     __device__ __forceinline__ void start(const uint32_t* stream, uint32_t stream_words)
     {
-        g = (const HJ_GLOBAL uint32_t*)stream;
-        nwords = stream_words;
-        vbase = 0;
+        open(stream, stream_words);
         p = 0;
-        W = swap(fetch_raw(0), 0);
-        X = swap(fetch_raw(64), 64);
-        Y = fetch_raw(128);
         make_shifted();
     }
     __device__ __forceinline__ uint32_t window()
     {
         uint32_t i = (p >> 5) - vbase;
         if (__builtin_expect(i >= 64u, 0)) {  // rare: once per 2048 bits
-            reposition(p >> 5);
+            seek(p >> 5);
+            make_shifted();
             i = (p >> 5) - vbase;
         }
         const unsigned long long two = ((unsigned long long)lane_read(W, i) << 32) | lane_read(W1, i);
@@ -125,34 +118,78 @@ struct DevWalker {
     }
     __device__ __forceinline__ void advance(uint32_t n) { p += n; }
     __device__ __forceinline__ uint32_t pos() const { return p; }
-    // Symbols decoded ahead: lane o of `pre` = the lookup-table entry of the code that starts at bit pbase + o, for all 64
-    // offsets at once (vector work: two crossbar reads for the stream words, the table lookups in LDS).  The walk's dependent
-    // chain then costs ONE readlane per symbol instead of two for the window, a shift, and one for the table.
-    __device__ __forceinline__ void predecode()
+};
+
+// The scalar machine of prog_walk_ac (progressive_gpu_core.h) on one wave.
+// Symbols are decoded ahead one 64-bit WINDOW of the stream at a time: lane l = whatever code starts at bit 64 wv + l (its 32 stream
+// bits, its lookup-table entry, the entry's fast view) -- vector work: three readlanes for the window's words, a funnel shift, one or
+// two table lookups in LDS.  The windows are aligned, so the next one is known before the walk gets there: its words are picked and its
+// first-level lookups issued when the walk ENTERS the current window, and nothing waits for them until it leaves it.
+struct DevWalker : WordStream {
+    uint32_t wv;                       // the current window: bits [64 wv, 64 wv + 64)
+    uint32_t cur, cur_fast, cur_win;   // per lane l, for the code at bit 64 wv + l: table entry, prog_fast_entry of it, the 32 bits from there on
+    uint32_t nxt, nxt_win;             // window wv + 1: first-level entry (lookup in flight), bits
+    bool refine;                       // a refinement scan (decides what counts as a plain symbol)
+    const HJ_LDS uint16_t* table;      // the scan's full lookup table
+    // per group
+    uint32_t hlo, hhi, pos_out;        // per lane: block 64 g + lane
+    uint32_t zpos, zpos_next;          // per lane i: (position of the i-th zero-history coefficient of the current / the next block) - i
+    uint32_t nz, nz_next;
+    // pipeline
+    WalkShared* sh;
+    bool has_prev, has_next;                 // the scan refines what another scan of the component left / is refined by another
+    HJ_LDS WalkRing* ring_in;                // history from the predecessor; ring_in + 1 = ring to the successor
+    int self;                                // this scan's index into done[] / taken[] (predecessor self - 1, successor self + 1)
+    uint32_t* block_pos;
+    uint32_t nblocks;
+    bool aborted;
+    uint32_t waited;                         // 10 ns ticks spent in wait_for (profiling aid)
+
+    // first-level decode of window `target`; the lookups stay in flight
+    __device__ __forceinline__ void issue(uint32_t target)
     {
-        pbase = p;
-        const uint32_t q = p + lane;
-        uint32_t wi = (q >> 5) - vbase;  // p's word lies inside W (window() / symbol() make sure); q's may reach two words into X
-        const uint32_t x0 = lane_read(X, 0), x1 = lane_read(X, 1), x2 = lane_read(X, 2);
-        const uint32_t in_w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((wi & 63u) * 4u), (int)W);
-        const uint32_t in_w1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((wi & 63u) * 4u), (int)W1);
-        const uint32_t hi = wi < 64u ? in_w : (wi == 64u ? x0 : x1);
-        const uint32_t lo = wi < 64u ? in_w1 : (wi == 64u ? x1 : x2);
-        const uint32_t sh = q & 31u;
-        const uint32_t win = sh ? (hi << sh) | (lo >> (32u - sh)) : hi;
-        uint32_t e = table[win >> 24];
-        if (e & kProgLong) e = table[(e & 0x7FFFu) * 256u + ((win >> 16) & 255u)];
-        pre = e;
-    }
-    __device__ __forceinline__ uint32_t symbol()
-    {
-        uint32_t d = p - pbase;
-        if (__builtin_expect(d >= 64u, 0)) {
-            if (__builtin_expect((p >> 5) - vbase >= 64u, 0)) reposition(p >> 5);
-            predecode();
-            d = 0;
+        uint32_t i0 = 2u * target - vbase;  // the window's words: i0, i0 + 1 and (for the codes that start in its second half) i0 + 2
+        if (__builtin_expect(i0 >= 64u, 0)) {  // once per 32 windows
+            seek(2u * target);
+            i0 = 2u * target - vbase;
         }
-        return lane_read(pre, d);
+        const uint32_t w0 = lane_read(W, i0), w1 = lane_read(W, i0 + 1u);
+        const uint32_t w2 = i0 == 62u ? lane_read(X, 0) : lane_read(W, i0 + 2u);
+        const uint32_t hi = lane < 32u ? w0 : w1, lo = lane < 32u ? w1 : w2;
+        const uint32_t win = (uint32_t)(((((unsigned long long)hi << 32) | lo) << (lane & 31u)) >> 32);
+        nxt_win = win;
+        nxt = table[win >> 24];
+    }
+    // window wv + 1 becomes the current one
+    __device__ __forceinline__ void finish()
+    {
+        uint32_t e = nxt;
+        if (e & kProgLong) e = table[(e & 0x7FFFu) * 256u + ((nxt_win >> 16) & 255u)];
+        cur = e;
+        cur_win = nxt_win;
+        cur_fast = prog_fast_entry(e, refine);
+    }
+    __device__ __forceinline__ void start(const uint32_t* stream, uint32_t stream_words)
+    {
+        open(stream, stream_words);
+        issue(0);
+        finish();
+        wv = 0;
+        issue(1);
+    }
+    // prog_walk_ac's view (progressive_gpu_core.h)
+    __device__ __forceinline__ uint32_t sym_base() const { return wv * 64u; }
+    __device__ __forceinline__ uint32_t fast_at(uint32_t d) const { return lane_read(cur_fast, d); }
+    __device__ __forceinline__ uint32_t sym_at(uint32_t d) const { return lane_read(cur, d); }
+    __device__ __forceinline__ uint32_t bits_at(uint32_t d) const { return lane_read(cur_win, d); }
+    __device__ __forceinline__ void sym_window(uint32_t at)
+    {
+        const uint32_t target = at >> 6;
+        if (target == wv) return;
+        if (__builtin_expect(target != wv + 1u, 0)) issue(target);  // a long end-of-band run has skipped windows
+        finish();
+        wv = target;
+        issue(target + 1u);
     }
     __device__ __forceinline__ bool wait_for(const uint32_t* counter, uint32_t above)
     {
@@ -210,17 +247,23 @@ struct DevWalker {
             if (lane == 0) __hip_atomic_store(&sh->done[self], gi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    __device__ __forceinline__ void zeros_build(unsigned long long z)
+    // rank/select over the set bits of z, for the NEXT block: the crossbar write stays in flight until zeros_take()
+    __device__ __forceinline__ void zeros_prepare(unsigned long long z)
     {
         const uint32_t zl = (uint32_t)z, zh = (uint32_t)(z >> 32);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(zh, __builtin_amdgcn_mbcnt_lo(zl, 0u));  // set bits of z below this lane
-        nz = __popcll(z);
+        nz_next = uni((uint32_t)__popcll(z));
         const bool mine = (z >> lane) & 1ull;
-        const uint32_t target = mine ? rank : (uint32_t)nz + (lane - rank);  // a full permutation: zeros first, in order
-        zpos = (uint32_t)__builtin_amdgcn_ds_permute((int)(target * 4u), (int)lane);
+        const uint32_t target = mine ? rank : nz_next + (lane - rank);  // a full permutation: zeros first, in order
+        zpos_next = (uint32_t)__builtin_amdgcn_ds_permute((int)(target * 4u), (int)lane) - lane;  // lane i < nz: (position of the i-th zero) - i
     }
-    __device__ __forceinline__ int zeros_count() const { return nz; }
-    __device__ __forceinline__ int zero_at(int i) const { return (int)lane_read(zpos, (uint32_t)i); }
+    __device__ __forceinline__ void zeros_take()
+    {
+        zpos = zpos_next;
+        nz = uni(nz_next);
+    }
+    __device__ __forceinline__ uint32_t zeros_count() const { return nz; }
+    __device__ __forceinline__ uint32_t zero_gap(uint32_t i) const { return lane_read(zpos, i); }
 };
 
 // one scan's lookup table: pool (global) -> LDS slot, by one wave
@@ -277,10 +320,8 @@ __device__ __forceinline__ void dc_block_address(const ProgImage& im, const Prog
 
 __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint16_t* tables, uint32_t slot_words, uint32_t lane)
 {
-    DevWalker w;
+    DcReader w;
     w.lane = lane;
-    w.aborted = false;
-    w.waited = 0;
     for (int d = 0; d < (int)im.dc_len; d++) {
         const ProgScan& sc = im.scan[im.dc_chain[d]];
         const HuffImage& hi = himgs[sc.huff_image];
@@ -383,14 +424,30 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         ok = walk_dc_chain(im, himgs, tables, slot_words, lane);
     } else {
         // which component's chain, which stage of it; rings of the chains in front (a chain of n scans has n - 1 hand-overs)
-        int a = wave - 1, c = 0, ring_base = 0;
-        while (c < 4 && a >= (int)uni(im.chain_len[c])) {
-            const int n = (int)uni(im.chain_len[c]);
-            a -= n;
-            ring_base += n > 0 ? n - 1 : 0;
-            c++;
+        // Waves are dealt to the scans LAST stage first, component after component: the last refinement scans are the long ones
+        // (DESIGN.md 3.5), the hardware deals a workgroup's waves to the four SIMDs in turn, and three long walks on one SIMD share
+        // its issue slot while another SIMD idles.  `self` (the index into done[] / taken[]) stays the position in chain order.
+        int a = -1, c = 0, ring_base = 0, self = 1;
+        {
+            int left = wave - 1;
+            for (int level = 0; level < kProgMaxStages && a < 0; level++)
+                for (int cc = 0; cc < 4; cc++) {
+                    const int n = (int)uni(im.chain_len[cc]);
+                    if (n <= level) continue;
+                    if (left-- == 0) {
+                        c = cc;
+                        a = n - 1 - level;
+                        break;
+                    }
+                }
+            if (a < 0 || c >= (int)im.ncomp) return;
+            for (int cc = 0; cc < c; cc++) {
+                const int n = (int)uni(im.chain_len[cc]);
+                ring_base += n > 0 ? n - 1 : 0;
+                self += n;
+            }
+            self += a;
         }
-        if (c >= 4 || c >= (int)im.ncomp) return;
         const int chain_len = (int)uni(im.chain_len[c]);
         const ProgScan& sc = im.scan[im.chain[c][a]];
         const HuffImage& hi = himgs[sc.huff_image];
@@ -404,16 +461,16 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         w.has_prev = a > 0;
         w.has_next = a + 1 < chain_len;
         w.ring_in = rings + (ring_base + a - 1);  // not dereferenced without a predecessor; ring_in + 1 = the ring to the successor
-        w.self = wave;
+        w.self = self;
         w.block_pos = sc.block_pos;
         w.nblocks = sc.nblocks;
         w.aborted = false;
         w.waited = 0;
-        w.nz = 0;
-        w.zpos = 0;
+        w.nz = w.nz_next = 0;
+        w.zpos = w.zpos_next = 0;
         w.table = slot;
+        w.refine = uni(sc.ah) != 0;
         w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
-        w.predecode();
         const unsigned long long t0 = wall_clock64();
         ok = prog_walk_ac(w, (int)sc.ss, (int)sc.se, (int)sc.ah, sc.nblocks, hi.total_bits);
         if (lane == 0) {

@@ -102,96 +102,158 @@ HJ_HD int prog_popc64(uint64_t v)
 }
 
 // ---------------------------------------------------------------------------------------------------------- the walk
-// Walks one AC scan and records the start of every block.  `W` supplies the machine:
-//   uint32_t symbol()           lookup-table entry for the code at the current position (0 = invalid), nothing consumed
-//   uint32_t window()           the next 32 bits of the stream, MSB first, without consuming (end-of-band run lengths only)
-//   void advance(uint32_t n)    any n: the position moves on by n bits
-//   uint32_t pos()              bit position of the next unread bit
+// "Fast" view of a lookup-table entry, made once per decoded-ahead symbol (vector work on the device), read by the walk's inner loops:
+// a PLAIN coefficient symbol -- first scans: any size s > 0; refinement scans: s == 1 -- becomes (run r << 16) | bits the symbol takes
+// (code + value bits, resp. code + sign bit); everything else (no such code, end of band, run of sixteen, a size a refinement scan may
+// not carry) becomes a run no band can hold, so the ONE bound check of the inner loop also sorts those out.
+constexpr uint32_t kProgNotPlain = 64u << 16;
+HJ_HD uint32_t prog_fast_entry(uint32_t e, bool refine)
+{
+    const uint32_t len = e & 31u, s = (e >> 5) & 15u, r = (e >> 9) & 15u;
+    const bool plain = refine ? s == 1u : s != 0u;
+    return plain ? (r << 16) | (len + s) : kProgNotPlain;
+}
+HJ_HD uint64_t prog_bit_set(uint64_t h, uint32_t t)  // t < 64
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("s_bitset1_b64 %0, %1" : "+s"(h) : "s"(t));  // the compiler spells it shift + or
+    return h;
+#else
+    return h | (1ull << (t & 63u));
+#endif
+}
+
+// Walks one AC scan and records the start of every block.  `W` supplies the machine.  Symbols are decoded ahead a WINDOW at a time:
+// for all 64 bit offsets of an aligned 64-bit stretch of the stream at once, whatever code would start there.
+//   uint32_t sym_base()            bit position the current window starts at
+//   uint32_t fast_at(uint32_t d)   prog_fast_entry of the code that starts at bit sym_base() + d; d >= 64 returns anything
+//   uint32_t sym_at(uint32_t d)    its lookup-table entry (0 = no such code), d < 64
+//   uint32_t bits_at(uint32_t d)   the 32 bits of the stream from bit sym_base() + d on, MSB first, d < 64
+//   void sym_window(uint32_t p)    make the window that holds bit p the current one
 //   void group_begin(uint32_t g)   history bitmaps of blocks [64 g, 64 g + 64) become available (waits for the previous stage)
 //   uint64_t hist(int j) / void set_hist(int j, uint64_t)   history bitmap of block j of the current group
 //   void set_pos(int j, uint32_t)  block_pos of block j of the current group
-//   void group_end(uint32_t g)  stores the positions, hands the bitmaps to the next stage
-//   void zeros_build(uint64_t z)   rank/select over the set bits of z:  int zeros_count(),  int zero_at(int i) = position of the
-//                                  i-th set bit (i < zeros_count())
-// Everything is wave-uniform on the device; the only state of the bit reader is the position (a symbol never needs more than
-// the 32 bits of one window: code <= 16 bits, end-of-band run length <= 14 bits), so a step is straight-line code.  A lone
-// wave pays ~9 cycles per dependent scalar instruction and ~24 more per taken branch or VGPR->SGPR read (tools/
-// scalar_chain_rate.hip), which is what bounds the walk: ~40 instructions per symbol.
+//   void group_end(uint32_t g)     stores the positions, hands the bitmaps to the next stage
+//   void zeros_prepare(uint64_t z) / void zeros_take()   rank/select over the set bits of z, prepared one block ahead, then made current:
+//                                  uint32_t zeros_count(),  uint32_t zero_gap(uint32_t i) = (position of the i-th set bit) - i
+// Everything is wave-uniform on the device; the position is base + d, locals here.  A lone wave pays ~9 cycles per dependent scalar
+// instruction and ~24 more per taken branch or VGPR->SGPR read (tools/scalar_chain_rate.hip), so what counts is the length of the path a
+// PLAIN symbol takes: the coefficient symbols -- nearly all symbols of the scans that bound a batch's latency, the last refinement scans
+//  -- have an inner loop with ONE exit: window exhausted (d >= 64 is added to the run), end of band, run of sixteen, a broken
+// stream and "band complete" all show as a run past the band's end and are told apart behind the exit.  In a refinement scan the position
+// of the next coefficient is not tracked at all: with g[i] = zero_gap(i) (how many non-zero-history coefficients lie in front of the i-th
+// zero-history one), a new coefficient behind r more zeros costs  code + sign + (g[zr + r] - g_prev)  bits, and k is g_prev + zr whenever
+// somebody asks.
 // Returns false when the stream breaks the rules (the host decoder then takes the image and names the error).
 template <class W>
 HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t total_bits)
 {
     const uint64_t band = prog_band_mask(ss, se);
+    const uint32_t last = (uint32_t)se;
     uint32_t eobrun = 0;
+    uint32_t base = w.sym_base();
+    uint32_t d = 0;  // the position is base + d
     bool ok = true;
     for (uint32_t g = 0; g * kProgGroup < nblocks; g++) {
         w.group_begin(g);
         const int n = (int)((nblocks - g * kProgGroup) < (uint32_t)kProgGroup ? (nblocks - g * kProgGroup) : (uint32_t)kProgGroup);
+        if (ah) w.zeros_prepare(~w.hist(0) & band);
         for (int j = 0; j < n; j++) {
             uint64_t h = w.hist(j);
+            if (ah) {
+                w.zeros_take();
+                if (j + 1 < n) w.zeros_prepare(~w.hist(j + 1) & band);  // the next block's, in the shadow of this block's walk
+            }
             if (HJ_UNLIKELY(eobrun != 0)) {
                 // inside an end-of-band run: a first scan has nothing for this block, a refinement scan one correction bit per
                 // coefficient of the band that is already non-zero
-                w.set_pos(j, w.pos() | kProgInRun);
-                if (ah) w.advance((uint32_t)prog_popc64(h & band));
+                w.set_pos(j, (base + d) | kProgInRun);
+                if (ah) d += (uint32_t)prog_popc64(h & band);
                 eobrun--;
                 continue;
             }
-            w.set_pos(j, w.pos());
-            int k = ss;
+            w.set_pos(j, base + d);
             if (ah == 0) {
-                while (k <= se) {
-                    const uint32_t e = w.symbol();
+                uint32_t k = (uint32_t)ss;
+                for (;;) {
+                    // plain coefficients: run of r zeros, then a coefficient of s bits
+                    uint32_t f = w.fast_at(d);
+                    uint32_t kk = k + (f >> 16) + (d & ~63u);
+                    while (HJ_LIKELY(kk <= last)) {
+                        h = prog_bit_set(h, kk);
+                        d += f & 0xFFFFu;
+                        k = kk + 1u;
+                        f = w.fast_at(d);
+                        kk = k + (f >> 16) + (d & ~63u);
+                    }
+                    if (k > last) break;  // the band is complete
+                    if (d >= 64u) {
+                        w.sym_window(base + d);
+                        const uint32_t nb = w.sym_base();
+                        d = base + d - nb;
+                        base = nb;
+                        continue;
+                    }
+                    const uint32_t e = w.sym_at(d);
                     const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
-                    if (HJ_UNLIKELY(len == 0)) { ok = false; break; }
-                    if (HJ_LIKELY(s != 0)) {
-                        k += (int)r;
-                        if (HJ_UNLIKELY(k > se)) { ok = false; break; }
-                        h |= 1ull << k;
-                        k++;
-                        w.advance(len + s);
-                    } else if (r == 15) {
+                    if (len == 0 || s != 0) { ok = false; break; }  // no such code / a run past the band's end
+                    if (r == 15) {
                         k += 16;
-                        w.advance(len);
+                        d += len;
+                        if (k > last) break;
                     } else {
-                        eobrun = (1u << r) - 1 + (r ? (w.window() << len) >> (32 - r) : 0u);
-                        w.advance(len + r);
+                        eobrun = (1u << r) - 1 + (r ? (w.bits_at(d) << len) >> (32 - r) : 0u);
+                        d += len + r;
                         break;
                     }
                 }
             } else {
-                w.zeros_build(~h & band);
-                const int nz = w.zeros_count();
-                int zr = 0;  // zero-history coefficients of the band below k
-                while (k <= se) {
-                    const uint32_t e = w.symbol();
+                const uint32_t nz = w.zeros_count();
+                uint32_t zr = 0;                 // zero-history coefficients of the band already passed
+                uint32_t gprev = (uint32_t)ss;   // (position of the next coefficient to look at) - zr
+                for (;;) {
+                    uint32_t q = d - gprev;
+                    // plain new coefficients: behind r zero-history coefficients; code, sign bit, then one correction bit for every
+                    // non-zero-history coefficient passed on the way
+                    uint32_t f = w.fast_at(d);
+                    uint32_t zi = zr + (f >> 16) + (d & ~63u);
+                    while (HJ_LIKELY(zi < nz)) {
+                        const uint32_t gz = w.zero_gap(zi);
+                        q += f & 0xFFFFu;
+                        d = q + gz;
+                        zr = zi + 1u;
+                        h = prog_bit_set(h, gz + zi);  // the coefficient's position
+                        gprev = gz;
+                        f = w.fast_at(d);
+                        zi = zr + (f >> 16) + (d & ~63u);
+                    }
+                    const uint32_t k = gprev + zr;  // position of the next coefficient to look at
+                    if (k > last) break;            // the band is complete
+                    if (d >= 64u) {
+                        w.sym_window(base + d);
+                        const uint32_t nb = w.sym_base();
+                        d = base + d - nb;
+                        base = nb;
+                        continue;
+                    }
+                    const uint32_t e = w.sym_at(d);
                     const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
-                    if (HJ_UNLIKELY(len == 0 || s > 1)) { ok = false; break; }
-                    if (HJ_LIKELY(s == 1)) {
-                        // a new coefficient: behind r zero-history coefficients; code, sign bit, then one correction bit for
-                        // every non-zero-history coefficient passed on the way
-                        const int zi = zr + (int)r;
-                        if (HJ_UNLIKELY(zi >= nz)) { ok = false; break; }
-                        const int t = w.zero_at(zi);
-                        w.advance(len + 1u + (uint32_t)(t - k - (int)r));
-                        h |= 1ull << t;
-                        k = t + 1;
-                        zr = zi + 1;
-                    } else if (r == 15) {
+                    if (len == 0 || s != 0) { ok = false; break; }  // no such code, a size other than 1, or a run past the last zero
+                    if (r == 15) {
                         // sixteen zero-history coefficients are skipped (or the rest of the band, if it has fewer)
-                        const int zi = zr + 15;
+                        zi = zr + 15;
                         if (zi >= nz) {
-                            w.advance(len + (uint32_t)prog_popc64(h & band & prog_from_mask(k)));
-                            k = se + 1;
-                        } else {
-                            const int t = w.zero_at(zi);
-                            w.advance(len + (uint32_t)(t - k - 15));
-                            k = t + 1;
-                            zr = zi + 1;
+                            d += len + (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));
+                            break;
                         }
+                        const uint32_t gz = w.zero_gap(zi);
+                        d += len + gz - gprev;
+                        gprev = gz;
+                        zr = zi + 1u;
+                        if (gz + zi >= last) break;
                     } else {
-                        eobrun = (1u << r) + (r ? (w.window() << len) >> (32 - r) : 0u) - 1;  // this block is the run's first
-                        w.advance(len + r + (uint32_t)prog_popc64(h & band & prog_from_mask(k)));  // + the rest of this block's band
+                        eobrun = (1u << r) + (r ? (w.bits_at(d) << len) >> (32 - r) : 0u) - 1;  // this block is the run's first
+                        d += len + r + (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));  // + the rest of this block's band
                         break;
                     }
                 }
@@ -203,10 +265,10 @@ HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t
         if (!ok) break;
         // once per 64 blocks (wave-uniform, nearly free): a walk that has left the data stops here instead of decoding the ones behind
         // the end as symbols for the rest of a forged frame; also keeps the 32-bit position far from kProgInRun's bit
-        if (HJ_UNLIKELY(w.pos() > total_bits)) { ok = false; break; }
+        if (HJ_UNLIKELY(base + d > total_bits)) { ok = false; break; }
     }
     // nothing may be read from behind the data (the host decoder calls that TRUNCATED)
-    if (ok && w.pos() > total_bits) ok = false;
+    if (ok && base + d > total_bits) ok = false;
     return ok;
 }
 

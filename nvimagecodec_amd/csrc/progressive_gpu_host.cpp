@@ -257,20 +257,39 @@ struct HostWalker {
     }
     void advance(uint32_t n) { p += n; }
     uint32_t pos() const { return p; }
-    uint32_t symbol() const { return host_lookup(table, window()); }
+    // prog_walk_ac's view of the symbols "decoded ahead": here every offset is looked up when it is asked for.  Indices wrap at 64
+    // like the lane select of the device's v_readlane, so a walk that relied on what an index >= 64 returns would show here too.
+    uint32_t wv = 0;      // current window: bits [64 wv, 64 wv + 64)
+    bool refine = false;
+    uint32_t sym_base() const { return wv * 64u; }
+    uint32_t bits_at(uint32_t d)
+    {
+        p = wv * 64u + (d & 63u);
+        return window();
+    }
+    uint32_t sym_at(uint32_t d) { return host_lookup(table, bits_at(d)); }
+    uint32_t fast_at(uint32_t d) { return prog_fast_entry(sym_at(d), refine); }
+    void sym_window(uint32_t at) { wv = at >> 6; }
     void group_begin(uint32_t g) { group = g; }
     uint64_t hist(int j) const { return hist_all[(size_t)group * kProgGroup + j]; }
     void set_hist(int j, uint64_t h) { hist_all[(size_t)group * kProgGroup + j] = h; }
     void set_pos(int j, uint32_t v) { pos_all[(size_t)group * kProgGroup + j] = v; }
     void group_end(uint32_t) {}
-    void zeros_build(uint64_t z)
+    int zpos_next[64];
+    int nz_next = 0;
+    void zeros_prepare(uint64_t z)
     {
-        nz = 0;
+        nz_next = 0;
         for (int i = 0; i < 64; i++)
-            if ((z >> i) & 1) zpos[nz++] = i;
+            if ((z >> i) & 1) zpos_next[nz_next++] = i;
     }
-    int zeros_count() const { return nz; }
-    int zero_at(int i) const { return zpos[i]; }
+    void zeros_take()
+    {
+        nz = nz_next;
+        memcpy(zpos, zpos_next, sizeof zpos);
+    }
+    uint32_t zeros_count() const { return (uint32_t)nz; }
+    uint32_t zero_gap(uint32_t i) const { return (uint32_t)(zpos[i & 63u] - (int)(i & 63u)); }
 };
 
 struct HostReplayEnv {
@@ -320,6 +339,7 @@ int emulate_gpu_progressive(const uint8_t* data, size_t size, const FrameInfo& f
             w.table = pool.data() + sc.table[0];
             w.hist_all = hist.data();
             w.pos_all = block_pos[s].data();
+            w.refine = sc.ah != 0;
             if (!prog_walk_ac(w, sc.ss, sc.se, sc.ah, sc.nblocks, total_bits[s])) return 1;
         }
     }
