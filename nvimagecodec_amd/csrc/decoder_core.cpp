@@ -1198,9 +1198,25 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
     const ProgImage* hprog = reinterpret_cast<const ProgImage*>(pinned_.data() + prog_desc_offset_);
     if (debug_stats && !prog_to_image_.empty()) {
         const ProgImage& q0 = hprog[0];
-        for (uint32_t k = 0; k < q0.num_scans; k++)
-            fprintf(stderr, "[hipjpeg] progressive image 0 scan %u (ss %u se %u ah %u al %u): walk %.3f ms, of which waiting for neighbours %.3f ms\n", k,
-                    q0.scan[k].ss, q0.scan[k].se, q0.scan[k].ah, q0.scan[k].al, q0.scan[k].walk_ticks * 1e-5, q0.scan[k].wait_ticks * 1e-5);
+        for (uint32_t k = 0; k < q0.num_scans; k++) {
+            // the same scan over all images of the batch that have it (min / mean / max), and where image 0's wave ran
+            uint32_t lo = ~0u, hi = 0, cnt = 0;
+            double sum = 0;
+            for (size_t q = 0; q < prog_to_image_.size(); q++) {
+                if (hprog[q].num_scans <= k) continue;
+                const uint32_t t = hprog[q].scan[k].walk_ticks;
+                lo = std::min(lo, t);
+                hi = std::max(hi, t);
+                sum += t;
+                cnt++;
+            }
+            const uint32_t hw = q0.scan[k].pad_ticks[0];  // HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+            fprintf(stderr,
+                    "[hipjpeg] progressive image 0 scan %u (ss %u se %u ah %u al %u): walk %.3f ms, of which waiting for neighbours %.3f ms; se %u cu %u simd %u; "
+                    "all %u images: %.3f / %.3f / %.3f ms\n",
+                    k, q0.scan[k].ss, q0.scan[k].se, q0.scan[k].ah, q0.scan[k].al, q0.scan[k].walk_ticks * 1e-5, q0.scan[k].wait_ticks * 1e-5, (hw >> 13) & 7u,
+                    (hw >> 8) & 15u, (hw >> 4) & 3u, cnt, lo * 1e-5, cnt ? sum / cnt * 1e-5 : 0.0, hi * 1e-5);
+        }
     }
     for (size_t q = 0; q < prog_to_image_.size(); q++) {
         const PlannedImage& im = images_[prog_to_image_[q]];

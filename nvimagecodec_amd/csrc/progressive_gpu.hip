@@ -88,36 +88,74 @@ struct WordStream {
     }
 };
 
-// Bit reader of the DC first scans: the only state is the bit position p.  W1 holds W shifted by one lane (lane j = word vbase + j + 1),
-// so a 64-bit window is two readlanes at ONE index.
-struct DcReader : WordStream {
-    uint32_t W1;
-    uint32_t p;
-    __device__ __forceinline__ void make_shifted()
+// The 32 stream bits that start at each of the 64 bit offsets of window `target` (bits [64 target, 64 target + 64)): lane l = the bits
+// from 64 target + l on, MSB first.  Three readlanes for the window's words, a funnel shift.
+__device__ __forceinline__ uint32_t window_bits(WordStream& ws, uint32_t target)
+{
+    uint32_t i0 = 2u * target - ws.vbase;  // the window's words: i0, i0 + 1 and (for the codes that start in its second half) i0 + 2
+    if (__builtin_expect(i0 >= 64u, 0)) {  // once per 32 windows
+        ws.seek(2u * target);
+        i0 = 2u * target - ws.vbase;
+    }
+    const uint32_t w0 = lane_read(ws.W, i0), w1 = lane_read(ws.W, i0 + 1u);
+    const uint32_t w2 = i0 == 62u ? lane_read(ws.X, 0) : lane_read(ws.W, i0 + 2u);
+    const uint32_t hi = ws.lane < 32u ? w0 : w1, lo = ws.lane < 32u ? w1 : w2;
+    return (uint32_t)(((((unsigned long long)hi << 32) | lo) << (ws.lane & 31u)) >> 32);
+}
+
+// Reader of the DC first scans.  Like the AC walker it decodes ahead one aligned 64-bit window at a time -- for every bit offset of the
+// window and every DC table of the scan, the code that would start there -- so that a DC symbol costs the walk two readlanes (entry,
+// bits) instead of a window assembly and a table lookup in LDS it has to wait for.
+struct DcWalker : WordStream {
+    uint32_t wv;                  // the current window
+    uint32_t d;                   // the position is 64 wv + d
+    uint32_t win;                 // per lane l: the 32 bits from bit 64 wv + l on
+    uint32_t F0, F1, F2, F3;      // per lane l and table slot: len | size << 5 of the code at bit 64 wv + l (0 = no such code)
+    const HJ_LDS uint16_t* tables;
+    uint32_t slot_words;
+    uint32_t need;                // bit j: table slot j is looked up (slots that repeat an earlier slot's table are not)
+
+    __device__ __forceinline__ uint32_t lookup(uint32_t j, uint32_t w) const
     {
-        const uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 1) & 63u) * 4u), (int)W);  // lane j <- lane j + 1
-        const uint32_t first_of_next = lane_read(X, 0);
-        W1 = lane == 63 ? first_of_next : up;
+        const HJ_LDS uint16_t* t = tables + j * slot_words;
+        uint32_t e = t[w >> 24];
+        if (e & kProgLong) e = t[(e & 0x7FFFu) * 256u + ((w >> 16) & 255u)];
+        return e & 0x1FFFu;
+    }
+    __device__ __forceinline__ void decode(uint32_t target)
+    {
+        wv = target;
+        win = window_bits(*this, target);
+        F0 = lookup(0, win);
+        if (need & 2u) F1 = lookup(1, win);
+        if (need & 4u) F2 = lookup(2, win);
+        if (need & 8u) F3 = lookup(3, win);
     }
     __device__ __forceinline__ void start(const uint32_t* stream, uint32_t stream_words)
     {
         open(stream, stream_words);
-        p = 0;
-        make_shifted();
+        d = 0;
+        F1 = F2 = F3 = 0;
+        decode(0);
     }
-    __device__ __forceinline__ uint32_t window()
+    __device__ __forceinline__ uint32_t pos() const { return wv * 64u + d; }
+    // one DC symbol with the table in slot u: false = no such code.  *diff = the difference it carries.
+    __device__ __forceinline__ bool symbol(uint32_t u, int* diff)
     {
-        uint32_t i = (p >> 5) - vbase;
-        if (__builtin_expect(i >= 64u, 0)) {  // rare: once per 2048 bits
-            seek(p >> 5);
-            make_shifted();
-            i = (p >> 5) - vbase;
+        if (__builtin_expect(d >= 64u, 0)) {
+            const uint32_t at = wv * 64u + d;
+            decode(at >> 6);
+            d = at & 63u;
         }
-        const unsigned long long two = ((unsigned long long)lane_read(W, i) << 32) | lane_read(W1, i);
-        return (uint32_t)((two << (p & 31u)) >> 32);
+        const uint32_t f = u == 0 ? lane_read(F0, d) : u == 1 ? lane_read(F1, d) : u == 2 ? lane_read(F2, d) : lane_read(F3, d);
+        const uint32_t len = f & 31u, sz = f >> 5;
+        if (__builtin_expect(len == 0 || sz > 15u, 0)) return false;
+        // code (<= 16 bits) and value (<= 15 bits) lie in the same 32-bit window; sz == 0: v = 0 < 2^31 gives 0 - 1 + 1
+        const uint32_t v = (uint32_t)(((unsigned long long)(lane_read(win, d) << len) << sz) >> 32);
+        *diff = v < (1u << ((sz - 1u) & 31u)) ? (int)v - (int)(1u << sz) + 1 : (int)v;
+        d += len + sz;
+        return true;
     }
-    __device__ __forceinline__ void advance(uint32_t n) { p += n; }
-    __device__ __forceinline__ uint32_t pos() const { return p; }
 };
 
 // The scalar machine of prog_walk_ac (progressive_gpu_core.h) on one wave.
@@ -133,7 +171,7 @@ struct DevWalker : WordStream {
     const HJ_LDS uint16_t* table;      // the scan's full lookup table
     // per group
     uint32_t hlo, hhi, pos_out;        // per lane: block 64 g + lane
-    uint32_t zpos, zpos_next;          // per lane i: (position of the i-th zero-history coefficient of the current / the next block) - i
+    uint32_t zpos, zraw_next;          // lane t >= 1: (position of the t-th zero-history coefficient of the current block) - t; the next block's positions
     uint32_t nz, nz_next;
     // pipeline
     WalkShared* sh;
@@ -148,15 +186,7 @@ struct DevWalker : WordStream {
     // first-level decode of window `target`; the lookups stay in flight
     __device__ __forceinline__ void issue(uint32_t target)
     {
-        uint32_t i0 = 2u * target - vbase;  // the window's words: i0, i0 + 1 and (for the codes that start in its second half) i0 + 2
-        if (__builtin_expect(i0 >= 64u, 0)) {  // once per 32 windows
-            seek(2u * target);
-            i0 = 2u * target - vbase;
-        }
-        const uint32_t w0 = lane_read(W, i0), w1 = lane_read(W, i0 + 1u);
-        const uint32_t w2 = i0 == 62u ? lane_read(X, 0) : lane_read(W, i0 + 2u);
-        const uint32_t hi = lane < 32u ? w0 : w1, lo = lane < 32u ? w1 : w2;
-        const uint32_t win = (uint32_t)(((((unsigned long long)hi << 32) | lo) << (lane & 31u)) >> 32);
+        const uint32_t win = window_bits(*this, target);
         nxt_win = win;
         nxt = table[win >> 24];
     }
@@ -247,7 +277,8 @@ struct DevWalker : WordStream {
             if (lane == 0) __hip_atomic_store(&sh->done[self], gi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    // rank/select over the set bits of z, for the NEXT block: the crossbar write stays in flight until zeros_take()
+    // rank/select over the set bits of z, for the NEXT block: the crossbar write stays in flight until zeros_take().  The t-th zero
+    // (t >= 1) lands in lane t.
     __device__ __forceinline__ void zeros_prepare(unsigned long long z)
     {
         const uint32_t zl = (uint32_t)z, zh = (uint32_t)(z >> 32);
@@ -255,15 +286,15 @@ struct DevWalker : WordStream {
         nz_next = uni((uint32_t)__popcll(z));
         const bool mine = (z >> lane) & 1ull;
         const uint32_t target = mine ? rank : nz_next + (lane - rank);  // a full permutation: zeros first, in order
-        zpos_next = (uint32_t)__builtin_amdgcn_ds_permute((int)(target * 4u), (int)lane) - lane;  // lane i < nz: (position of the i-th zero) - i
+        zraw_next = (uint32_t)__builtin_amdgcn_ds_permute((int)(((target + 1u) & 63u) * 4u), (int)lane);
     }
     __device__ __forceinline__ void zeros_take()
     {
-        zpos = zpos_next;
+        zpos = zraw_next - lane;  // lane t, 1 <= t <= nz: (position of the t-th zero) - t
         nz = uni(nz_next);
     }
     __device__ __forceinline__ uint32_t zeros_count() const { return nz; }
-    __device__ __forceinline__ uint32_t zero_gap(uint32_t i) const { return lane_read(zpos, i); }
+    __device__ __forceinline__ uint32_t zero_at(uint32_t t) const { return lane_read(zpos, t); }
 };
 
 // one scan's lookup table: pool (global) -> LDS slot, by one wave
@@ -320,8 +351,10 @@ __device__ __forceinline__ void dc_block_address(const ProgImage& im, const Prog
 
 __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint16_t* tables, uint32_t slot_words, uint32_t lane)
 {
-    DcReader w;
+    DcWalker w;
     w.lane = lane;
+    w.tables = tables;
+    w.slot_words = slot_words;
     for (int d = 0; d < (int)im.dc_len; d++) {
         const ProgScan& sc = im.scan[im.dc_chain[d]];
         const HuffImage& hi = himgs[sc.huff_image];
@@ -351,43 +384,61 @@ __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint
         for (uint32_t i = 0; i < sc.ncomp; i++) stage_table(tables + i * slot_words, im.pool, sc.table[i], table_words(im.pool, sc.table[i], lane), lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        // what the walk needs per scan component, one component per lane: read with a readlane when the block order reaches the component,
+        // instead of scalar loads from the descriptors in the innermost loops
+        const uint32_t ncomp = uni(sc.ncomp);
+        uint32_t par = 0, bwv = 0, predv = 0, plo = 0, phi = 0;  // lane i: h | v << 8 | table slot << 16; blocks_w; predictor; plane pointer
+        uint32_t need = 1;
+        {
+            const uint32_t i = lane < ncomp ? lane : 0;
+            const uint32_t c = sc.comps[i];
+            uint32_t slot = i;  // the first component that uses the same table
+            for (uint32_t j = 0; j < i; j++)
+                if (sc.table[j] == sc.table[i]) {
+                    slot = j;
+                    break;
+                }
+            par = im.comp_h[c] | (im.comp_v[c] << 8) | (slot << 16);
+            bwv = im.blocks_w[c];
+            const unsigned long long ptr = (unsigned long long)(uintptr_t)im.dc_plane[c];
+            plo = (uint32_t)ptr;
+            phi = (uint32_t)(ptr >> 32);
+            for (uint32_t j = 1; j < ncomp; j++) need |= lane_read(par, j) >> 16 == j ? 1u << j : 0u;
+        }
+        w.need = uni(need);
         w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
-        int pred[4] = {0, 0, 0, 0};
+        const uint32_t al = uni(sc.al);
         // block order: MCU by MCU, the scan's components in turn (single-component scans: raster over the real blocks)
-        auto one = [&](uint32_t i, uint32_t c, uint32_t index) -> bool {
-            const HJ_LDS uint16_t* t = tables + i * slot_words;
-            const uint32_t win = w.window();
-            uint32_t e = t[win >> 24];
-            if (e & kProgLong) e = t[(e & 0x7FFFu) * 256u + ((win >> 16) & 255u)];
-            e = uni(e);
-            const uint32_t len = e & 31u, sz = (e >> 5) & 255u;
-            if (len == 0 || sz > 15) return false;
-            int diff = 0;
-            if (sz) {  // code (<= 16 bits) and value (<= 15 bits) lie in the same 32-bit window
-                const uint32_t v = (win << len) >> (32 - sz);
-                diff = v < (1u << (sz - 1)) ? (int)v - (int)(1u << sz) + 1 : (int)v;
-            }
-            w.advance(len + sz);
-            pred[i] += diff;
-            if (lane == 0) ((HJ_GLOBAL int16_t*)im.dc_plane[c])[index] = (int16_t)(pred[i] * (1 << sc.al));
-            return true;
-        };
-        if (sc.ncomp == 1) {
-            const uint32_t c = sc.comps[0], nbx = im.nbx[c], nby = im.nby[c], bw = im.blocks_w[c];
+        if (ncomp == 1) {
+            const uint32_t c = uni(sc.comps[0]), nbx = uni(im.nbx[c]), nby = uni(im.nby[c]), bw = lane_read(bwv, 0);
+            HJ_GLOBAL int16_t* plane = (HJ_GLOBAL int16_t*)(uintptr_t)(((unsigned long long)lane_read(phi, 0) << 32) | lane_read(plo, 0));
+            int pred = 0;
             // (the position is checked once per row: a forged frame size cannot keep the wave walking through imaginary data)
             for (uint32_t by = 0; by < nby; by++) {
-                for (uint32_t bx = 0; bx < nbx; bx++)
-                    if (!one(0, c, by * bw + bx)) return false;
+                for (uint32_t bx = 0; bx < nbx; bx++) {
+                    int diff;
+                    if (!w.symbol(0, &diff)) return false;
+                    pred += diff;
+                    if (lane == 0) plane[by * bw + bx] = (int16_t)(pred * (1 << al));
+                }
                 if (w.pos() > total_bits) return false;
             }
         } else {
-            for (uint32_t my = 0; my < im.mcus_y; my++) {
-                for (uint32_t mx = 0; mx < im.mcus_x; mx++)
-                    for (uint32_t i = 0; i < sc.ncomp; i++) {
-                        const uint32_t c = sc.comps[i], h = im.comp_h[c], v = im.comp_v[c], bw = im.blocks_w[c];
+            const uint32_t mcus_x = uni(im.mcus_x), mcus_y = uni(im.mcus_y);
+            for (uint32_t my = 0; my < mcus_y; my++) {
+                for (uint32_t mx = 0; mx < mcus_x; mx++)
+                    for (uint32_t i = 0; i < ncomp; i++) {
+                        const uint32_t p = lane_read(par, i), h = p & 255u, v = (p >> 8) & 255u, slot = p >> 16, bw = lane_read(bwv, i);
+                        HJ_GLOBAL int16_t* plane = (HJ_GLOBAL int16_t*)(uintptr_t)(((unsigned long long)lane_read(phi, i) << 32) | lane_read(plo, i));
+                        int pred = (int)lane_read(predv, i);
                         for (uint32_t dy = 0; dy < v; dy++)
-                            for (uint32_t dx = 0; dx < h; dx++)
-                                if (!one(i, c, (my * v + dy) * bw + mx * h + dx)) return false;
+                            for (uint32_t dx = 0; dx < h; dx++) {
+                                int diff;
+                                if (!w.symbol(slot, &diff)) return false;
+                                pred += diff;
+                                if (lane == 0) plane[(my * v + dy) * bw + mx * h + dx] = (int16_t)(pred * (1 << al));
+                            }
+                        predv = lane == i ? (uint32_t)pred : predv;
                     }
                 if (w.pos() > total_bits) return false;
             }
@@ -421,7 +472,12 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
     __syncthreads();
     bool ok = true;
     if (wave == 0) {
+        const unsigned long long t0 = wall_clock64();
         ok = walk_dc_chain(im, himgs, tables, slot_words, lane);
+        if (lane == 0 && im.dc_len) {  // the whole DC chain, booked on its first scan
+            im.scan[im.dc_chain[0]].walk_ticks = (uint32_t)(wall_clock64() - t0);
+            im.scan[im.dc_chain[0]].pad_ticks[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
     } else {
         // which component's chain, which stage of it; rings of the chains in front (a chain of n scans has n - 1 hand-overs)
         // Waves are dealt to the scans LAST stage first, component after component: the last refinement scans are the long ones
@@ -467,7 +523,7 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         w.aborted = false;
         w.waited = 0;
         w.nz = w.nz_next = 0;
-        w.zpos = w.zpos_next = 0;
+        w.zpos = w.zraw_next = 0;
         w.table = slot;
         w.refine = uni(sc.ah) != 0;
         w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
@@ -476,6 +532,7 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         if (lane == 0) {
             im.scan[im.chain[c][a]].walk_ticks = (uint32_t)(wall_clock64() - t0);
             im.scan[im.chain[c][a]].wait_ticks = w.waited;
+            im.scan[im.chain[c][a]].pad_ticks[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID, all 32 bits
         }
         if (w.aborted) ok = false;
         if (!ok && lane == 0) __hip_atomic_store(&sh.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -103,15 +103,15 @@ HJ_HD int prog_popc64(uint64_t v)
 
 // ---------------------------------------------------------------------------------------------------------- the walk
 // "Fast" view of a lookup-table entry, made once per decoded-ahead symbol (vector work on the device), read by the walk's inner loops:
-// a PLAIN coefficient symbol -- first scans: any size s > 0; refinement scans: s == 1 -- becomes (run r << 16) | bits the symbol takes
-// (code + value bits, resp. code + sign bit); everything else (no such code, end of band, run of sixteen, a size a refinement scan may
-// not carry) becomes a run no band can hold, so the ONE bound check of the inner loop also sorts those out.
+// a PLAIN coefficient symbol -- first scans: any size s > 0; refinement scans: s == 1 -- becomes (run r + 1) << 16 | bits the symbol
+// takes (code + value bits, resp. code + sign bit); everything else (no such code, end of band, run of sixteen, a size a refinement scan
+// may not carry) becomes a run no band can hold, so the ONE bound check of the inner loop also sorts those out.
 constexpr uint32_t kProgNotPlain = 64u << 16;
 HJ_HD uint32_t prog_fast_entry(uint32_t e, bool refine)
 {
     const uint32_t len = e & 31u, s = (e >> 5) & 15u, r = (e >> 9) & 15u;
     const bool plain = refine ? s == 1u : s != 0u;
-    return plain ? (r << 16) | (len + s) : kProgNotPlain;
+    return plain ? ((r + 1u) << 16) | (len + s) : kProgNotPlain;
 }
 HJ_HD uint64_t prog_bit_set(uint64_t h, uint32_t t)  // t < 64
 {
@@ -135,141 +135,168 @@ HJ_HD uint64_t prog_bit_set(uint64_t h, uint32_t t)  // t < 64
 //   void set_pos(int j, uint32_t)  block_pos of block j of the current group
 //   void group_end(uint32_t g)     stores the positions, hands the bitmaps to the next stage
 //   void zeros_prepare(uint64_t z) / void zeros_take()   rank/select over the set bits of z, prepared one block ahead, then made current:
-//                                  uint32_t zeros_count(),  uint32_t zero_gap(uint32_t i) = (position of the i-th set bit) - i
+//                                  uint32_t zeros_count(),  uint32_t zero_at(uint32_t t) = (position of the t-th set bit, t >= 1) - t
 // Everything is wave-uniform on the device; the position is base + d, locals here.  A lone wave pays ~9 cycles per dependent scalar
-// instruction and ~24 more per taken branch or VGPR->SGPR read (tools/scalar_chain_rate.hip), so what counts is the length of the path a
-// PLAIN symbol takes: the coefficient symbols -- nearly all symbols of the scans that bound a batch's latency, the last refinement scans
-//  -- have an inner loop with ONE exit: window exhausted (d >= 64 is added to the run), end of band, run of sixteen, a broken
-// stream and "band complete" all show as a run past the band's end and are told apart behind the exit.  In a refinement scan the position
-// of the next coefficient is not tracked at all: with g[i] = zero_gap(i) (how many non-zero-history coefficients lie in front of the i-th
-// zero-history one), a new coefficient behind r more zeros costs  code + sign + (g[zr + r] - g_prev)  bits, and k is g_prev + zr whenever
-// somebody asks.
+// instruction and ~24 more per taken branch or VGPR->SGPR read (tools/scalar_chain_rate.hip), so what counts is the number of instructions
+// on the path a PLAIN symbol takes and on the path from block to block:
+//   * the coefficient symbols -- nearly all symbols of the scans that bound a batch's latency, the last refinement scans --
+//     have an inner loop with ONE exit: window exhausted (d >= 64 is added to the run), end of band, run of sixteen, a broken stream and
+//     "band complete" all show as a run past the band's end and are told apart behind the exit.  In a refinement scan the position of the
+//     next coefficient is not tracked at all: with G[t] = zero_at(t) (one less than the number of non-zero-history coefficients in front
+//     of the t-th zero-history one), a new coefficient behind r more zeros costs  code + sign + (G[zr + r + 1] - G_prev)  bits, and k is
+//     G_prev + 1 + zr whenever somebody asks;
+//   * everything else is ONE loop, an iteration per event (block complete, window exhausted, run of sixteen, end of band): the machine's
+//     vector state is carried by that loop alone.  (Nested block / symbol loops made the compiler copy the whole state -- twenty registers
+//     -- into and out of every block, and wait for the lookups of the next window right behind their issue.)
 // Returns false when the stream breaks the rules (the host decoder then takes the image and names the error).
-template <class W>
-HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t total_bits)
+template <bool REFINE, class W>
+HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total_bits)
 {
+    if (nblocks == 0) return true;
     const uint64_t band = prog_band_mask(ss, se);
     const uint32_t last = (uint32_t)se;
     uint32_t eobrun = 0;
     uint32_t base = w.sym_base();
     uint32_t d = 0;  // the position is base + d
+    uint32_t g = 0, j = 0;
+    uint32_t n = nblocks < (uint32_t)kProgGroup ? nblocks : (uint32_t)kProgGroup;
+    // the current block
+    uint64_t h = 0;
+    uint32_t c = 0;             // first scans: position of the last coefficient placed (k - 1)
+    uint32_t zr = 0, gprev = 0; // refinement scans: zero-history coefficients of the band already passed; G of the last one placed
+    uint32_t nz = 0;
+    bool skip = false;          // the block lies inside an end-of-band run: nothing to parse
     bool ok = true;
-    for (uint32_t g = 0; g * kProgGroup < nblocks; g++) {
-        w.group_begin(g);
-        const int n = (int)((nblocks - g * kProgGroup) < (uint32_t)kProgGroup ? (nblocks - g * kProgGroup) : (uint32_t)kProgGroup);
-        if (ah) w.zeros_prepare(~w.hist(0) & band);
-        for (int j = 0; j < n; j++) {
-            uint64_t h = w.hist(j);
-            if (ah) {
-                w.zeros_take();
-                if (j + 1 < n) w.zeros_prepare(~w.hist(j + 1) & band);  // the next block's, in the shadow of this block's walk
-            }
-            if (HJ_UNLIKELY(eobrun != 0)) {
-                // inside an end-of-band run: a first scan has nothing for this block, a refinement scan one correction bit per
-                // coefficient of the band that is already non-zero
-                w.set_pos(j, (base + d) | kProgInRun);
-                if (ah) d += (uint32_t)prog_popc64(h & band);
-                eobrun--;
-                continue;
-            }
-            w.set_pos(j, base + d);
-            if (ah == 0) {
-                uint32_t k = (uint32_t)ss;
-                for (;;) {
-                    // plain coefficients: run of r zeros, then a coefficient of s bits
-                    uint32_t f = w.fast_at(d);
-                    uint32_t kk = k + (f >> 16) + (d & ~63u);
-                    while (HJ_LIKELY(kk <= last)) {
-                        h = prog_bit_set(h, kk);
-                        d += f & 0xFFFFu;
-                        k = kk + 1u;
-                        f = w.fast_at(d);
-                        kk = k + (f >> 16) + (d & ~63u);
-                    }
-                    if (k > last) break;  // the band is complete
-                    if (d >= 64u) {
-                        w.sym_window(base + d);
-                        const uint32_t nb = w.sym_base();
-                        d = base + d - nb;
-                        base = nb;
-                        continue;
-                    }
-                    const uint32_t e = w.sym_at(d);
-                    const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
-                    if (len == 0 || s != 0) { ok = false; break; }  // no such code / a run past the band's end
-                    if (r == 15) {
-                        k += 16;
-                        d += len;
-                        if (k > last) break;
-                    } else {
-                        eobrun = (1u << r) - 1 + (r ? (w.bits_at(d) << len) >> (32 - r) : 0u);
-                        d += len + r;
-                        break;
-                    }
-                }
-            } else {
-                const uint32_t nz = w.zeros_count();
-                uint32_t zr = 0;                 // zero-history coefficients of the band already passed
-                uint32_t gprev = (uint32_t)ss;   // (position of the next coefficient to look at) - zr
-                for (;;) {
-                    uint32_t q = d - gprev;
-                    // plain new coefficients: behind r zero-history coefficients; code, sign bit, then one correction bit for every
-                    // non-zero-history coefficient passed on the way
-                    uint32_t f = w.fast_at(d);
-                    uint32_t zi = zr + (f >> 16) + (d & ~63u);
-                    while (HJ_LIKELY(zi < nz)) {
-                        const uint32_t gz = w.zero_gap(zi);
-                        q += f & 0xFFFFu;
-                        d = q + gz;
-                        zr = zi + 1u;
-                        h = prog_bit_set(h, gz + zi);  // the coefficient's position
-                        gprev = gz;
-                        f = w.fast_at(d);
-                        zi = zr + (f >> 16) + (d & ~63u);
-                    }
-                    const uint32_t k = gprev + zr;  // position of the next coefficient to look at
-                    if (k > last) break;            // the band is complete
-                    if (d >= 64u) {
-                        w.sym_window(base + d);
-                        const uint32_t nb = w.sym_base();
-                        d = base + d - nb;
-                        base = nb;
-                        continue;
-                    }
-                    const uint32_t e = w.sym_at(d);
-                    const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
-                    if (len == 0 || s != 0) { ok = false; break; }  // no such code, a size other than 1, or a run past the last zero
-                    if (r == 15) {
-                        // sixteen zero-history coefficients are skipped (or the rest of the band, if it has fewer)
-                        zi = zr + 15;
-                        if (zi >= nz) {
-                            d += len + (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));
-                            break;
-                        }
-                        const uint32_t gz = w.zero_gap(zi);
-                        d += len + gz - gprev;
-                        gprev = gz;
-                        zr = zi + 1u;
-                        if (gz + zi >= last) break;
-                    } else {
-                        eobrun = (1u << r) + (r ? (w.bits_at(d) << len) >> (32 - r) : 0u) - 1;  // this block is the run's first
-                        d += len + r + (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));  // + the rest of this block's band
-                        break;
-                    }
-                }
-            }
-            if (HJ_UNLIKELY(!ok)) break;
-            w.set_hist(j, h);
+
+    auto block_start = [&]() {
+        h = w.hist((int)j);
+        if (REFINE) {
+            w.zeros_take();
+            if (j + 1 < n) w.zeros_prepare(~w.hist((int)j + 1) & band);  // the next block's, in the shadow of this block's walk
         }
-        w.group_end(g);
-        if (!ok) break;
-        // once per 64 blocks (wave-uniform, nearly free): a walk that has left the data stops here instead of decoding the ones behind
-        // the end as symbols for the rest of a forged frame; also keeps the 32-bit position far from kProgInRun's bit
-        if (HJ_UNLIKELY(base + d > total_bits)) { ok = false; break; }
+        if (HJ_UNLIKELY(eobrun != 0)) {
+            // inside an end-of-band run: a first scan has nothing for this block, a refinement scan one correction bit per coefficient of
+            // the band that is already non-zero
+            w.set_pos((int)j, (base + d) | kProgInRun);
+            if (REFINE) d += (uint32_t)prog_popc64(h & band);
+            eobrun--;
+            skip = true;
+        } else {
+            w.set_pos((int)j, base + d);
+            skip = false;
+            if (REFINE) {
+                nz = w.zeros_count();
+                zr = 0;
+                gprev = (uint32_t)ss - 1u;
+            } else {
+                c = (uint32_t)ss - 1u;
+            }
+        }
+    };
+
+    w.group_begin(0);
+    if (REFINE) w.zeros_prepare(~w.hist(0) & band);
+    block_start();
+    for (;;) {
+        bool next = true;
+        if (HJ_LIKELY(!skip)) {
+            uint32_t k;  // position of the next coefficient to look at
+            if (!REFINE) {
+                // plain coefficients: run of r zeros, then a coefficient of s bits
+                uint32_t f = w.fast_at(d);
+                uint32_t kk = c + (f >> 16) + (d & ~63u);
+                while (HJ_LIKELY(kk <= last)) {
+                    h = prog_bit_set(h, kk);
+                    d += f & 0xFFFFu;
+                    c = kk;
+                    f = w.fast_at(d);
+                    kk = c + (f >> 16) + (d & ~63u);
+                }
+                k = c + 1u;
+            } else {
+                // plain new coefficients: behind r zero-history coefficients; code, sign bit, then one correction bit for every
+                // non-zero-history coefficient passed on the way
+                uint32_t q = d - gprev;
+                uint32_t f = w.fast_at(d);
+                uint32_t t = zr + (f >> 16) + (d & ~63u);
+                while (HJ_LIKELY(t <= nz)) {
+                    const uint32_t gz = w.zero_at(t);
+                    q += f & 0xFFFFu;
+                    d = q + gz;
+                    zr = t;
+                    h = prog_bit_set(h, gz + t);  // the coefficient's position
+                    gprev = gz;
+                    f = w.fast_at(d);
+                    t = zr + (f >> 16) + (d & ~63u);
+                }
+                k = gprev + 1u + zr;
+            }
+            if (k > last) {
+                // the band is complete
+            } else if (d >= 64u) {
+                w.sym_window(base + d);
+                const uint32_t nb = w.sym_base();
+                d = base + d - nb;
+                base = nb;
+                next = false;
+            } else {
+                const uint32_t e = w.sym_at(d);
+                const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
+                // no such code / a run past the band's end (resp. past the last zero) / refinement: a size other than 1
+                if (HJ_UNLIKELY(len == 0 || s != 0)) {
+                    ok = false;
+                    break;
+                }
+                if (r == 15) {
+                    if (!REFINE) {
+                        c += 16;
+                        d += len;
+                        next = c + 1u > last;
+                    } else {
+                        // sixteen zero-history coefficients are skipped (or the rest of the band, if it has fewer)
+                        const uint32_t t = zr + 16;
+                        if (t > nz) {
+                            d += len + (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));
+                        } else {
+                            const uint32_t gz = w.zero_at(t);
+                            d += len + gz - gprev;
+                            gprev = gz;
+                            zr = t;
+                            next = gz + t >= last;
+                        }
+                    }
+                } else {
+                    eobrun = (1u << r) - 1u + (r ? (w.bits_at(d) << len) >> (32 - r) : 0u);  // this block is the run's first
+                    d += len + r;
+                    if (REFINE) d += (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));  // + the rest of this block's band
+                }
+            }
+            if (next) w.set_hist((int)j, h);
+        }
+        if (next) {
+            if (HJ_UNLIKELY(++j == n)) {
+                w.group_end(g);
+                // once per 64 blocks (wave-uniform, nearly free): a walk that has left the data stops here instead of decoding the ones
+                // behind the end as symbols for the rest of a forged frame; also keeps the 32-bit position far from kProgInRun's bit
+                if (HJ_UNLIKELY(base + d > total_bits)) return false;
+                g++;
+                if (g * (uint32_t)kProgGroup >= nblocks) return true;
+                w.group_begin(g);
+                n = (nblocks - g * kProgGroup) < (uint32_t)kProgGroup ? (nblocks - g * kProgGroup) : (uint32_t)kProgGroup;
+                j = 0;
+                if (REFINE) w.zeros_prepare(~w.hist(0) & band);
+            }
+            block_start();
+        }
     }
-    // nothing may be read from behind the data (the host decoder calls that TRUNCATED)
-    if (ok && base + d > total_bits) ok = false;
+    w.group_end(g);  // only a broken stream gets here
     return ok;
+}
+
+template <class W>
+HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t total_bits)
+{
+    return ah ? prog_walk_scan<true>(w, ss, se, nblocks, total_bits) : prog_walk_scan<false>(w, ss, se, nblocks, total_bits);
 }
 
 // ---------------------------------------------------------------------------------------------------------- the replay

@@ -289,7 +289,7 @@ struct HostWalker {
         memcpy(zpos, zpos_next, sizeof zpos);
     }
     uint32_t zeros_count() const { return (uint32_t)nz; }
-    uint32_t zero_gap(uint32_t i) const { return (uint32_t)(zpos[i & 63u] - (int)(i & 63u)); }
+    uint32_t zero_at(uint32_t t) const { return (uint32_t)(zpos[(t - 1u) & 63u] - (int)(t & 63u)); }  // t >= 1: the t-th zero
 };
 
 struct HostReplayEnv {
