@@ -1216,6 +1216,11 @@ hipjpegStatus_t DecodeBatch::resolve(void* stream)
                     "all %u images: %.3f / %.3f / %.3f ms\n",
                     k, q0.scan[k].ss, q0.scan[k].se, q0.scan[k].ah, q0.scan[k].al, q0.scan[k].walk_ticks * 1e-5, q0.scan[k].wait_ticks * 1e-5, (hw >> 13) & 7u,
                     (hw >> 8) & 15u, (hw >> 4) & 3u, cnt, lo * 1e-5, cnt ? sum / cnt * 1e-5 : 0.0, hi * 1e-5);
+            if (getenv("HIPJPEG_WALK_LAPS"))  // a library built with -DHJ_WALK_PROFILE (tools/walk_laps.sh): the packed lap timers
+                fprintf(stderr, "[hipjpeg]   laps (cycles / count): fast %u / %u, event %u / %u, window %u / %u, block %u / %u\n",
+                        (q0.scan[k].wait_ticks & 0xFFFFu) << 12, (q0.scan[k].pad_ticks[1] & 0xFFFFu) << 4, (q0.scan[k].wait_ticks >> 16) << 12,
+                        (q0.scan[k].pad_ticks[1] >> 16) << 4, (q0.scan[k].pad_ticks[0] & 0xFFFFu) << 12, (q0.scan[k].pad_ticks[2] & 0xFFFFu) << 4,
+                        (q0.scan[k].pad_ticks[0] >> 16) << 12, (q0.scan[k].pad_ticks[2] >> 16) << 4);
         }
     }
     for (size_t q = 0; q < prog_to_image_.size(); q++) {

@@ -293,6 +293,35 @@ struct DevWalker : WordStream {
         zpos = zraw_next - lane;  // lane t, 1 <= t <= nz: (position of the t-th zero) - t
         nz = uni(nz_next);
     }
+#if defined(HJ_WALK_PROFILE)
+    // HJ_WALK_PROFILE=1: lap timers around the parts of prog_walk_scan (0 fast loops, 1 event handling, 2 window switches, 3 block starts);
+    // =2: the fast loops alone, by the number of symbols a visit took (0, 1, 2, more)
+    unsigned long long lap_last;
+    uint32_t lap_sum[4], lap_n[4], lap_syms;
+    __device__ __forceinline__ void lap(int id)
+    {
+        unsigned long long now = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(now));  // (keeps the two stamps apart: the second is taken when the first has arrived)
+        const uint32_t dt = (uint32_t)(now - lap_last);
+        if (HJ_WALK_PROFILE == 1) {
+            lap_sum[id] += dt;
+            lap_n[id]++;
+        } else if (id == 0) {
+            const uint32_t b = lap_syms < 3u ? lap_syms : 3u;
+            lap_sum[0] += b == 0 ? dt : 0;
+            lap_sum[1] += b == 1 ? dt : 0;
+            lap_sum[2] += b == 2 ? dt : 0;
+            lap_sum[3] += b == 3 ? dt : 0;
+            lap_n[0] += b == 0;
+            lap_n[1] += b == 1;
+            lap_n[2] += b == 2;
+            lap_n[3] += b == 3;
+        }
+        lap_syms = 0;
+        lap_last = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lap_last));
+    }
+#endif
     __device__ __forceinline__ uint32_t zeros_count() const { return nz; }
     __device__ __forceinline__ uint32_t zero_at(uint32_t t) const { return lane_read(zpos, t); }
 };
@@ -474,6 +503,18 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
     if (wave == 0) {
         const unsigned long long t0 = wall_clock64();
         ok = walk_dc_chain(im, himgs, tables, slot_words, lane);
+#if defined(HJ_WALK_PROFILE)
+        {  // what a lap books although nothing happens in it (the second stamp's own flight time)
+            unsigned long long last = __builtin_readcyclecounter();
+            uint32_t sum = 0;
+            for (int i = 0; i < 256; i++) {
+                const unsigned long long now = __builtin_readcyclecounter();
+                sum += (uint32_t)(now - last);
+                last = __builtin_readcyclecounter();
+            }
+            if (lane == 0 && im.dc_len) im.scan[im.dc_chain[0]].pad_ticks[1] = sum >> 8 >> 4;  // shown as "fast count"
+        }
+#endif
         if (lane == 0 && im.dc_len) {  // the whole DC chain, booked on its first scan
             im.scan[im.dc_chain[0]].walk_ticks = (uint32_t)(wall_clock64() - t0);
             im.scan[im.dc_chain[0]].pad_ticks[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -527,12 +568,25 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         w.table = slot;
         w.refine = uni(sc.ah) != 0;
         w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
+#if defined(HJ_WALK_PROFILE)
+        for (int i = 0; i < 4; i++) w.lap_sum[i] = w.lap_n[i] = 0;
+        w.lap_syms = 0;
+        w.lap_last = __builtin_readcyclecounter();
+#endif
         const unsigned long long t0 = wall_clock64();
         ok = prog_walk_ac(w, (int)sc.ss, (int)sc.se, (int)sc.ah, sc.nblocks, hi.total_bits);
         if (lane == 0) {
             im.scan[im.chain[c][a]].walk_ticks = (uint32_t)(wall_clock64() - t0);
             im.scan[im.chain[c][a]].wait_ticks = w.waited;
             im.scan[im.chain[c][a]].pad_ticks[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID, all 32 bits
+#if defined(HJ_WALK_PROFILE)
+            // cycles (units of 4096) in the fast loops / event handling / window switches / block starts, and how many of each
+            ProgScan& out = im.scan[im.chain[c][a]];
+            out.wait_ticks = (w.lap_sum[0] >> 12) | ((w.lap_sum[1] >> 12) << 16);
+            out.pad_ticks[0] = (w.lap_sum[2] >> 12) | ((w.lap_sum[3] >> 12) << 16);
+            out.pad_ticks[1] = (w.lap_n[0] >> 4) | ((w.lap_n[1] >> 4) << 16);
+            out.pad_ticks[2] = (w.lap_n[2] >> 4) | ((w.lap_n[3] >> 4) << 16);
+#endif
         }
         if (w.aborted) ok = false;
         if (!ok && lane == 0) __hip_atomic_store(&sh.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -106,6 +106,15 @@ HJ_HD int prog_popc64(uint64_t v)
 // a PLAIN coefficient symbol -- first scans: any size s > 0; refinement scans: s == 1 -- becomes (run r + 1) << 16 | bits the symbol
 // takes (code + value bits, resp. code + sign bit); everything else (no such code, end of band, run of sixteen, a size a refinement scan
 // may not carry) becomes a run no band can hold, so the ONE bound check of the inner loop also sorts those out.
+// development aid (tools/walk_laps.sh): where a walking wave's time goes -- lap timers around the parts of prog_walk_scan
+#if defined(HJ_WALK_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define HJ_WALK_LAP(w, id) (w).lap(id)
+#define HJ_WALK_COUNT(n) ((n)++)
+#else
+#define HJ_WALK_LAP(w, id) ((void)0)
+#define HJ_WALK_COUNT(n) ((void)0)
+#endif
+
 constexpr uint32_t kProgNotPlain = 64u << 16;
 HJ_HD uint32_t prog_fast_entry(uint32_t e, bool refine)
 {
@@ -145,8 +154,8 @@ HJ_HD uint64_t prog_bit_set(uint64_t h, uint32_t t)  // t < 64
 //     next coefficient is not tracked at all: with G[t] = zero_at(t) (one less than the number of non-zero-history coefficients in front
 //     of the t-th zero-history one), a new coefficient behind r more zeros costs  code + sign + (G[zr + r + 1] - G_prev)  bits, and k is
 //     G_prev + 1 + zr whenever somebody asks;
-//   * everything else is ONE loop, an iteration per event (block complete, window exhausted, run of sixteen, end of band): the machine's
-//     vector state is carried by that loop alone.  (Nested block / symbol loops made the compiler copy the whole state -- twenty registers
+//   * everything else is ONE loop per group of 64 blocks, an iteration per event (block complete, window exhausted, run of sixteen, end
+//     of band): the machine's vector state is carried by that loop alone.  (Nested block / symbol loops made the compiler copy the whole state -- twenty registers
 //     -- into and out of every block, and wait for the lookups of the next window right behind their issue.)
 // Returns false when the stream breaks the rules (the host decoder then takes the image and names the error).
 template <bool REFINE, class W>
@@ -166,15 +175,20 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
     uint32_t zr = 0, gprev = 0; // refinement scans: zero-history coefficients of the band already passed; G of the last one placed
     uint32_t nz = 0;
     bool skip = false;          // the block lies inside an end-of-band run: nothing to parse
-    bool ok = true;
 
+    // Called from ONE place (a second call site would make the compiler merge the two in-flight rank/select tables with a copy, and wait
+    // for the crossbar right behind its issue): the loop below starts one block early, on a block that does not exist.
     auto block_start = [&]() {
         h = w.hist((int)j);
         if (REFINE) {
             w.zeros_take();
-            if (j + 1 < n) w.zeros_prepare(~w.hist((int)j + 1) & band);  // the next block's, in the shadow of this block's walk
+            // the next block's, in the shadow of this block's walk (behind the group's last block: of whatever lane 0 holds, never used --
+            // a condition here would cost a copy of the table and a wait for the crossbar)
+            w.zeros_prepare(~w.hist((int)j + 1) & band);
         }
-        if (HJ_UNLIKELY(eobrun != 0)) {
+        if (HJ_UNLIKELY(j == ~0u)) {
+            skip = true;  // the block in front of the group's first: nothing but the preparation of block 0
+        } else if (HJ_UNLIKELY(eobrun != 0)) {
             // inside an end-of-band run: a first scan has nothing for this block, a refinement scan one correction bit per coefficient of
             // the band that is already non-zero
             w.set_pos((int)j, (base + d) | kProgInRun);
@@ -194,103 +208,126 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
         }
     };
 
-    w.group_begin(0);
-    if (REFINE) w.zeros_prepare(~w.hist(0) & band);
-    block_start();
+    // Per group of 64 blocks: ONE loop, an iteration per event, left only at its bottom (no break, no return inside: every way out
+    // of the middle costs flag registers and branches on the way of the events that stay).
     for (;;) {
-        bool next = true;
-        if (HJ_LIKELY(!skip)) {
-            uint32_t k;  // position of the next coefficient to look at
-            if (!REFINE) {
-                // plain coefficients: run of r zeros, then a coefficient of s bits
-                uint32_t f = w.fast_at(d);
-                uint32_t kk = c + (f >> 16) + (d & ~63u);
-                while (HJ_LIKELY(kk <= last)) {
-                    h = prog_bit_set(h, kk);
-                    d += f & 0xFFFFu;
-                    c = kk;
-                    f = w.fast_at(d);
-                    kk = c + (f >> 16) + (d & ~63u);
-                }
-                k = c + 1u;
-            } else {
-                // plain new coefficients: behind r zero-history coefficients; code, sign bit, then one correction bit for every
-                // non-zero-history coefficient passed on the way
-                uint32_t q = d - gprev;
-                uint32_t f = w.fast_at(d);
-                uint32_t t = zr + (f >> 16) + (d & ~63u);
-                while (HJ_LIKELY(t <= nz)) {
-                    const uint32_t gz = w.zero_at(t);
-                    q += f & 0xFFFFu;
-                    d = q + gz;
-                    zr = t;
-                    h = prog_bit_set(h, gz + t);  // the coefficient's position
-                    gprev = gz;
-                    f = w.fast_at(d);
-                    t = zr + (f >> 16) + (d & ~63u);
-                }
-                k = gprev + 1u + zr;
-            }
-            if (k > last) {
-                // the band is complete
-            } else if (d >= 64u) {
-                w.sym_window(base + d);
-                const uint32_t nb = w.sym_base();
-                d = base + d - nb;
-                base = nb;
-                next = false;
-            } else {
-                const uint32_t e = w.sym_at(d);
-                const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
-                // no such code / a run past the band's end (resp. past the last zero) / refinement: a size other than 1
-                if (HJ_UNLIKELY(len == 0 || s != 0)) {
-                    ok = false;
-                    break;
-                }
-                if (r == 15) {
-                    if (!REFINE) {
-                        c += 16;
-                        d += len;
-                        next = c + 1u > last;
-                    } else {
-                        // sixteen zero-history coefficients are skipped (or the rest of the band, if it has fewer)
-                        const uint32_t t = zr + 16;
-                        if (t > nz) {
-                            d += len + (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));
-                        } else {
-                            const uint32_t gz = w.zero_at(t);
-                            d += len + gz - gprev;
-                            gprev = gz;
-                            zr = t;
-                            next = gz + t >= last;
-                        }
+        w.group_begin(g);
+        j = ~0u - 1u;
+        skip = true;
+        uint32_t run = 1;  // 1 = walking, 0 = the group is complete, 2 = the stream broke the rules
+        do {
+            bool next = true;
+            if (HJ_LIKELY(!skip)) {
+                uint32_t k;  // position of the next coefficient to look at
+                if (!REFINE) {
+                    // plain coefficients: run of r zeros, then a coefficient of s bits
+                    uint32_t f = w.fast_at(d);
+                    uint32_t kk = c + (f >> 16) + (d & ~63u);
+                    while (HJ_LIKELY(kk <= last)) {  // (two symbols per turn: every second one saves the taken branch back to the top)
+                        HJ_WALK_COUNT(w.lap_syms);
+                        h = prog_bit_set(h, kk);
+                        d += f & 0xFFFFu;
+                        c = kk;
+                        f = w.fast_at(d);
+                        kk = c + (f >> 16) + (d & ~63u);
+                        if (HJ_UNLIKELY(kk > last)) break;
+                        HJ_WALK_COUNT(w.lap_syms);
+                        h = prog_bit_set(h, kk);
+                        d += f & 0xFFFFu;
+                        c = kk;
+                        f = w.fast_at(d);
+                        kk = c + (f >> 16) + (d & ~63u);
                     }
+                    k = c + 1u;
                 } else {
-                    eobrun = (1u << r) - 1u + (r ? (w.bits_at(d) << len) >> (32 - r) : 0u);  // this block is the run's first
-                    d += len + r;
-                    if (REFINE) d += (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));  // + the rest of this block's band
+                    // plain new coefficients: behind r zero-history coefficients; code, sign bit, then one correction bit for every
+                    // non-zero-history coefficient passed on the way
+                    uint32_t q = d - gprev;
+                    uint32_t f = w.fast_at(d);
+                    uint32_t t = zr + (f >> 16) + (d & ~63u);
+                    while (HJ_LIKELY(t <= nz)) {  // (two symbols per turn: every second one saves the taken branch back to the top)
+                        HJ_WALK_COUNT(w.lap_syms);
+                        gprev = w.zero_at(t);
+                        q += f & 0xFFFFu;
+                        d = q + gprev;
+                        zr = t;
+                        h = prog_bit_set(h, gprev + t);  // the coefficient's position
+                        f = w.fast_at(d);
+                        t = zr + (f >> 16) + (d & ~63u);
+                        if (HJ_UNLIKELY(t > nz)) break;
+                        HJ_WALK_COUNT(w.lap_syms);
+                        gprev = w.zero_at(t);
+                        q += f & 0xFFFFu;
+                        d = q + gprev;
+                        zr = t;
+                        h = prog_bit_set(h, gprev + t);
+                        f = w.fast_at(d);
+                        t = zr + (f >> 16) + (d & ~63u);
+                    }
+                    k = gprev + 1u + zr;
                 }
+                HJ_WALK_LAP(w, 0);
+                if (k > last) {
+                    // the band is complete
+                } else if (d >= 64u) {
+                    w.sym_window(base + d);
+                    const uint32_t nb = w.sym_base();
+                    d = base + d - nb;
+                    base = nb;
+                    next = false;
+                    HJ_WALK_LAP(w, 2);
+                } else {
+                    const uint32_t e = w.sym_at(d);
+                    const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
+                    if (HJ_UNLIKELY(len == 0 || s != 0)) {
+                        // no such code / a run past the band's end (resp. past the last zero) / refinement: a size other than 1
+                        run = 2;
+                        next = false;
+                    } else if (r == 15) {
+                        if (!REFINE) {
+                            c += 16;
+                            d += len;
+                            next = c + 1u > last;
+                        } else {
+                            // sixteen zero-history coefficients are skipped (or the rest of the band, if it has fewer)
+                            const uint32_t t = zr + 16;
+                            if (t > nz) {
+                                d += len + (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));
+                            } else {
+                                const uint32_t gz = w.zero_at(t);
+                                d += len + gz - gprev;
+                                gprev = gz;
+                                zr = t;
+                                next = gz + t >= last;
+                            }
+                        }
+                    } else {
+                        eobrun = (1u << r) - 1u + (r ? (w.bits_at(d) << len) >> (32 - r) : 0u);  // this block is the run's first
+                        d += len + r;
+                        if (REFINE) d += (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));  // + the rest of this block's band
+                    }
+                }
+                if (next) w.set_hist((int)j, h);
+                HJ_WALK_LAP(w, 1);
             }
-            if (next) w.set_hist((int)j, h);
-        }
-        if (next) {
-            if (HJ_UNLIKELY(++j == n)) {
-                w.group_end(g);
-                // once per 64 blocks (wave-uniform, nearly free): a walk that has left the data stops here instead of decoding the ones
-                // behind the end as symbols for the rest of a forged frame; also keeps the 32-bit position far from kProgInRun's bit
-                if (HJ_UNLIKELY(base + d > total_bits)) return false;
-                g++;
-                if (g * (uint32_t)kProgGroup >= nblocks) return true;
-                w.group_begin(g);
-                n = (nblocks - g * kProgGroup) < (uint32_t)kProgGroup ? (nblocks - g * kProgGroup) : (uint32_t)kProgGroup;
-                j = 0;
-                if (REFINE) w.zeros_prepare(~w.hist(0) & band);
+            if (next) {
+                j++;
+                if (j == n)
+                    run = 0;
+                else
+                    block_start();
+                HJ_WALK_LAP(w, 3);
             }
-            block_start();
-        }
+        } while (run == 1);
+        w.group_end(g);
+        if (run == 2) return false;
+        // once per 64 blocks (wave-uniform, nearly free): a walk that has left the data stops here instead of decoding the ones behind
+        // the end as symbols for the rest of a forged frame; also keeps the 32-bit position far from kProgInRun's bit
+        if (HJ_UNLIKELY(base + d > total_bits)) return false;
+        g++;
+        if (g * (uint32_t)kProgGroup >= nblocks) return true;
+        n = (nblocks - g * kProgGroup) < (uint32_t)kProgGroup ? (nblocks - g * kProgGroup) : (uint32_t)kProgGroup;
     }
-    w.group_end(g);  // only a broken stream gets here
-    return ok;
 }
 
 template <class W>
