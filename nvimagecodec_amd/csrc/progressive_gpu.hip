@@ -139,7 +139,8 @@ struct DcWalker : WordStream {
         decode(0);
     }
     __device__ __forceinline__ uint32_t pos() const { return wv * 64u + d; }
-    // one DC symbol with the table in slot u: false = no such code.  *diff = the difference it carries.
+    // one DC symbol with the table in slot u: false = no such code (the position then stays where it is).  *diff = the difference it
+    // carries.  No way out of the middle: the caller collects the verdicts.
     __device__ __forceinline__ bool symbol(uint32_t u, int* diff)
     {
         if (__builtin_expect(d >= 64u, 0)) {
@@ -147,14 +148,14 @@ struct DcWalker : WordStream {
             decode(at >> 6);
             d = at & 63u;
         }
-        const uint32_t f = u == 0 ? lane_read(F0, d) : u == 1 ? lane_read(F1, d) : u == 2 ? lane_read(F2, d) : lane_read(F3, d);
-        const uint32_t len = f & 31u, sz = f >> 5;
-        if (__builtin_expect(len == 0 || sz > 15u, 0)) return false;
+        const uint32_t f01 = u & 1u ? lane_read(F1, d) : lane_read(F0, d), f23 = u & 1u ? lane_read(F3, d) : lane_read(F2, d);
+        const uint32_t f = u & 2u ? f23 : f01;
+        const uint32_t len = f & 31u, sz = f >> 5;  // sz <= 15: gpu_progressive_eligible() keeps other tables away
         // code (<= 16 bits) and value (<= 15 bits) lie in the same 32-bit window; sz == 0: v = 0 < 2^31 gives 0 - 1 + 1
         const uint32_t v = (uint32_t)(((unsigned long long)(lane_read(win, d) << len) << sz) >> 32);
         *diff = v < (1u << ((sz - 1u) & 31u)) ? (int)v - (int)(1u << sz) + 1 : (int)v;
         d += len + sz;
-        return true;
+        return len != 0;
     }
 };
 
@@ -413,65 +414,62 @@ __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint
         for (uint32_t i = 0; i < sc.ncomp; i++) stage_table(tables + i * slot_words, im.pool, sc.table[i], table_words(im.pool, sc.table[i], lane), lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        // what the walk needs per scan component, one component per lane: read with a readlane when the block order reaches the component,
-        // instead of scalar loads from the descriptors in the innermost loops
+        // The walk is ONE loop over the scan's blocks in scan order, no way out of its middle (a broken stream is noticed once per 64
+        // blocks).  What a block needs -- which component it belongs to, which table that component uses -- comes from a pattern of the
+        // MCU, one block per lane, read with a readlane; the predictors live in the lanes of a register too.  The 64 values of a group are
+        // collected in a register and stored together, every lane working out its own block's address.
         const uint32_t ncomp = uni(sc.ncomp);
-        uint32_t par = 0, bwv = 0, predv = 0, plo = 0, phi = 0;  // lane i: h | v << 8 | table slot << 16; blocks_w; predictor; plane pointer
-        uint32_t need = 1;
+        uint32_t pat = 0;   // lane k < bpm: the k-th block of an MCU: table slot | component (position in the scan) << 2
+        uint32_t need = 1;  // bit j: slot j holds a table of its own (the first component that uses the table owns the slot)
         {
-            const uint32_t i = lane < ncomp ? lane : 0;
-            const uint32_t c = sc.comps[i];
-            uint32_t slot = i;  // the first component that uses the same table
-            for (uint32_t j = 0; j < i; j++)
-                if (sc.table[j] == sc.table[i]) {
-                    slot = j;
-                    break;
-                }
-            par = im.comp_h[c] | (im.comp_v[c] << 8) | (slot << 16);
-            bwv = im.blocks_w[c];
-            const unsigned long long ptr = (unsigned long long)(uintptr_t)im.dc_plane[c];
-            plo = (uint32_t)ptr;
-            phi = (uint32_t)(ptr >> 32);
-            for (uint32_t j = 1; j < ncomp; j++) need |= lane_read(par, j) >> 16 == j ? 1u << j : 0u;
-        }
-        w.need = uni(need);
-        w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
-        const uint32_t al = uni(sc.al);
-        // block order: MCU by MCU, the scan's components in turn (single-component scans: raster over the real blocks)
-        if (ncomp == 1) {
-            const uint32_t c = uni(sc.comps[0]), nbx = uni(im.nbx[c]), nby = uni(im.nby[c]), bw = lane_read(bwv, 0);
-            HJ_GLOBAL int16_t* plane = (HJ_GLOBAL int16_t*)(uintptr_t)(((unsigned long long)lane_read(phi, 0) << 32) | lane_read(plo, 0));
-            int pred = 0;
-            // (the position is checked once per row: a forged frame size cannot keep the wave walking through imaginary data)
-            for (uint32_t by = 0; by < nby; by++) {
-                for (uint32_t bx = 0; bx < nbx; bx++) {
-                    int diff;
-                    if (!w.symbol(0, &diff)) return false;
-                    pred += diff;
-                    if (lane == 0) plane[by * bw + bx] = (int16_t)(pred * (1 << al));
-                }
-                if (w.pos() > total_bits) return false;
-            }
-        } else {
-            const uint32_t mcus_x = uni(im.mcus_x), mcus_y = uni(im.mcus_y);
-            for (uint32_t my = 0; my < mcus_y; my++) {
-                for (uint32_t mx = 0; mx < mcus_x; mx++)
-                    for (uint32_t i = 0; i < ncomp; i++) {
-                        const uint32_t p = lane_read(par, i), h = p & 255u, v = (p >> 8) & 255u, slot = p >> 16, bw = lane_read(bwv, i);
-                        HJ_GLOBAL int16_t* plane = (HJ_GLOBAL int16_t*)(uintptr_t)(((unsigned long long)lane_read(phi, i) << 32) | lane_read(plo, i));
-                        int pred = (int)lane_read(predv, i);
-                        for (uint32_t dy = 0; dy < v; dy++)
-                            for (uint32_t dx = 0; dx < h; dx++) {
-                                int diff;
-                                if (!w.symbol(slot, &diff)) return false;
-                                pred += diff;
-                                if (lane == 0) plane[(my * v + dy) * bw + mx * h + dx] = (int16_t)(pred * (1 << al));
-                            }
-                        predv = lane == i ? (uint32_t)pred : predv;
+            uint32_t slot_of[4] = {0, 0, 0, 0};
+            for (uint32_t i = 1; i < ncomp; i++) {
+                uint32_t slot = i;
+                for (uint32_t j = 0; j < i; j++)
+                    if (uni(sc.table[j]) == uni(sc.table[i])) {
+                        slot = j;
+                        break;
                     }
-                if (w.pos() > total_bits) return false;
+                slot_of[i] = slot;
+                if (slot == i) need |= 1u << i;
+            }
+            uint32_t first = 0;
+            for (uint32_t i = 0; i < ncomp; i++) {
+                const uint32_t c = uni(sc.comps[i]);
+                const uint32_t nb = ncomp == 1 ? 1u : uni(im.comp_h[c]) * uni(im.comp_v[c]);
+                if (lane >= first && lane < first + nb) pat = slot_of[i] | (i << 2);
+                first += nb;
             }
         }
+        const uint32_t blocks_per_mcu = ncomp == 1 ? 1u : bpm;
+        w.need = need;
+        w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
+        const uint32_t al = uni(sc.al), nblocks = uni(sc.nblocks);
+        uint32_t predv = 0;  // lane i: predictor of the scan's i-th component
+        uint32_t k = 0;      // position in the MCU
+        bool bad = false;
+        for (uint32_t b0 = 0; b0 < nblocks && !bad; b0 += 64) {
+            const uint32_t cnt = nblocks - b0 < 64u ? nblocks - b0 : 64u;
+            uint32_t outv = 0;
+            for (uint32_t jj = 0; jj < cnt; jj++) {
+                const uint32_t p = lane_read(pat, k);
+                k = k + 1u == blocks_per_mcu ? 0u : k + 1u;
+                int diff;
+                bad |= !w.symbol(p & 3u, &diff);
+                const uint32_t i = p >> 2;
+                const uint32_t pred = lane_read(predv, i) + (uint32_t)diff;
+                predv = lane == i ? pred : predv;
+                outv = lane == jj ? pred : outv;
+            }
+            if (lane < cnt) {
+                uint32_t c, index, slot;
+                dc_block_address(im, sc, b0 + lane, bpm, &c, &index, &slot);
+                ((HJ_GLOBAL int16_t*)im.dc_plane[c])[index] = (int16_t)((int)outv * (1 << al));
+            }
+            // (the position is checked once per group: a forged frame size cannot keep the wave walking through imaginary data)
+            if (w.pos() > total_bits) bad = true;
+        }
+        if (bad) return false;
         if (w.pos() > total_bits) return false;
         __threadfence_block();
     }
