@@ -292,7 +292,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                             // sixteen zero-history coefficients are skipped (or the rest of the band, if it has fewer)
                             const uint32_t t = zr + 16;
                             if (t > nz) {
-                                d += len + (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));
+                                d += len + (last - nz - gprev);  // + the rest of the band (see below)
                             } else {
                                 const uint32_t gz = w.zero_at(t);
                                 d += len + gz - gprev;
@@ -304,7 +304,9 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                     } else {
                         eobrun = (1u << r) - 1u + (r ? (w.bits_at(d) << len) >> (32 - r) : 0u);  // this block is the run's first
                         d += len + r;
-                        if (REFINE) d += (uint32_t)prog_popc64(h & band & prog_from_mask((int)k));  // + the rest of this block's band
+                        // + a correction bit for every non-zero-history coefficient in the rest of the band: the band has se - ss + 1 - nz of
+                        // them, gprev + 1 - ss lie in front of k (k - ss positions, zr of them zero-history)
+                        if (REFINE) d += last - nz - gprev;
                     }
                 }
                 if (next) w.set_hist((int)j, h);
