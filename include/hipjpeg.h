@@ -68,8 +68,9 @@ typedef enum {
 } hipjpegChromaSubsampling_t;
 
 #define HIPJPEG_FLAG_FANCY_UPSAMPLING 1u /* libjpeg do_fancy_upsampling (plugin option fancy_upsampling, default on) */
-#define HIPJPEG_FLAG_GPU_HUFFMAN 2u      /* entropy-decode eligible streams (baseline, one interleaved scan, no restart markers) on the
-                                            GPU; the host then only destuffs the scan.  Other streams keep the host entropy stage. */
+#define HIPJPEG_FLAG_GPU_HUFFMAN 2u      /* entropy-decode eligible streams on the GPU (sequential Huffman with one interleaved scan, with or
+                                            without restart intervals; progressive SOF2 with up to 24 scans); the host then only finds the
+                                            scans.  Other streams keep the host entropy stage. */
 
 typedef struct {
     int32_t width, height, num_components;
@@ -148,7 +149,7 @@ HIPJPEG_API hipjpegStatus_t hipjpegEntropyDecodeHostSparse(const uint8_t* data, 
 /* The GPU entropy decoder's algorithm (self-synchronizing subsequence decoding, csrc/huffman_gpu_core.h) executed on the
  * host, lane by lane, with the very code the kernels run: lets the algorithm be verified without a GPU.  Same output
  * layout as hipjpegEntropyDecodeHost; returns HIPJPEG_STATUS_UNSUPPORTED for streams the GPU entropy path does not take
- * (progressive, multi-scan, restart markers). */
+ * (sequential streams in several scans, arithmetic coding, progressive scripts beyond the walker's limits). */
 HIPJPEG_API hipjpegStatus_t hipjpegEntropyDecodeGpuAlgorithmHost(const uint8_t* data, size_t length, int16_t* coef,
                                                                  size_t coef_capacity_bytes, uint64_t comp_offsets[4],
                                                                  int32_t* sync_passes);
@@ -245,10 +246,11 @@ HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchDevice(hipjpegHandle_t handle, con
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchRelaunch(hipjpegHandle_t handle, void* stream);
 /* D2H of the quantized coefficients, then Huffman coding + marker writing on the host thread pool (blocking). */
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchHost(hipjpegHandle_t handle, hipjpegStatus_t* statuses);
-/* Entropy stage with a choice: flags = HIPJPEG_FLAG_GPU_HUFFMAN codes every image that uses the Annex-K tables without
- * restart markers on the GPU (lengths, prefix sums, bit packing, byte stuffing, file assembly -- only finished JPEG files
- * cross PCIe); images with optimized tables or restart intervals, and everything when flags = 0, go through the host coder
- * as in hipjpegEncodeBatchHost.  Blocking. */
+/* Entropy stage with a choice: flags = HIPJPEG_FLAG_GPU_HUFFMAN codes every baseline image without restart markers on the GPU
+ * (Annex-K tables, or optimized ones: histograms on the device, jpeg_gen_optimal_table on the host, second pass on the device; then
+ * lengths, prefix sums, bit packing, byte stuffing, file assembly -- only finished JPEG files cross PCIe); progressive output and restart
+ * intervals (which the reference's encode parameters do not have), and everything when flags = 0, go through the host coder as in
+ * hipjpegEncodeBatchHost.  Blocking. */
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatchEntropy(hipjpegHandle_t handle, unsigned flags, hipjpegStatus_t* statuses);
 /* Both of the above. */
 HIPJPEG_API hipjpegStatus_t hipjpegEncodeBatch(hipjpegHandle_t handle, const hipjpegEncodeInput_t* inputs, const hipjpegEncodeParams_t* params,
