@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Golden hashes for do_fancy_upsampling = FALSE (plugin option fancy_upsampling=0), from the REAL libjpeg-turbo.  Dev-container only.
+
+Pillow cannot switch fancy upsampling off, so until round 3 the replication path of the oracle and the kernels was "parity unpinned".
+This script drives the libjpeg-turbo that Pillow ships (pillow.libs/libjpeg-*.so.62.*, the library the other goldens come from) through
+its public C API with ctypes: jpeg_std_error, jpeg_CreateDecompress, jpeg_mem_src, jpeg_read_header, jpeg_start_decompress,
+jpeg_read_scanlines, jpeg_finish_decompress -- and clears cinfo.do_fancy_upsampling in between.
+
+No header of the library is installed here, so the two facts about `struct jpeg_decompress_struct` the script needs are MEASURED, not
+assumed:
+  * its size: jpeg_CreateDecompress refuses a wrong size with JERR_BAD_STRUCT_SIZE and names the right one in the message parameters
+    (a child process asks with size 1 and reads the answer in its error_exit callback);
+  * the offsets of the fields it reads and writes (image_width/height, num_components, out_color_space, do_fancy_upsampling,
+    output_width/height/components, output_scanline; libjpeg API v6.2 layout on LP64): the binding decodes EVERY file with fancy
+    upsampling left ON first and the pixels must equal Pillow's decode of the same file -- and with it OFF every 4:4:4 and gray file must
+    still equal Pillow's (nothing to upsample), every subsampled one must differ.  A wrong offset fails one of the three.
+
+Output: manifest_plain.json -- per file of tests/golden/decode: sha256 of the H x W x 3 RGB pixels (gray files: expanded to RGB like the
+other goldens) decoded with do_fancy_upsampling = FALSE.  (For 4:2:0 / 4:2:2 the library then takes its merged upsampling + colour
+conversion path, jdmerge.c -- the reference plugin's `fancy_upsampling=0` does exactly this, extensions/libjpeg_turbo/jpeg_mem.cpp:166.)"""
+import ctypes as C
+import glob
+import hashlib
+import io
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# struct jpeg_decompress_struct, libjpeg API 6.2, LP64 (validated below)
+OFF_IMAGE_WIDTH, OFF_IMAGE_HEIGHT, OFF_NUM_COMPONENTS, OFF_OUT_COLOR_SPACE = 48, 52, 56, 64
+OFF_DCT_METHOD, OFF_DO_FANCY = 96, 100
+OFF_OUTPUT_WIDTH, OFF_OUTPUT_HEIGHT, OFF_OUTPUT_COMPONENTS, OFF_OUTPUT_SCANLINE = 136, 140, 148, 168
+JCS_GRAYSCALE, JCS_RGB = 1, 2
+# struct jpeg_error_mgr: error_exit at 0, msg_code at 40, msg_parm.i[] at 44
+ERR_MSG_CODE, ERR_PARM = 40, 44
+
+
+def library_path():
+    import PIL
+    hits = glob.glob(os.path.join(os.path.dirname(PIL.__file__), "..", "pillow.libs", "libjpeg-*.so.62*"))
+    assert len(hits) == 1, hits
+    return os.path.abspath(hits[0])
+
+
+def load():
+    lib = C.CDLL(library_path())
+    lib.jpeg_std_error.restype = C.c_void_p
+    lib.jpeg_std_error.argtypes = [C.c_void_p]
+    lib.jpeg_CreateDecompress.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    lib.jpeg_mem_src.argtypes = [C.c_void_p, C.c_void_p, C.c_ulong]
+    lib.jpeg_read_header.argtypes = [C.c_void_p, C.c_int]
+    lib.jpeg_start_decompress.argtypes = [C.c_void_p]
+    lib.jpeg_read_scanlines.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    lib.jpeg_read_scanlines.restype = C.c_uint
+    lib.jpeg_finish_decompress.argtypes = [C.c_void_p]
+    lib.jpeg_destroy_decompress.argtypes = [C.c_void_p]
+    return lib
+
+
+ERROR_EXIT = C.CFUNCTYPE(None, C.c_void_p)
+
+
+def probe_struct_size():
+    """Runs in a child: asks jpeg_CreateDecompress with a wrong size and prints what the library says the size is."""
+    lib = load()
+    err = C.create_string_buffer(1024)
+    cinfo = C.create_string_buffer(4096)
+
+    @ERROR_EXIT
+    def on_error(cptr):
+        e = C.cast(cptr, C.POINTER(C.c_void_p))[0]  # cinfo->err
+        code = C.cast(e + ERR_MSG_CODE, C.POINTER(C.c_int))[0]
+        parm = C.cast(e + ERR_PARM, C.POINTER(C.c_int))
+        print("probe", code, parm[0], parm[1], flush=True)
+        os._exit(0)  # the library cannot be returned into from an error
+
+    lib.jpeg_std_error(err)
+    C.cast(err, C.POINTER(C.c_void_p))[0] = C.cast(on_error, C.c_void_p).value
+    C.cast(cinfo, C.POINTER(C.c_void_p))[0] = C.addressof(err)
+    lib.jpeg_CreateDecompress(cinfo, 62, 1)
+    print("probe none", flush=True)
+
+
+def struct_size():
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe"], capture_output=True, text=True, timeout=120).stdout.split()
+    # JERR_BAD_STRUCT_SIZE: parameters = (size the library was built with, size given)
+    assert out[0] == "probe" and out[1] != "none" and int(out[3]) == 1, out
+    return int(out[2])
+
+
+class Decoder:
+    def __init__(self):
+        self.lib = load()
+        self.size = struct_size()
+        assert 400 < self.size < 1024, self.size
+
+    def decode(self, data, fancy):
+        lib = self.lib
+        err = C.create_string_buffer(1024)
+        cinfo = C.create_string_buffer(self.size + 64)
+        base = C.addressof(cinfo)
+
+        def i32(off):
+            return C.cast(base + off, C.POINTER(C.c_int))
+
+        lib.jpeg_std_error(err)  # the default error_exit ends the process: the caller runs this in a child and checks its exit
+        C.cast(cinfo, C.POINTER(C.c_void_p))[0] = C.addressof(err)
+        lib.jpeg_CreateDecompress(cinfo, 62, self.size)
+        buf = C.create_string_buffer(bytes(data), len(data))
+        lib.jpeg_mem_src(cinfo, buf, len(data))
+        assert lib.jpeg_read_header(cinfo, 1) == 1
+        width, height, ncomp = i32(OFF_IMAGE_WIDTH)[0], i32(OFF_IMAGE_HEIGHT)[0], i32(OFF_NUM_COMPONENTS)[0]
+        assert i32(OFF_DCT_METHOD)[0] == 0 and i32(OFF_DO_FANCY)[0] == 1  # defaults: JDCT_ISLOW, fancy upsampling on
+        assert i32(OFF_OUT_COLOR_SPACE)[0] == (JCS_GRAYSCALE if ncomp == 1 else JCS_RGB)
+        i32(OFF_DO_FANCY)[0] = 1 if fancy else 0
+        lib.jpeg_start_decompress(cinfo)
+        ow, oh, oc = i32(OFF_OUTPUT_WIDTH)[0], i32(OFF_OUTPUT_HEIGHT)[0], i32(OFF_OUTPUT_COMPONENTS)[0]
+        assert (ow, oh) == (width, height) and oc == (1 if ncomp == 1 else 3), (ow, oh, oc)
+        out = np.zeros((oh, ow * oc), dtype=np.uint8)
+        row = (C.c_void_p * 1)()
+        while i32(OFF_OUTPUT_SCANLINE)[0] < oh:
+            y = i32(OFF_OUTPUT_SCANLINE)[0]
+            row[0] = out.ctypes.data + y * out.strides[0]
+            assert lib.jpeg_read_scanlines(cinfo, row, 1) == 1
+        lib.jpeg_finish_decompress(cinfo)
+        lib.jpeg_destroy_decompress(cinfo)
+        out = out.reshape(oh, ow, oc)
+        return np.repeat(out, 3, axis=2) if oc == 1 else out
+
+
+def main():
+    from PIL import Image, features
+    manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+    assert features.version_feature("libjpeg_turbo") == manifest["libjpeg_turbo"], "the goldens come from another library version"
+    dec = Decoder()
+    cases = []
+    differ = 0
+    for c in manifest["decode"]:
+        data = open(os.path.join(HERE, "decode", c["name"] + ".jpg"), "rb").read()
+        pil = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        assert hashlib.sha256(pil.tobytes()).hexdigest() == c["rgb_sha256"], c["name"]
+        on = dec.decode(data, True)
+        assert np.array_equal(on, pil), ("the binding's decode with fancy upsampling on is not Pillow's", c["name"])
+        off = dec.decode(data, False)
+        if c["sub"] in ("444", "gray"):
+            assert np.array_equal(off, pil), ("nothing to upsample, yet the switch changed pixels", c["name"])
+        elif c["width"] > 2 and c["height"] > 2:
+            differ += int(not np.array_equal(off, pil))
+        cases.append({"name": c["name"], "sub": c["sub"], "width": c["width"], "height": c["height"],
+                      "plain_rgb_sha256": hashlib.sha256(np.ascontiguousarray(off).tobytes()).hexdigest()})
+    assert differ > 40, differ  # the switch reached the library
+    out = {"generator": "tests/golden/make_golden_plain_upsampling.py", "libjpeg_turbo": manifest["libjpeg_turbo"], "library": os.path.basename(library_path()),
+           "jpeg_decompress_struct_bytes": dec.size, "subsampled_files_that_differ_from_fancy": differ, "decode": cases}
+    json.dump(out, open(os.path.join(HERE, "manifest_plain.json"), "w"), indent=1)
+    print("wrote manifest_plain.json:", len(cases), "files,", differ, "differ from the fancy decode; struct size", dec.size)
+
+
+if __name__ == "__main__":
+    if "--probe" in sys.argv:
+        probe_struct_size()
+    else:
+        main()

@@ -100,7 +100,7 @@ def test_cmyk_without_fancy_upsampling_and_as_raw_planes(dec):
     jpeg, _ = _load(e)
     outs, _ = dec.decode([jpeg], fmt="rgb", fancy=False)
     torch.cuda.synchronize()
-    assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(jpeg, oracle.FMT_RGB, fancy=False))   # parity unpinned (no fancy=0 vector)
+    assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(jpeg, oracle.FMT_RGB, fancy=False))   # parity unpinned for CMYK (manifest_plain.json pins fancy=0 for 1- and 3-component files)
     out = torch.zeros((e["height"], e["width"]), dtype=torch.uint8, device="cuda")
     _, st = dec.decode([jpeg], fmt="yuv_planar", outs=[[out, out, out]], check=False)
     assert st == [3]   # raw planes of a four-component frame: UNSUPPORTED, the chain moves on

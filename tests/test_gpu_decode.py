@@ -99,14 +99,18 @@ def test_tile_shapes_at_the_right_edge(dec, fmt):
 
 
 def test_fancy_upsampling_off(dec):
-    """fancy_upsampling=0 (python/decoder.cpp:283 default): replication.  The oracle's replicate path is not pinned by a
-    libjpeg-turbo vector (Pillow cannot switch do_fancy_upsampling off) -- 'parity unpinned' for this option."""
-    names = ["s50x37_420_base_q90", "s33x65_422_base_q50", "o50x37_440_base_q90", "s64x48_444_base_q90"]
-    jpegs = [load_decode_case(next(e for e in _M["decode"] if e["name"] == n))[0] for n in names]
-    outs, _ = dec.decode(jpegs, fmt="rgb", fancy=False)
-    _sync()
-    for j, o in zip(jpegs, outs):
-        assert np.array_equal(o.cpu().numpy(), oracle.decode(j, oracle.FMT_RGB, fancy=False))
+    """fancy_upsampling=0 (extensions/libjpeg_turbo/jpeg_mem.cpp:166 do_fancy_upsampling = FALSE): every golden file against the real
+    library's pixels (tests/golden/manifest_plain.json, made by driving libjpeg-turbo's C API: Pillow has no such switch), both entropy
+    stages."""
+    with open(os.path.join(GOLDEN, "manifest_plain.json")) as f:
+        plain = json.load(f)["decode"]
+    jpegs = [open(os.path.join(GOLDEN, "decode", e["name"] + ".jpg"), "rb").read() for e in plain]
+    for gh in (False, True):
+        outs, statuses = dec.decode(jpegs, fmt="rgb", fancy=False, gpu_huffman=gh)
+        _sync()
+        assert all(s == 0 for s in statuses)
+        for e, j, o in zip(plain, jpegs, outs):
+            assert _sha(o.cpu().numpy()) == e["plain_rgb_sha256"], (e["name"], gh)
 
 
 def test_pitched_and_unaligned_outputs(dec):

@@ -91,7 +91,7 @@ def _strided(torch, h, w, ch, pitch, offset):
 def test_generic_kernel_flavours_at_full_size(torch_mod, dec, shape, sub):
     """Everything that is NOT the COMMON flavour of the luma/colour kernel, at 1080p and 4K: BGR, planar RGB/BGR, an
     interleaved output that is not 16-byte aligned (odd offset, odd pitch), luma only, raw YUV planes, and
-    fancy_upsampling=0 (parity unpinned by libjpeg-turbo vectors: checked against the oracle's replication path only)."""
+    fancy_upsampling=0 (against the oracle's replication path, which tests/golden/manifest_plain.json pins to the real library)."""
     torch = torch_mod
     w, h = shape
     jpeg = oracle.encode(synth_image(w, h, seed=w + h + int(sub)), sub, 90)

@@ -2,30 +2,16 @@
 semantics, extensions/libjpeg_turbo/jpeg_mem.cpp:206-240) and EXIF orientation = the stored picture brought upright
 (ref src/parsers/exif_orientation.h:36-57 + extensions/nvjpeg/type_convert.cpp:43-64).  Expected values: the oracle's full
 decode, cropped and turned with numpy.  The reference applies orientation only inside closed-source nvJPEG, so the mapping
-itself is pinned by the EXIF definition (the same one Pillow's ImageOps.exif_transpose implements), not by a reference run."""
+itself is pinned by the EXIF definition and by Pillow's ImageOps.exif_transpose on files that carry the tag (tests/test_exif_turns.py), not by
+a reference run."""
 import numpy as np
 import pytest
 
 import oracle
+from helpers.geometry import upright
 from nvimagecodec_amd.synth import synth_image
 
 pytestmark = pytest.mark.gpu
-
-
-def upright(a, orientation):
-    """EXIF orientation -> numpy (a is H x W x C or H x W)"""
-    return {1: lambda x: x, 2: lambda x: x[:, ::-1], 3: lambda x: x[::-1, ::-1], 4: lambda x: x[::-1],
-            5: lambda x: x.swapaxes(0, 1), 6: lambda x: np.rot90(x, -1), 7: lambda x: np.rot90(x, 2).swapaxes(0, 1)[...],
-            8: lambda x: np.rot90(x, 1)}[orientation](a)
-
-
-def test_upright_helper_matches_the_exif_definition():
-    a = np.arange(6).reshape(2, 3)  # rows: [0 1 2], [3 4 5]
-    assert np.array_equal(upright(a, 6), [[3, 0], [4, 1], [5, 2]])      # turn 90 degrees clockwise
-    assert np.array_equal(upright(a, 8), [[2, 5], [1, 4], [0, 3]])      # turn 270 degrees clockwise
-    assert np.array_equal(upright(a, 5), a.T)                            # transpose
-    assert np.array_equal(upright(a, 7), [[5, 2], [4, 1], [3, 0]])      # transverse
-    assert np.array_equal(upright(a, 3), [[5, 4, 3], [2, 1, 0]])
 
 
 @pytest.fixture(scope="module")
