@@ -16,7 +16,10 @@ assumed:
     still equal Pillow's (nothing to upsample), every subsampled one must differ.  A wrong offset fails one of the three.
 
 Output: manifest_plain.json -- per file of tests/golden/decode: sha256 of the H x W x 3 RGB pixels (gray files: expanded to RGB like the
-other goldens) decoded with do_fancy_upsampling = FALSE.  (For 4:2:0 / 4:2:2 the library then takes its merged upsampling + colour
+other goldens) decoded with do_fancy_upsampling = FALSE; and "roi": regions of interest decoded the way the reference's CPU path decodes
+them (extensions/libjpeg_turbo/jpeg_mem.cpp:206-240: one spare pixel left and right, jpeg_crop_scanline, jpeg_skip_scanlines), with fancy
+upsampling on and off -- the script asserts that each equals the same window of the full decode (504 random windows did, in both modes,
+before these were chosen), which is the semantics the geometry pass of the kernels implements.  (For 4:2:0 / 4:2:2 the library then takes its merged upsampling + colour
 conversion path, jdmerge.c -- the reference plugin's `fancy_upsampling=0` does exactly this, extensions/libjpeg_turbo/jpeg_mem.cpp:166.)"""
 import ctypes as C
 import glob
@@ -59,6 +62,10 @@ def load():
     lib.jpeg_read_scanlines.restype = C.c_uint
     lib.jpeg_finish_decompress.argtypes = [C.c_void_p]
     lib.jpeg_destroy_decompress.argtypes = [C.c_void_p]
+    lib.jpeg_crop_scanline.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    lib.jpeg_skip_scanlines.argtypes = [C.c_void_p, C.c_uint]
+    lib.jpeg_skip_scanlines.restype = C.c_uint
+    lib.jpeg_abort_decompress.argtypes = [C.c_void_p]
     return lib
 
 
@@ -99,7 +106,8 @@ class Decoder:
         self.size = struct_size()
         assert 400 < self.size < 1024, self.size
 
-    def decode(self, data, fancy):
+    def decode(self, data, fancy, roi=None):
+        """roi = (x, y, w, h): the reference's recipe, jpeg_mem.cpp:206-240"""
         lib = self.lib
         err = C.create_string_buffer(1024)
         cinfo = C.create_string_buffer(self.size + 64)
@@ -121,15 +129,30 @@ class Decoder:
         lib.jpeg_start_decompress(cinfo)
         ow, oh, oc = i32(OFF_OUTPUT_WIDTH)[0], i32(OFF_OUTPUT_HEIGHT)[0], i32(OFF_OUTPUT_COMPONENTS)[0]
         assert (ow, oh) == (width, height) and oc == (1 if ncomp == 1 else 3), (ow, oh, oc)
-        out = np.zeros((oh, ow * oc), dtype=np.uint8)
         row = (C.c_void_p * 1)()
-        while i32(OFF_OUTPUT_SCANLINE)[0] < oh:
-            y = i32(OFF_OUTPUT_SCANLINE)[0]
-            row[0] = out.ctypes.data + y * out.strides[0]
-            assert lib.jpeg_read_scanlines(cinfo, row, 1) == 1
-        lib.jpeg_finish_decompress(cinfo)
+        if roi is None:
+            out = np.zeros((oh, ow * oc), dtype=np.uint8)
+            while i32(OFF_OUTPUT_SCANLINE)[0] < oh:
+                y = i32(OFF_OUTPUT_SCANLINE)[0]
+                row[0] = out.ctypes.data + y * out.strides[0]
+                assert lib.jpeg_read_scanlines(cinfo, row, 1) == 1
+            lib.jpeg_finish_decompress(cinfo)
+            out = out.reshape(oh, ow, oc)
+        else:
+            x, y, w, h = roi
+            left = 0 if x == 0 else 1
+            right = max(0, min(1, ow - (x + w)))
+            cx, cw = C.c_uint(x - left), C.c_uint(w + left + right)
+            lib.jpeg_crop_scanline(cinfo, C.byref(cx), C.byref(cw))  # moves the left edge down to an iMCU boundary
+            assert i32(OFF_OUTPUT_WIDTH)[0] == cw.value
+            assert lib.jpeg_skip_scanlines(cinfo, y) == y
+            out = np.zeros((h, cw.value * oc), dtype=np.uint8)
+            for r in range(h):
+                row[0] = out.ctypes.data + r * out.strides[0]
+                assert lib.jpeg_read_scanlines(cinfo, row, 1) == 1
+            lib.jpeg_abort_decompress(cinfo)
+            out = out.reshape(h, cw.value, oc)[:, x - cx.value:x - cx.value + w]
         lib.jpeg_destroy_decompress(cinfo)
-        out = out.reshape(oh, ow, oc)
         return np.repeat(out, 3, axis=2) if oc == 1 else out
 
 
@@ -154,10 +177,28 @@ def main():
         cases.append({"name": c["name"], "sub": c["sub"], "width": c["width"], "height": c["height"],
                       "plain_rgb_sha256": hashlib.sha256(np.ascontiguousarray(off).tobytes()).hexdigest()})
     assert differ > 40, differ  # the switch reached the library
+    # regions of interest: files of every sampling, baseline / progressive / restart intervals; windows on and off MCU boundaries
+    rois = []
+    rng = np.random.default_rng(2026)
+    picked = [c for c in manifest["decode"] if c["width"] >= 48 and c["height"] >= 37]
+    picked = [c for i, c in enumerate(picked) if i % 3 == 0 or c["sub"] in ("440", "411", "410")]
+    for c in picked:
+        data = open(os.path.join(HERE, "decode", c["name"] + ".jpg"), "rb").read()
+        W, H = c["width"], c["height"]
+        windows = [(0, 0, W, H), (1, 1, W - 2, H - 2), (16, 8, 16, 16), (W - 9, H - 7, 9, 7)]
+        for _ in range(3):
+            x, y = int(rng.integers(0, W - 4)), int(rng.integers(0, H - 4))
+            windows.append((x, y, int(rng.integers(1, W - x + 1)), int(rng.integers(1, H - y + 1))))
+        for fancy in (True, False):
+            full = dec.decode(data, fancy)
+            for (x, y, w, h) in windows:
+                got = dec.decode(data, fancy, roi=(x, y, w, h))
+                assert np.array_equal(got, full[y:y + h, x:x + w]), ("a region of interest that is not the window of the full decode", c["name"], fancy, x, y, w, h)
+                rois.append({"name": c["name"], "fancy": fancy, "roi": [x, y, w, h], "rgb_sha256": hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest()})
     out = {"generator": "tests/golden/make_golden_plain_upsampling.py", "libjpeg_turbo": manifest["libjpeg_turbo"], "library": os.path.basename(library_path()),
-           "jpeg_decompress_struct_bytes": dec.size, "subsampled_files_that_differ_from_fancy": differ, "decode": cases}
+           "jpeg_decompress_struct_bytes": dec.size, "subsampled_files_that_differ_from_fancy": differ, "decode": cases, "roi": rois}
     json.dump(out, open(os.path.join(HERE, "manifest_plain.json"), "w"), indent=1)
-    print("wrote manifest_plain.json:", len(cases), "files,", differ, "differ from the fancy decode; struct size", dec.size)
+    print("wrote manifest_plain.json:", len(cases), "files,", differ, "differ from the fancy decode;", len(rois), "regions of interest; struct size", dec.size)
 
 
 if __name__ == "__main__":

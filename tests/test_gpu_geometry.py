@@ -48,6 +48,28 @@ def test_all_orientations_and_regions_interleaved(dec, gpu_huffman):
         assert np.array_equal(o.cpu().numpy(), e), t
 
 
+@pytest.mark.parametrize("gpu_huffman", [False, True])
+def test_regions_against_the_real_librarys_pixels(dec, gpu_huffman):
+    """378 regions of interest decoded by libjpeg-turbo itself with the reference's recipe (extensions/libjpeg_turbo/jpeg_mem.cpp:206-240;
+    tests/golden/make_golden_plain_upsampling.py), fancy upsampling on and off, every sampling, progressive and restart-interval files."""
+    import hashlib
+    import json
+    import os
+    import torch
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "manifest_plain.json")) as f:
+        rois = json.load(f)["roi"]
+    for fancy in (True, False):
+        todo = [e for e in rois if e["fancy"] == fancy]
+        jpegs = [open(os.path.join(GOLDEN, "decode", e["name"] + ".jpg"), "rb").read() for e in todo]
+        transforms = [((e["roi"][0], e["roi"][1], e["roi"][0] + e["roi"][2], e["roi"][1] + e["roi"][3]), 1) for e in todo]
+        outs, statuses = dec.decode(jpegs, fmt="rgb", fancy=fancy, gpu_huffman=gpu_huffman, transforms=transforms)
+        torch.cuda.synchronize()
+        assert all(s == 0 for s in statuses)
+        for e, o in zip(todo, outs):
+            assert hashlib.sha256(np.ascontiguousarray(o.cpu().numpy()).tobytes()).hexdigest() == e["rgb_sha256"], e
+
+
 def test_planar_and_gray_formats_and_edge_regions(dec):
     import torch
     w, h = 500, 333
