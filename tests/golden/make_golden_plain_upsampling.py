@@ -16,7 +16,8 @@ assumed:
     still equal Pillow's (nothing to upsample), every subsampled one must differ.  A wrong offset fails one of the three.
 
 Output: manifest_plain.json -- per file of tests/golden/decode: sha256 of the H x W x 3 RGB pixels (gray files: expanded to RGB like the
-other goldens) decoded with do_fancy_upsampling = FALSE; and "roi": regions of interest decoded the way the reference's CPU path decodes
+other goldens) decoded with do_fancy_upsampling = FALSE; "cmyk": the same for the four-component files of tests/golden/cmyk (the library's
+CMYK samples; with the switch on they must equal the stored goldens); and "roi": regions of interest decoded the way the reference's CPU path decodes
 them (extensions/libjpeg_turbo/jpeg_mem.cpp:206-240: one spare pixel left and right, jpeg_crop_scanline, jpeg_skip_scanlines), with fancy
 upsampling on and off -- the script asserts that each equals the same window of the full decode (504 random windows did, in both modes,
 before these were chosen), which is the semantics the geometry pass of the kernels implements.  (For 4:2:0 / 4:2:2 the library then takes its merged upsampling + colour
@@ -38,7 +39,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OFF_IMAGE_WIDTH, OFF_IMAGE_HEIGHT, OFF_NUM_COMPONENTS, OFF_OUT_COLOR_SPACE = 48, 52, 56, 64
 OFF_DCT_METHOD, OFF_DO_FANCY = 96, 100
 OFF_OUTPUT_WIDTH, OFF_OUTPUT_HEIGHT, OFF_OUTPUT_COMPONENTS, OFF_OUTPUT_SCANLINE = 136, 140, 148, 168
-JCS_GRAYSCALE, JCS_RGB = 1, 2
+JCS_GRAYSCALE, JCS_RGB, JCS_CMYK = 1, 2, 4
 # struct jpeg_error_mgr: error_exit at 0, msg_code at 40, msg_parm.i[] at 44
 ERR_MSG_CODE, ERR_PARM = 40, 44
 
@@ -124,11 +125,11 @@ class Decoder:
         assert lib.jpeg_read_header(cinfo, 1) == 1
         width, height, ncomp = i32(OFF_IMAGE_WIDTH)[0], i32(OFF_IMAGE_HEIGHT)[0], i32(OFF_NUM_COMPONENTS)[0]
         assert i32(OFF_DCT_METHOD)[0] == 0 and i32(OFF_DO_FANCY)[0] == 1  # defaults: JDCT_ISLOW, fancy upsampling on
-        assert i32(OFF_OUT_COLOR_SPACE)[0] == (JCS_GRAYSCALE if ncomp == 1 else JCS_RGB)
+        assert i32(OFF_OUT_COLOR_SPACE)[0] == {1: JCS_GRAYSCALE, 3: JCS_RGB, 4: JCS_CMYK}[ncomp]  # (YCCK sources come out as CMYK too)
         i32(OFF_DO_FANCY)[0] = 1 if fancy else 0
         lib.jpeg_start_decompress(cinfo)
         ow, oh, oc = i32(OFF_OUTPUT_WIDTH)[0], i32(OFF_OUTPUT_HEIGHT)[0], i32(OFF_OUTPUT_COMPONENTS)[0]
-        assert (ow, oh) == (width, height) and oc == (1 if ncomp == 1 else 3), (ow, oh, oc)
+        assert (ow, oh) == (width, height) and oc == ncomp, (ow, oh, oc)
         row = (C.c_void_p * 1)()
         if roi is None:
             out = np.zeros((oh, ow * oc), dtype=np.uint8)
@@ -195,8 +196,23 @@ def main():
                 got = dec.decode(data, fancy, roi=(x, y, w, h))
                 assert np.array_equal(got, full[y:y + h, x:x + w]), ("a region of interest that is not the window of the full decode", c["name"], fancy, x, y, w, h)
                 rois.append({"name": c["name"], "fancy": fancy, "roi": [x, y, w, h], "rgb_sha256": hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest()})
+    # four-component files (tests/golden/cmyk): the library's CMYK samples, which the reference turns into RGB itself (jpeg_mem.cpp:292-337)
+    cmyk = []
+    cm = json.load(open(os.path.join(HERE, "manifest_cmyk.json")))
+    assert cm["libjpeg_turbo"] == manifest["libjpeg_turbo"]
+    cmyk_differ = 0
+    for c in cm["cmyk"]:
+        data = open(os.path.join(HERE, "cmyk", c["name"] + ".jpg"), "rb").read()
+        ref = np.fromfile(os.path.join(HERE, "cmyk", c["name"] + ".cmyk"), dtype=np.uint8).reshape(c["height"], c["width"], 4)
+        assert np.array_equal(dec.decode(data, True), ref), ("the binding's CMYK samples are not the golden ones", c["name"])
+        off = dec.decode(data, False)
+        assert c["subsampled"] or np.array_equal(off, ref), c["name"]
+        cmyk_differ += int(not np.array_equal(off, ref))
+        cmyk.append({"name": c["name"], "kind": c["kind"], "subsampled": c["subsampled"], "width": c["width"], "height": c["height"],
+                     "plain_cmyk_sha256": hashlib.sha256(np.ascontiguousarray(off).tobytes()).hexdigest()})
+    assert cmyk_differ >= 10, cmyk_differ
     out = {"generator": "tests/golden/make_golden_plain_upsampling.py", "libjpeg_turbo": manifest["libjpeg_turbo"], "library": os.path.basename(library_path()),
-           "jpeg_decompress_struct_bytes": dec.size, "subsampled_files_that_differ_from_fancy": differ, "decode": cases, "roi": rois}
+           "jpeg_decompress_struct_bytes": dec.size, "subsampled_files_that_differ_from_fancy": differ, "decode": cases, "cmyk": cmyk, "roi": rois}
     json.dump(out, open(os.path.join(HERE, "manifest_plain.json"), "w"), indent=1)
     print("wrote manifest_plain.json:", len(cases), "files,", differ, "differ from the fancy decode;", len(rois), "regions of interest; struct size", dec.size)
 

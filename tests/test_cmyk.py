@@ -4,6 +4,7 @@ the CPU path decodes them with libjpeg-turbo's JCS_CMYK output followed by its o
 Pinned by libjpeg-turbo vectors (tests/golden/make_golden_cmyk.py): the CMYK samples, including the YCCK conversion and the
 upsampling of subsampled components.  NOT pinned by any executable (the reference cannot be built here): the final
 CMYK -> RGB arithmetic -- restated from the cited lines in the oracle and in the kernel."""
+import hashlib
 import json
 import os
 
@@ -92,15 +93,30 @@ def test_gpu_decodes_every_cmyk_golden(dec, fmt, gpu_huffman):
         assert np.array_equal(o.cpu().numpy(), ref), (e["name"], fmt)
 
 
+with open(os.path.join(GOLDEN, "manifest_plain.json")) as _f:
+    _PLAIN = json.load(_f)["cmyk"]
+
+
+@pytest.mark.parametrize("entry", _PLAIN, ids=lambda e: e["name"])
+def test_oracle_cmyk_samples_without_fancy_upsampling_equal_libjpeg_turbo(entry):
+    """do_fancy_upsampling = FALSE on four-component files: the real library's samples (tests/golden/make_golden_plain_upsampling.py)"""
+    with open(os.path.join(GOLDEN, "cmyk", entry["name"] + ".jpg"), "rb") as f:
+        jpeg = f.read()
+    assert hashlib.sha256(np.ascontiguousarray(oracle.decode_cmyk(jpeg, fancy=False)).tobytes()).hexdigest() == entry["plain_cmyk_sha256"]
+
+
 @pytest.mark.gpu
 def test_cmyk_without_fancy_upsampling_and_as_raw_planes(dec):
     import torch
-    from nvimagecodec_amd import _native as N
+    for e in _PLAIN:
+        with open(os.path.join(GOLDEN, "cmyk", e["name"] + ".jpg"), "rb") as f:
+            jpeg = f.read()
+        outs, _ = dec.decode([jpeg], fmt="rgb", fancy=False)
+        torch.cuda.synchronize()
+        # the oracle's samples are pinned by the real library's (test above); its RGB is the reference's formula on them
+        assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(jpeg, oracle.FMT_RGB, fancy=False)), e["name"]
     e = next(x for x in _M if x["subsampled"] and x["kind"] == "adobe2" and not x["progressive"])
     jpeg, _ = _load(e)
-    outs, _ = dec.decode([jpeg], fmt="rgb", fancy=False)
-    torch.cuda.synchronize()
-    assert np.array_equal(outs[0].cpu().numpy(), oracle.decode(jpeg, oracle.FMT_RGB, fancy=False))   # parity unpinned for CMYK (manifest_plain.json pins fancy=0 for 1- and 3-component files)
     out = torch.zeros((e["height"], e["width"]), dtype=torch.uint8, device="cuda")
     _, st = dec.decode([jpeg], fmt="yuv_planar", outs=[[out, out, out]], check=False)
     assert st == [3]   # raw planes of a four-component frame: UNSUPPORTED, the chain moves on
