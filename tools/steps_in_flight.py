@@ -1,5 +1,5 @@
 """Dev tool: configs[1] from bitstreams resident in HBM with 1 / 2 / 3 decoder instances taking turns on streams of their own -- how much of a
-batch's idle phases (the tail kernels of the entropy stage) the next batch's kernels fill.  usage (GPU box): python tools/steps_in_flight.py [steps]"""
+batch's idle phases (the tail kernels of the entropy stage) the next batch's kernels fill.  usage (GPU box): python tools/steps_in_flight.py [steps [only this many in flight]]"""
 import os
 import sys
 import time
@@ -11,7 +11,8 @@ from nvimagecodec_amd.lowlevel import BatchDecoder
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 sources, _ = bench.make_inputs()
 jpegs = [sources[i % len(sources)] for i in range(bench.BATCH)]
-for n in (1, 2, 3):
+only = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for n in ((only,) if only else (1, 2, 3)):
     decs = [BatchDecoder(device=0, num_threads=bench.usable_cpus()) for _ in range(n)]
     streams = [torch.cuda.Stream() for _ in range(n)]
     outs = [d.allocate_outputs(jpegs, "rgb") for d in decs]
@@ -20,9 +21,19 @@ for n in (1, 2, 3):
         d.transfer()
     torch.cuda.synchronize()
 
+    stagger = os.environ.get("STAGGER", "1") != "0"
+    last_entropy = [None]
+
     def step(k):
         d, s = decs[k % n], streams[k % n]
+        # the entropy stages take turns (each waits for the one before it, whichever stream that ran on): a batch's pixel kernels -- bound by
+        # HBM -- then run beside the NEXT batch's entropy stage -- bound by instruction issue and latency -- instead of beside its pixel kernels
+        if stagger and n > 1 and last_entropy[0] is not None:
+            s.wait_event(last_entropy[0])
         d.device_stage(stream=s, which=6)
+        if stagger and n > 1:
+            last_entropy[0] = torch.cuda.Event()
+            last_entropy[0].record(s)
         d.device_stage(stream=s, which=0)
         d.device_stage(stream=s, which=1)
 
