@@ -1,13 +1,14 @@
 // progressive_gpu.hip -- gfx950 kernels for progressive (SOF2) scans on the GPU entropy stage.  Algorithm, data structures and
 // the reasons for the split into a sequential WALK and a parallel REPLAY: progressive_gpu_core.h.
 //
-//   prog_walk_kernel    grid = images x kProgChains workgroups of kProgMaxStages waves.  Workgroup (image, c < 4): the AC scans
-//                       of component c, one wave per scan, pipelined 64 blocks at a time through an LDS ring that carries the
-//                       blocks' history bitmaps from scan to scan.  Workgroup (image, 4): the DC scans, one wave, in file order
-//                       (first scans walked symbol by symbol into the compact DC planes, refinement scans 64 blocks per step).
-//                       A wave runs as a scalar machine: control flow, bit buffer, history bitmap, zigzag position are uniform
-//                       (SGPRs); what it indexes -- 64 stream words, a 64-entry first-level Huffman table, 64 history bitmaps,
-//                       the rank/select table of the current block -- sits in VGPRs and is read with v_readlane.
+//   prog_walk_kernel    grid = images: one workgroup per image, a wave for the DC scans and a wave per AC scan (the last stages of
+//                       the components first: they are the long ones and want SIMDs of their own).  The AC scans of a component are
+//                       pipelined 64 blocks at a time through LDS rings that carry the blocks' history bitmaps from scan to scan.
+//                       A wave runs as a scalar machine: control flow, position, history bitmap, zigzag state are uniform (SGPRs);
+//                       what it indexes -- the symbols decoded ahead for the 64 bit offsets of the current window of the stream, 64
+//                       history bitmaps, the rank/select table of the current block, the stream words -- sits in VGPRs and is read
+//                       with v_readlane.  DC first scans: the same windows, one loop over the scan's blocks; DC refinement scans:
+//                       64 blocks per step.
 //   prog_replay_kernel  one lane per block: all AC scans of the block from the recorded positions, coefficients assembled in
 //                       LDS, blocks stored as whole 128-byte lines (eight lanes per block).
 #include <hip/hip_runtime.h>

@@ -12,12 +12,12 @@
 //     (huffman_gpu_core.h) does not apply: the parse of a refinement scan is a sequential chain.  In libjpeg's standard
 //     script those scans carry ~3/4 of the bits of a q90 photo.
 // Therefore the work is split in two:
-//   walk   one WAVE per scan walks it sequentially, as a scalar machine (uniform control flow, tables and per-block history
-//          bitmaps in registers read with v_readlane, stream words 64 at a time in a VGPR), and records nothing but WHERE
+//   walk   one WAVE per scan walks it sequentially, as a scalar machine (uniform control flow; per-block history bitmaps and the
+//          symbols decoded ahead for a 64-bit window of the stream in registers read with v_readlane), and records nothing but WHERE
 //          every block's data starts.  It never touches a coefficient: the correction bits after a symbol are counted from
 //          the block's history bitmap with popcounts and a rank/select table, not looped over.  The scans of one component
-//          run as a pipeline of waves in one workgroup (scan n+1 needs the history scan n leaves behind, 64 blocks at a
-//          time, through an LDS ring), the components and the DC scans in other workgroups, all images at once -- the
+//          run as a pipeline of waves (scan n+1 needs the history scan n leaves behind, 64 blocks at a time, through an LDS
+//          ring), the components and the DC scans on other waves of the image's workgroup, all images at once -- the
 //          parallelism that exists: images x components x pipeline stages.
 //   replay one LANE per block replays all scans of its block from those positions (now every block is independent), builds
 //          the 64 coefficients in LDS and stores the block once, as a whole 128-byte line.

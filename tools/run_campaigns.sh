@@ -12,6 +12,7 @@ run() { echo "== $*" | tee -a $OUT; timeout -k 10 900 python3 "$@" 2>&1 | tail -
 run tests/campaigns/fuzz_pass1.py 31 $((40 * S))
 run tests/campaigns/fuzz_gpu.py 32 $((40 * S))
 run tests/campaigns/fuzz_damage.py 33 $((60 * S))
+run tests/campaigns/fuzz_progressive.py 41 $((40 * S))
 run tests/campaigns/fuzz_encode.py 34 $((60 * S))
 run tests/campaigns/fuzz_outputs.py 35 $((20 * S))
 run tests/campaigns/fuzz_geometry.py 36 $((20 * S))
