@@ -540,7 +540,11 @@ __global__ __launch_bounds__(kSyncThreads) void huff_sync_kernel(const HuffImage
 // place.
 constexpr int kTailWaves = 4;
 constexpr int kTailThreads = 64 * kTailWaves;
-constexpr int kTailSlots = 32;
+#ifndef HJ_TAIL_SLOTS
+#define HJ_TAIL_SLOTS 32  // A/B switch (tools/ab_entropy.sh): 64 row buffers per wave halve the helpings of the first tail round -- and take 414 us against 287
+#endif
+constexpr int kTailSlots = HJ_TAIL_SLOTS;
+static_assert(kTailSlots == 32 || kTailSlots == 64, "a power of two, at most one row buffer per lane");
 constexpr int kTailRowWords = kSubseqWords + 4;  // whole 16-byte groups
 
 struct TailWave {

@@ -16,7 +16,7 @@ seq = []
 for r in rows:
     n = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].split('::')[-1][:28]
     seq.append((n, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
-last = [i for i, (n, _) in enumerate(seq) if n.startswith('destuff_count')][-1]
+last = [i for i, (n, _) in enumerate(seq) if n.startswith('destuff_c')][-1]
 tot = 0
 for n, us in seq[last:]:
     print("%-30s %9.1f us" % (n, us)); tot += us
