@@ -25,6 +25,11 @@ namespace {
 #define HJ_GLOBAL __attribute__((address_space(1)))
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// How long a wave that waits for its pipeline neighbour sleeps between two looks at the counter, in units of 64 cycles.  A poll is a dozen
+// instructions through the compute unit's one scalar ALU, which the walking waves of up to three images share.
+#ifndef HJ_WALK_SLEEP
+#define HJ_WALK_SLEEP 2
+#endif
 constexpr int kWalkMaxWaves = 16;  // one workgroup per image: a wave for the DC scans and one per AC scan (gpu_progressive_eligible)
 constexpr int kWalkThreads = 64 * kWalkMaxWaves;
 
@@ -111,7 +116,8 @@ struct DcWalker : WordStream {
     uint32_t wv;                  // the current window
     uint32_t d;                   // the position is 64 wv + d
     uint32_t win;                 // per lane l: the 32 bits from bit 64 wv + l on
-    uint32_t F0, F1, F2, F3;      // per lane l and table slot: len | size << 5 of the code at bit 64 wv + l (0 = no such code)
+    uint32_t FA, FB;              // per lane l: len | size << 5 of the code at bit 64 wv + l (0 = no such code), 16 bits per table slot:
+                                  // slots 0 and 1 in FA, 2 and 3 in FB
     const HJ_LDS uint16_t* tables;
     uint32_t slot_words;
     uint32_t need;                // bit j: table slot j is looked up (slots that repeat an earlier slot's table are not)
@@ -127,30 +133,30 @@ struct DcWalker : WordStream {
     {
         wv = target;
         win = window_bits(*this, target);
-        F0 = lookup(0, win);
-        if (need & 2u) F1 = lookup(1, win);
-        if (need & 4u) F2 = lookup(2, win);
-        if (need & 8u) F3 = lookup(3, win);
+        FA = lookup(0, win);
+        if (need & 2u) FA |= lookup(1, win) << 16;
+        FB = 0;
+        if (need & 4u) FB = lookup(2, win);
+        if (need & 8u) FB |= lookup(3, win) << 16;
     }
     __device__ __forceinline__ void start(const uint32_t* stream, uint32_t stream_words)
     {
         open(stream, stream_words);
         d = 0;
-        F1 = F2 = F3 = 0;
         decode(0);
     }
     __device__ __forceinline__ uint32_t pos() const { return wv * 64u + d; }
-    // one DC symbol with the table in slot u: false = no such code (the position then stays where it is).  *diff = the difference it
-    // carries.  No way out of the middle: the caller collects the verdicts.
-    __device__ __forceinline__ bool symbol(uint32_t u, int* diff)
+    // One DC symbol with the table in slot shift16 / 16: false = no such code (the position then stays where it is).  *diff = the
+    // difference it carries.  No way out of the middle, no branch but the window's: the caller collects the verdicts.
+    __device__ __forceinline__ bool symbol(uint32_t shift16, int* diff)
     {
         if (__builtin_expect(d >= 64u, 0)) {
             const uint32_t at = wv * 64u + d;
             decode(at >> 6);
             d = at & 63u;
         }
-        const uint32_t f01 = u & 1u ? lane_read(F1, d) : lane_read(F0, d), f23 = u & 1u ? lane_read(F3, d) : lane_read(F2, d);
-        const uint32_t f = u & 2u ? f23 : f01;
+        const unsigned long long both = ((unsigned long long)lane_read(FB, d) << 32) | lane_read(FA, d);
+        const uint32_t f = (uint32_t)(both >> shift16) & 0xFFFFu;
         const uint32_t len = f & 31u, sz = f >> 5;  // sz <= 15: gpu_progressive_eligible() keeps other tables away
         // code (<= 16 bits) and value (<= 15 bits) lie in the same 32-bit window; sz == 0: v = 0 < 2^31 gives 0 - 1 + 1
         const uint32_t v = (uint32_t)(((unsigned long long)(lane_read(win, d) << len) << sz) >> 32);
@@ -236,7 +242,7 @@ struct DevWalker : WordStream {
                 slept = true;
                 w0 = wall_clock64();
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(HJ_WALK_SLEEP);
         }
         if (slept) waited += (uint32_t)(wall_clock64() - w0);
         return true;
@@ -418,34 +424,48 @@ __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint
         // The walk is ONE loop over the scan's blocks in scan order, no way out of its middle (a broken stream is noticed once per 64
         // blocks).  What a block needs -- which component it belongs to, which table that component uses -- comes from a pattern of the
         // MCU, one block per lane, read with a readlane; the predictors live in the lanes of a register too.  The 64 values of a group are
-        // collected in a register and stored together, every lane working out its own block's address.
+        // collected in a register and stored together: every lane keeps the MCU position and the MCU coordinates of "its" block of the
+        // group up to date by additions (no division, no descriptor loads in the loop) and looks the block's geometry up in the pattern.
         const uint32_t ncomp = uni(sc.ncomp);
-        uint32_t pat = 0;   // lane k < bpm: the k-th block of an MCU: table slot | component (position in the scan) << 2
-        uint32_t need = 1;  // bit j: slot j holds a table of its own (the first component that uses the table owns the slot)
+        const uint32_t blocks_per_mcu = ncomp == 1 ? 1u : bpm;
+        // per MCU position k (lane k < blocks_per_mcu):
+        uint32_t pat = 0;             // 16 x table slot | component (position in the scan) << 8   -- what the walk reads
+        uint32_t geo = 0, gbw = 0;    // h | v << 4 | dx << 8 | dy << 12 of the block; blocks_w of its component
+        uint32_t gplo = 0, gphi = 0;  // the component's DC plane
+        uint32_t need = 1;            // bit j: slot j holds a table of its own (the first component that uses the table owns the slot)
         {
-            uint32_t slot_of[4] = {0, 0, 0, 0};
-            for (uint32_t i = 1; i < ncomp; i++) {
+            uint32_t first = 0;
+            for (uint32_t i = 0; i < ncomp; i++) {
                 uint32_t slot = i;
                 for (uint32_t j = 0; j < i; j++)
                     if (uni(sc.table[j]) == uni(sc.table[i])) {
                         slot = j;
                         break;
                     }
-                slot_of[i] = slot;
                 if (slot == i) need |= 1u << i;
-            }
-            uint32_t first = 0;
-            for (uint32_t i = 0; i < ncomp; i++) {
                 const uint32_t c = uni(sc.comps[i]);
-                const uint32_t nb = ncomp == 1 ? 1u : uni(im.comp_h[c]) * uni(im.comp_v[c]);
-                if (lane >= first && lane < first + nb) pat = slot_of[i] | (i << 2);
-                first += nb;
+                const uint32_t h = ncomp == 1 ? 1u : uni(im.comp_h[c]), v = ncomp == 1 ? 1u : uni(im.comp_v[c]);
+                const unsigned long long plane = (unsigned long long)(uintptr_t)im.dc_plane[c];
+                if (lane >= first && lane < first + h * v) {
+                    const uint32_t r = lane - first, dy = r / h, dx = r - dy * h;
+                    pat = (slot * 16u) | (i << 8);
+                    geo = h | (v << 4) | (dx << 8) | (dy << 12);
+                    gbw = uni(im.blocks_w[c]);
+                    gplo = (uint32_t)plane;
+                    gphi = (uint32_t)(plane >> 32);
+                }
+                first += h * v;
             }
         }
-        const uint32_t blocks_per_mcu = ncomp == 1 ? 1u : bpm;
         w.need = need;
         w.start(reinterpret_cast<const uint32_t*>(sc.stream), hi.stream_words);
         const uint32_t al = uni(sc.al), nblocks = uni(sc.nblocks);
+        // scan-order block b = MCU b / blocks_per_mcu, position b % blocks_per_mcu; MCUs in raster order, `across` per row (a scan of one
+        // component: its real blocks in raster order, one per "MCU")
+        const uint32_t across = ncomp == 1 ? uni(im.nbx[uni(sc.comps[0])]) : uni(im.mcus_x);
+        uint32_t lk = lane % blocks_per_mcu, lm = lane / blocks_per_mcu;  // this lane's block of the current group: position, MCU ...
+        uint32_t lmy = lm / across, lmx = lm - lmy * across;               // ... and the MCU's coordinates
+        const uint32_t step_k = 64u % blocks_per_mcu, step_m = 64u / blocks_per_mcu;
         uint32_t predv = 0;  // lane i: predictor of the scan's i-th component
         uint32_t k = 0;      // position in the MCU
         bool bad = false;
@@ -456,16 +476,31 @@ __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint
                 const uint32_t p = lane_read(pat, k);
                 k = k + 1u == blocks_per_mcu ? 0u : k + 1u;
                 int diff;
-                bad |= !w.symbol(p & 3u, &diff);
-                const uint32_t i = p >> 2;
+                bad |= !w.symbol(p & 255u, &diff);
+                const uint32_t i = p >> 8;
                 const uint32_t pred = lane_read(predv, i) + (uint32_t)diff;
                 predv = lane == i ? pred : predv;
                 outv = lane == jj ? pred : outv;
             }
-            if (lane < cnt) {
-                uint32_t c, index, slot;
-                dc_block_address(im, sc, b0 + lane, bpm, &c, &index, &slot);
-                ((HJ_GLOBAL int16_t*)im.dc_plane[c])[index] = (int16_t)((int)outv * (1 << al));
+            {
+                const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lk * 4u), (int)geo);
+                const uint32_t bw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lk * 4u), (int)gbw);
+                const uint32_t plo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lk * 4u), (int)gplo);
+                const uint32_t phi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lk * 4u), (int)gphi);
+                const uint32_t h = g & 15u, v = (g >> 4) & 15u, dx = (g >> 8) & 15u, dy = g >> 12;
+                const uint32_t index = (lmy * v + dy) * bw + lmx * h + dx;
+                HJ_GLOBAL int16_t* plane = (HJ_GLOBAL int16_t*)(uintptr_t)(((unsigned long long)phi << 32) | plo);
+                if (lane < cnt) plane[index] = (int16_t)((int)outv * (1 << al));
+                // on to the lane's block of the next group
+                lk += step_k;
+                const bool carry = lk >= blocks_per_mcu;
+                lk -= carry ? blocks_per_mcu : 0u;
+                lmx += step_m + (carry ? 1u : 0u);
+                while (__builtin_amdgcn_ballot_w64(lmx >= across)) {  // (at most once for pictures wider than 64 MCUs)
+                    const bool wrap = lmx >= across;
+                    lmx -= wrap ? across : 0u;
+                    lmy += wrap ? 1u : 0u;
+                }
             }
             // (the position is checked once per group: a forged frame size cannot keep the wave walking through imaginary data)
             if (w.pos() > total_bits) bad = true;
