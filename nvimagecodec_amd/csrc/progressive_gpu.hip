@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kWalkThreads) void prog_walk_kernel(ProgImage* __re
         w.lap_last = __builtin_readcyclecounter();
 #endif
         const unsigned long long t0 = wall_clock64();
-        ok = prog_walk_ac(w, (int)sc.ss, (int)sc.se, (int)sc.ah, sc.nblocks, hi.total_bits);
+        ok = prog_walk_ac(w, (int)sc.ss, (int)sc.se, (int)sc.ah, w.has_next, sc.nblocks, hi.total_bits);
         if (lane == 0) {
             im.scan[im.chain[c][a]].walk_ticks = (uint32_t)(wall_clock64() - t0);
             im.scan[im.chain[c][a]].wait_ticks = w.waited;

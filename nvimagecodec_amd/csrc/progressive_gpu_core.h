@@ -115,12 +115,16 @@ HJ_HD int prog_popc64(uint64_t v)
 #define HJ_WALK_COUNT(n) ((void)0)
 #endif
 
+// The one non-plain symbol that is common -- "end of band, no run": how most blocks end -- keeps a tag of its own and its length, so that the
+// walk recognises it by the fast view alone.
 constexpr uint32_t kProgNotPlain = 64u << 16;
+constexpr uint32_t kProgEndOfBandTag = 65u;  // fast view (kProgEndOfBandTag << 16) | code length
 HJ_HD uint32_t prog_fast_entry(uint32_t e, bool refine)
 {
     const uint32_t len = e & 31u, s = (e >> 5) & 15u, r = (e >> 9) & 15u;
     const bool plain = refine ? s == 1u : s != 0u;
-    return plain ? ((r + 1u) << 16) | (len + s) : kProgNotPlain;
+    const uint32_t other = (s == 0u && r == 0u && len != 0u) ? (kProgEndOfBandTag << 16) | len : kProgNotPlain;
+    return plain ? ((r + 1u) << 16) | (len + s) : other;
 }
 HJ_HD uint64_t prog_bit_set(uint64_t h, uint32_t t)  // t < 64
 {
@@ -158,7 +162,9 @@ HJ_HD uint64_t prog_bit_set(uint64_t h, uint32_t t)  // t < 64
 //     of band): the machine's vector state is carried by that loop alone.  (Nested block / symbol loops made the compiler copy the whole state -- twenty registers
 //     -- into and out of every block, and wait for the lookups of the next window right behind their issue.)
 // Returns false when the stream breaks the rules (the host decoder then takes the image and names the error).
-template <bool REFINE, class W>
+// TRACK: another scan of the component follows and needs the history this one leaves behind (the last scan of a component -- the longest
+// walks are such -- does not keep it up to date: two instructions per symbol less).
+template <bool REFINE, bool TRACK, class W>
 HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total_bits)
 {
     if (nblocks == 0) return true;
@@ -219,20 +225,21 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
             bool next = true;
             if (HJ_LIKELY(!skip)) {
                 uint32_t k;  // position of the next coefficient to look at
+                uint32_t f;  // fast view of the symbol at the position (the one the coefficient loop stopped at)
                 if (!REFINE) {
                     // plain coefficients: run of r zeros, then a coefficient of s bits
-                    uint32_t f = w.fast_at(d);
+                    f = w.fast_at(d);
                     uint32_t kk = c + (f >> 16) + (d & ~63u);
                     while (HJ_LIKELY(kk <= last)) {  // (two symbols per turn: every second one saves the taken branch back to the top)
                         HJ_WALK_COUNT(w.lap_syms);
-                        h = prog_bit_set(h, kk);
+                        if (TRACK) h = prog_bit_set(h, kk);
                         d += f & 0xFFFFu;
                         c = kk;
                         f = w.fast_at(d);
                         kk = c + (f >> 16) + (d & ~63u);
                         if (HJ_UNLIKELY(kk > last)) break;
                         HJ_WALK_COUNT(w.lap_syms);
-                        h = prog_bit_set(h, kk);
+                        if (TRACK) h = prog_bit_set(h, kk);
                         d += f & 0xFFFFu;
                         c = kk;
                         f = w.fast_at(d);
@@ -243,7 +250,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                     // plain new coefficients: behind r zero-history coefficients; code, sign bit, then one correction bit for every
                     // non-zero-history coefficient passed on the way
                     uint32_t q = d - gprev;
-                    uint32_t f = w.fast_at(d);
+                    f = w.fast_at(d);
                     uint32_t t = zr + (f >> 16) + (d & ~63u);
                     while (HJ_LIKELY(t <= nz)) {  // (two symbols per turn: every second one saves the taken branch back to the top)
                         HJ_WALK_COUNT(w.lap_syms);
@@ -251,7 +258,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                         q += f & 0xFFFFu;
                         d = q + gprev;
                         zr = t;
-                        h = prog_bit_set(h, gprev + t);  // the coefficient's position
+                        if (TRACK) h = prog_bit_set(h, gprev + t);  // the coefficient's position
                         f = w.fast_at(d);
                         t = zr + (f >> 16) + (d & ~63u);
                         if (HJ_UNLIKELY(t > nz)) break;
@@ -260,7 +267,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                         q += f & 0xFFFFu;
                         d = q + gprev;
                         zr = t;
-                        h = prog_bit_set(h, gprev + t);
+                        if (TRACK) h = prog_bit_set(h, gprev + t);
                         f = w.fast_at(d);
                         t = zr + (f >> 16) + (d & ~63u);
                     }
@@ -276,6 +283,11 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                     base = nb;
                     next = false;
                     HJ_WALK_LAP(w, 2);
+                } else if (HJ_LIKELY((f >> 16) == kProgEndOfBandTag)) {
+                    // end of band, no run -- how most blocks end.  Refinement scans: + a correction bit for every non-zero-history
+                    // coefficient in the rest of the band (the band has se - ss + 1 - nz of them, gprev + 1 - ss lie in front of k)
+                    d += f & 0xFFFFu;
+                    if (REFINE) d += last - nz - gprev;
                 } else {
                     const uint32_t e = w.sym_at(d);
                     const uint32_t len = e & 31u, r = (e >> 9) & 15u, s = (e >> 5) & 15u;
@@ -309,7 +321,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                         if (REFINE) d += last - nz - gprev;
                     }
                 }
-                if (next) w.set_hist((int)j, h);
+                if (TRACK && next) w.set_hist((int)j, h);
                 HJ_WALK_LAP(w, 1);
             }
             if (next) {
@@ -333,9 +345,10 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
 }
 
 template <class W>
-HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, uint32_t nblocks, uint32_t total_bits)
+HJ_HD bool prog_walk_ac(W& w, int ss, int se, int ah, bool track, uint32_t nblocks, uint32_t total_bits)
 {
-    return ah ? prog_walk_scan<true>(w, ss, se, nblocks, total_bits) : prog_walk_scan<false>(w, ss, se, nblocks, total_bits);
+    if (ah) return track ? prog_walk_scan<true, true>(w, ss, se, nblocks, total_bits) : prog_walk_scan<true, false>(w, ss, se, nblocks, total_bits);
+    return track ? prog_walk_scan<false, true>(w, ss, se, nblocks, total_bits) : prog_walk_scan<false, false>(w, ss, se, nblocks, total_bits);
 }
 
 // ---------------------------------------------------------------------------------------------------------- the replay

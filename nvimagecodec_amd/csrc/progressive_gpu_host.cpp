@@ -340,7 +340,7 @@ int emulate_gpu_progressive(const uint8_t* data, size_t size, const FrameInfo& f
             w.hist_all = hist.data();
             w.pos_all = block_pos[s].data();
             w.refine = sc.ah != 0;
-            if (!prog_walk_ac(w, sc.ss, sc.se, sc.ah, sc.nblocks, total_bits[s])) return 1;
+            if (!prog_walk_ac(w, sc.ss, sc.se, sc.ah, stg + 1 < (int)im.chain_len[c], sc.nblocks, total_bits[s])) return 1;
         }
     }
     // ---- replay: every block of every component
