@@ -199,19 +199,19 @@ struct DevWalker : WordStream {
         nxt = table[win >> 24];
     }
     // window wv + 1 becomes the current one
-    __device__ __forceinline__ void finish()
+    __device__ __forceinline__ void finish(bool refinement)
     {
         uint32_t e = nxt;
         if (e & kProgLong) e = table[(e & 0x7FFFu) * 256u + ((nxt_win >> 16) & 255u)];
         cur = e;
         cur_win = nxt_win;
-        cur_fast = prog_fast_entry(e, refine);
+        cur_fast = prog_fast_entry(e, refinement);
     }
     __device__ __forceinline__ void start(const uint32_t* stream, uint32_t stream_words)
     {
         open(stream, stream_words);
         issue(0);
-        finish();
+        finish(refine);
         wv = 0;
         issue(1);
     }
@@ -220,12 +220,13 @@ struct DevWalker : WordStream {
     __device__ __forceinline__ uint32_t fast_at(uint32_t d) const { return lane_read(cur_fast, d); }
     __device__ __forceinline__ uint32_t sym_at(uint32_t d) const { return lane_read(cur, d); }
     __device__ __forceinline__ uint32_t bits_at(uint32_t d) const { return lane_read(cur_win, d); }
+    template <bool REFINE>
     __device__ __forceinline__ void sym_window(uint32_t at)
     {
         const uint32_t target = at >> 6;
         if (target == wv) return;
         if (__builtin_expect(target != wv + 1u, 0)) issue(target);  // a long end-of-band run has skipped windows
-        finish();
+        finish(REFINE);
         wv = target;
         issue(target + 1u);
     }

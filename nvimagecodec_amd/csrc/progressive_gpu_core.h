@@ -142,7 +142,7 @@ HJ_HD uint64_t prog_bit_set(uint64_t h, uint32_t t)  // t < 64
 //   uint32_t fast_at(uint32_t d)   prog_fast_entry of the code that starts at bit sym_base() + d; d >= 64 returns anything
 //   uint32_t sym_at(uint32_t d)    its lookup-table entry (0 = no such code), d < 64
 //   uint32_t bits_at(uint32_t d)   the 32 bits of the stream from bit sym_base() + d on, MSB first, d < 64
-//   void sym_window(uint32_t p)    make the window that holds bit p the current one
+//   void sym_window<REFINE>(p)     make the window that holds bit p the current one (REFINE: the fast views are a refinement scan's)
 //   void group_begin(uint32_t g)   history bitmaps of blocks [64 g, 64 g + 64) become available (waits for the previous stage)
 //   uint64_t hist(int j) / void set_hist(int j, uint64_t)   history bitmap of block j of the current group
 //   void set_pos(int j, uint32_t)  block_pos of block j of the current group
@@ -277,7 +277,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                 if (k > last) {
                     // the band is complete
                 } else if (d >= 64u) {
-                    w.sym_window(base + d);
+                    w.template sym_window<REFINE>(base + d);
                     const uint32_t nb = w.sym_base();
                     d = base + d - nb;
                     base = nb;

@@ -269,7 +269,11 @@ struct HostWalker {
     }
     uint32_t sym_at(uint32_t d) { return host_lookup(table, bits_at(d)); }
     uint32_t fast_at(uint32_t d) { return prog_fast_entry(sym_at(d), refine); }
-    void sym_window(uint32_t at) { wv = at >> 6; }
+    template <bool REFINE>
+    void sym_window(uint32_t at)
+    {
+        wv = at >> 6;
+    }
     void group_begin(uint32_t g) { group = g; }
     uint64_t hist(int j) const { return hist_all[(size_t)group * kProgGroup + ((unsigned)j & 63u)]; }  // (the walk's first hist(-1) reads lane 63)
     void set_hist(int j, uint64_t h) { hist_all[(size_t)group * kProgGroup + j] = h; }
