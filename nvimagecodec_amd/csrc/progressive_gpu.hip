@@ -428,7 +428,7 @@ __device__ bool walk_dc_chain(ProgImage& im, const HuffImage* himgs, HJ_LDS uint
         // collected in a register and stored together: every lane keeps the MCU position and the MCU coordinates of "its" block of the
         // group up to date by additions (no division, no descriptor loads in the loop) and looks the block's geometry up in the pattern.
         const uint32_t ncomp = uni(sc.ncomp);
-        const uint32_t blocks_per_mcu = ncomp == 1 ? 1u : bpm;
+        const uint32_t blocks_per_mcu = ncomp == 1 ? 1u : uni(bpm);  // (uniform anyway; said so, the MCU position stays in a scalar register)
         // per MCU position k (lane k < blocks_per_mcu):
         uint32_t pat = 0;             // 16 x table slot | component (position in the scan) << 8   -- what the walk reads
         uint32_t geo = 0, gbw = 0;    // h | v << 4 | dx << 8 | dy << 12 of the block; blocks_w of its component

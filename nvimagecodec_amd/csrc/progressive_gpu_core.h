@@ -184,13 +184,17 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
 
     // Called from ONE place (a second call site would make the compiler merge the two in-flight rank/select tables with a copy, and wait
     // for the crossbar right behind its issue): the loop below starts one block early, on a block that does not exist.
+    uint64_t hnext = 0;  // refinement scans: the history of the block after the current one (read once, for the preparation and for the block)
     auto block_start = [&]() {
-        h = w.hist((int)j);
         if (REFINE) {
+            h = hnext;
             w.zeros_take();
             // the next block's, in the shadow of this block's walk (behind the group's last block: of whatever lane 0 holds, never used --
             // a condition here would cost a copy of the table and a wait for the crossbar)
-            w.zeros_prepare(~w.hist((int)j + 1) & band);
+            hnext = w.hist((int)j + 1);
+            w.zeros_prepare(~hnext & band);
+        } else {
+            h = w.hist((int)j);
         }
         if (HJ_UNLIKELY(j == ~0u)) {
             skip = true;  // the block in front of the group's first: nothing but the preparation of block 0
@@ -224,7 +228,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
         do {
             bool next = true;
             if (HJ_LIKELY(!skip)) {
-                uint32_t k;  // position of the next coefficient to look at
+                uint32_t placed;  // position of the last coefficient placed or passed (the next one to look at is placed + 1)
                 uint32_t f;  // fast view of the symbol at the position (the one the coefficient loop stopped at)
                 if (!REFINE) {
                     // plain coefficients: run of r zeros, then a coefficient of s bits
@@ -245,7 +249,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                         f = w.fast_at(d);
                         kk = c + (f >> 16) + (d & ~63u);
                     }
-                    k = c + 1u;
+                    placed = c;
                 } else {
                     // plain new coefficients: behind r zero-history coefficients; code, sign bit, then one correction bit for every
                     // non-zero-history coefficient passed on the way
@@ -271,10 +275,10 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                         f = w.fast_at(d);
                         t = zr + (f >> 16) + (d & ~63u);
                     }
-                    k = gprev + 1u + zr;
+                    placed = gprev + zr;
                 }
                 HJ_WALK_LAP(w, 0);
-                if (k > last) {
+                if (placed >= last) {
                     // the band is complete
                 } else if (d >= 64u) {
                     w.template sym_window<REFINE>(base + d);
@@ -285,7 +289,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                     HJ_WALK_LAP(w, 2);
                 } else if (HJ_LIKELY((f >> 16) == kProgEndOfBandTag)) {
                     // end of band, no run -- how most blocks end.  Refinement scans: + a correction bit for every non-zero-history
-                    // coefficient in the rest of the band (the band has se - ss + 1 - nz of them, gprev + 1 - ss lie in front of k)
+                    // coefficient in the rest of the band (the band has se - ss + 1 - nz of them, gprev + 1 - ss lie in front of the position)
                     d += f & 0xFFFFu;
                     if (REFINE) d += last - nz - gprev;
                 } else {
@@ -317,7 +321,7 @@ HJ_HD bool prog_walk_scan(W& w, int ss, int se, uint32_t nblocks, uint32_t total
                         eobrun = (1u << r) - 1u + (r ? (w.bits_at(d) << len) >> (32 - r) : 0u);  // this block is the run's first
                         d += len + r;
                         // + a correction bit for every non-zero-history coefficient in the rest of the band: the band has se - ss + 1 - nz of
-                        // them, gprev + 1 - ss lie in front of k (k - ss positions, zr of them zero-history)
+                        // them, gprev + 1 - ss lie in front of the position (position - ss places, zr of them zero-history)
                         if (REFINE) d += last - nz - gprev;
                     }
                 }
