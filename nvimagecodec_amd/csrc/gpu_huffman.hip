@@ -342,8 +342,12 @@ __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __
     if (blockIdx.x == 0 && threadIdx.x < 64 && counters) counters[threadIdx.x] = 0u;
     __shared__ uint32_t scratch[4];
     __shared__ uint32_t wave_base[4];
-    __shared__ uint32_t out_words[kDestuffChunk / 4 + 2];
-    HJ_LDS uint8_t* out = (HJ_LDS uint8_t*)out_words;
+    // One LDS buffer, twice: first the raw chunk (loaded as consecutive dwords: whole lines per wave), then the compacted image.  Both are
+    // PADDED by a dword per 64 bytes -- dword g sits at g + (g >> 4), byte k at k + (k >> 6 << 2): a lane owns 64 consecutive bytes, its
+    // neighbour the next 64, and without the padding the lanes of a wave would all hit the same two banks (round 2's version did: 55 % of
+    // its LDS cycles were bank conflicts, and its global loads touched 64 lines per instruction).
+    __shared__ uint32_t buf[kDestuffChunk / 4 + kDestuffChunk / 64 + 8];
+    HJ_LDS uint8_t* bytes = (HJ_LDS uint8_t*)buf;
     const HuffUnit u = units[blockIdx.x];
     HuffImage& im = images[u.image];
     const int t = threadIdx.x;
@@ -357,15 +361,29 @@ __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __
     const uint32_t gout = chunk_begin - before;  // destination offset of the chunk's first kept byte
     const uint32_t a = gout & 3;                 // the LDS image shares the destination's misalignment
 
+    // raw chunk -> LDS (the raw copy is padded to 16 bytes with a neutral value and 16 more: whole 16-byte pieces are readable)
+    {
+        const uint32_t readable = (chunk_len + 15) / 16 * 4;  // dwords
+        const HJ_GLOBAL uint32_t* src = (const HJ_GLOBAL uint32_t*)(im.raw + chunk_begin);
+#pragma unroll
+        for (uint32_t i = 0; i < kDestuffChunk / 4 / kThreads; i++) {
+            const uint32_t g = i * kThreads + t;
+            buf[g + (g >> 4)] = g < readable ? src[g] : 0x01010101u;
+        }
+    }
+    const uint32_t before_chunk = chunk_begin > 0 ? im.raw[chunk_begin - 1] : 0u;                    // (lane 0's predecessor byte)
+    const uint32_t behind_chunk = chunk_len == (uint32_t)kDestuffChunk ? im.raw[chunk_begin + kDestuffChunk] : 0x01u;  // (lane 255's successor)
+    __syncthreads();
+
     const uint32_t off = chunk_begin + t * 64;
     uint32_t m[16], x[16];
     uint32_t n = 0, len = 0;
     if (off < raw_bytes) {
         len = min(64u, raw_bytes - off);
         const uint32_t pieces = (len + 15) / 16;
-        uint32_t prev = off > 0 ? im.raw[off - 1] : 0u;
-        for (uint32_t i = 0; i < 16; i++) x[i] = i < pieces * 4 ? reinterpret_cast<const uint32_t*>(im.raw + off)[i] : 0x01010101u;
-        const uint32_t behind = pieces == 4 ? im.raw[off + 64] : 0x01u;  // 16 neutral bytes of padding follow the data
+        uint32_t prev = t > 0 ? buf[(t - 1) * 17 + 15] >> 24 : before_chunk;
+        for (uint32_t i = 0; i < 16; i++) x[i] = i < pieces * 4 ? buf[t * 17 + i] : 0x01010101u;
+        const uint32_t behind = pieces == 4 ? (t < kThreads - 1 ? buf[(t + 1) * 17] & 0xFFu : behind_chunk) : 0x01u;
         for (uint32_t i = 0; i < 16; i++) {
             m[i] = stuffed_mask(x[i], prev, i < 15 ? (x[i < 15 ? i + 1 : 15] & 0xFFu) : behind);
             prev = x[i] >> 24;
@@ -379,24 +397,25 @@ __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __
         if ((t & 63) >= d) incl += v;
     }
     if ((t & 63) == 63) wave_base[t >> 6] = incl;
-    __syncthreads();
+    __syncthreads();  // (every lane holds its 64 bytes in registers from here on: the buffer is free for the compacted image)
     uint32_t excl = incl - n;
     for (int w = 0; w < (t >> 6); w++) excl += wave_base[w];
     const uint32_t chunk_drops = wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
     // kept bytes of this lane -> LDS
+    auto padded = [](uint32_t k) { return k + ((k >> 6) << 2); };
     if (len) {
         uint32_t o = a + t * 64 - excl;
         for (uint32_t i = 0; i < 16; i++) {
             const uint32_t w = x[i], mask = m[i];
             if (i * 4 + 4 <= len && mask == 0) {
-                out[o] = (uint8_t)w;
-                out[o + 1] = (uint8_t)(w >> 8);
-                out[o + 2] = (uint8_t)(w >> 16);
-                out[o + 3] = (uint8_t)(w >> 24);
+                bytes[padded(o)] = (uint8_t)w;
+                bytes[padded(o + 1)] = (uint8_t)(w >> 8);
+                bytes[padded(o + 2)] = (uint8_t)(w >> 16);
+                bytes[padded(o + 3)] = (uint8_t)(w >> 24);
                 o += 4;
             } else {
                 for (uint32_t b = 0; b < 4; b++)
-                    if (i * 4 + b < len && !((mask >> (8 * b + 7)) & 1)) out[o++] = (uint8_t)(w >> (8 * b));
+                    if (i * 4 + b < len && !((mask >> (8 * b + 7)) & 1)) bytes[padded(o++)] = (uint8_t)(w >> (8 * b));
             }
         }
     }
@@ -405,11 +424,11 @@ __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __
     const uint32_t n_out = chunk_len - chunk_drops;
     uint8_t* dst = const_cast<uint8_t*>(im.stream) + (gout - a);  // 4-byte aligned
     const uint32_t first_full = a ? 1 : 0, end_full = (a + n_out) / 4;
-    for (uint32_t d = first_full + t; d < end_full; d += kThreads) reinterpret_cast<uint32_t*>(dst)[d] = out_words[d];
+    for (uint32_t d = first_full + t; d < end_full; d += kThreads) reinterpret_cast<uint32_t*>(dst)[d] = buf[d + (d >> 4)];
     if (t < 4) {
-        if (a && (uint32_t)t >= a && (uint32_t)t < a + n_out) dst[t] = out[t];  // head
+        if (a && (uint32_t)t >= a && (uint32_t)t < a + n_out) dst[t] = bytes[padded((uint32_t)t)];  // head
         const uint32_t tail = max(end_full, first_full) * 4 + t;
-        if (tail >= a && tail < a + n_out && tail >= 4 * first_full) dst[tail] = out[tail];
+        if (tail >= a && tail < a + n_out && tail >= 4 * first_full) dst[tail] = bytes[padded(tail)];
     }
     // the last chunk knows the destuffed length: publish it and lay down the 0xFF slack behind the data
     if (chunk_begin + chunk_len == raw_bytes) {
