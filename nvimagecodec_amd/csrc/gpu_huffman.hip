@@ -334,6 +334,8 @@ __global__ __launch_bounds__(kThreads) void destuff_count_kernel(const HuffImage
     if (threadIdx.x == 0) drops[im.first_chunk + u.first] = total;
 }
 
+// (256 x 1080p: 94 us for 2,048 chunks, eight resident per CU.  The time is the chunks' work, not their number: two chunks per workgroup 147 us,
+// four 149.  Per CU and launch the LDS pipeline is busy 33 us -- 64 single-byte stores per lane -- and the vector ALUs 20.)
 __global__ __launch_bounds__(kThreads) void destuff_compact_kernel(HuffImage* __restrict__ images, const HuffUnit* __restrict__ units,
                                                                    const uint32_t* __restrict__ drops, unsigned int* __restrict__ counters)
 {
