@@ -844,6 +844,51 @@ void DecodeBatch::finalize(hipjpegStatus_t* statuses)
         off += v.size() * sizeof(WorkUnit);
     };
     put(plane_units_, &unit_off_plane_);
+    // The luma tiles of a tile row share chroma lines at their seams (fancy upsampling reads a sample to the left and to the right of a
+    // tile: one more 128-byte line on either side), and the hardware deals workgroups to the eight XCDs -- eight L2 caches -- in turn.  So the
+    // rows are dealt to eight queues and the list takes one tile of every queue in turn: position p goes to XCD p % 8, a row's tiles follow
+    // each other on ONE XCD and find their neighbour's lines in its L2.  (HIPJPEG_ROW_MAJOR_TILES=1: the plain order, for A/B runs.)
+    static const bool row_major = getenv("HIPJPEG_ROW_MAJOR_TILES") != nullptr;
+    auto deal_rows_to_xcds = [&](std::vector<WorkUnit>& v) {
+        if (row_major || v.size() < 64) return;
+        constexpr size_t kXcds = 8;
+        std::vector<WorkUnit> queue[kXcds], rest, out;
+        out.reserve(v.size());
+        auto flush = [&]() {  // one picture's tiles: a tile of every queue in turn, then its narrow edge tiles (the list stays sorted by picture)
+            size_t taken[kXcds] = {0};
+            for (bool any = true; any;) {
+                any = false;
+                for (size_t q = 0; q < kXcds; q++)
+                    if (taken[q] < queue[q].size()) {
+                        out.push_back(queue[q][taken[q]++]);
+                        any = true;
+                    }
+            }
+            out.insert(out.end(), rest.begin(), rest.end());
+            for (auto& q : queue) q.clear();
+            rest.clear();
+        };
+        size_t row = 0;
+        for (size_t a = 0; a < v.size();) {
+            size_t b = a + 1;
+            while (b < v.size() && v[b].image == v[a].image && v[b].comp == v[a].comp && v[b].mode == v[a].mode) b++;
+            if (a > 0 && v[a].image != v[a - 1].image) {
+                flush();
+                row = 0;
+            }
+            if (v[a].mode != 0) {
+                rest.insert(rest.end(), v.begin() + (long)a, v.begin() + (long)b);
+            } else {
+                std::vector<WorkUnit>& q = queue[row++ % kXcds];
+                q.insert(q.end(), v.begin() + (long)a, v.begin() + (long)b);
+            }
+            a = b;
+        }
+        flush();
+        v.swap(out);
+    };
+    for (int e = 0; e < kNumLumaLayouts; e++)
+        for (int k = 0; k < kNumLumaVariants; k++) deal_rows_to_xcds(luma_units_[e][k]);
     for (int e = 0; e < kNumLumaLayouts; e++)
         for (int k = 0; k < kNumLumaVariants; k++) put(luma_units_[e][k], &unit_off_luma_[e][k]);
     put(fused_plane_units_, &unit_off_fused_plane_);
