@@ -158,3 +158,95 @@ def random_coefficients(rng, width, height, sampling, extreme, dense=6, small=3,
             np.put_along_axis(a, pos[..., None], val[..., None], axis=2)
         res.append(a)
     return res
+
+
+def write_progressive(width, height, sampling, coefficients, qtables, script):
+    """A progressive (SOF2) file by spectral selection only -- no successive approximation, no end-of-band runs -- with a CHOSEN scan
+    script, for the scan layouts libjpeg's default script does not produce (DC scans of one component, DC scans of some components, AC
+    bands cut anywhere).  script: list of ("dc", [component, ...]) and ("ac", component, ss, se); every coefficient must be covered
+    exactly once and a component's DC scan must come before its AC scans.  Other arguments as write_baseline (8-bit tables only).
+    Interleaved scans walk the MCU-padded grid MCU by MCU; a scan of one component walks its REAL blocks (ceil(samples / 8) each way) in
+    raster order (T.81 A.2.2).  Returns the file as bytes."""
+    ncomp = len(sampling)
+    hmax, vmax = max(h for h, _ in sampling), max(v for _, v in sampling)
+    mcus_x, mcus_y = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    out = bytearray(b"\xff\xd8")
+    for c in range(ncomp):
+        q = [int(qtables[c][ZIGZAG[k]]) for k in range(64)]
+        assert all(1 <= x <= 255 for x in q)
+        out += b"\xff\xdb" + (67).to_bytes(2, "big") + bytes([c]) + bytes(q)
+    out += b"\xff\xc2" + (8 + 3 * ncomp).to_bytes(2, "big") + b"\x08" + height.to_bytes(2, "big") + width.to_bytes(2, "big") + bytes([ncomp])
+    for c, (h, v) in enumerate(sampling):
+        out += bytes([c + 1, (h << 4) | v, c])
+    tables = [(0x00, DC_LUMA), (0x10, AC_LUMA)] + ([(0x01, DC_CHROMA), (0x11, AC_CHROMA)] if ncomp > 1 else [])
+    for ident, (bits, vals) in tables:
+        out += b"\xff\xc4" + (19 + len(vals)).to_bytes(2, "big") + bytes([ident]) + bytes(bits) + bytes(vals)
+    dc_codes = [_codes(*DC_LUMA)] + [_codes(*DC_CHROMA)] * (ncomp - 1)
+    ac_codes = [_codes(*AC_LUMA)] + [_codes(*AC_CHROMA)] * (ncomp - 1)
+
+    def real_blocks(c):
+        h, v = sampling[c]
+        cw, ch = -(-width * h // hmax), -(-height * v // vmax)  # the component's samples
+        return -(-cw // 8), -(-ch // 8)
+
+    for entry in script:
+        bw = _Bits()
+        if entry[0] == "dc":
+            comps = list(entry[1])
+            out += b"\xff\xda" + (6 + 2 * len(comps)).to_bytes(2, "big") + bytes([len(comps)])
+            for c in comps:
+                out += bytes([c + 1, 0x00 if c == 0 else 0x10])
+            out += b"\x00\x00\x00"
+            pred = {c: 0 for c in comps}
+
+            def dc(c, blk):
+                diff = int(blk[0]) - pred[c]
+                pred[c] = int(blk[0])
+                nb, bits = _magnitude(diff)
+                assert nb <= 11
+                bw.put(*dc_codes[c][nb])
+                if nb:
+                    bw.put(bits, nb)
+
+            if len(comps) == 1:
+                c = comps[0]
+                nbx, nby = real_blocks(c)
+                for y in range(nby):
+                    for x in range(nbx):
+                        dc(c, coefficients[c][y][x])
+            else:
+                for my in range(mcus_y):
+                    for mx in range(mcus_x):
+                        for c in comps:
+                            h, v = sampling[c]
+                            for by in range(v):
+                                for bx in range(h):
+                                    dc(c, coefficients[c][my * v + by][mx * h + bx])
+        else:
+            _, c, ss, se = entry
+            assert 1 <= ss <= se <= 63
+            out += b"\xff\xda" + (8).to_bytes(2, "big") + bytes([1, c + 1, 0x00 if c == 0 else 0x11, ss, se, 0x00])
+            nbx, nby = real_blocks(c)
+            for y in range(nby):
+                for x in range(nbx):
+                    blk = coefficients[c][y][x]
+                    run = 0
+                    for k in range(ss, se + 1):
+                        val = int(blk[ZIGZAG[k]])
+                        if val == 0:
+                            run += 1
+                            continue
+                        while run > 15:
+                            bw.put(*ac_codes[c][0xF0])
+                            run -= 16
+                        nb, bits = _magnitude(val)
+                        assert nb <= 10
+                        bw.put(*ac_codes[c][(run << 4) | nb])
+                        bw.put(bits, nb)
+                        run = 0
+                    if run:
+                        bw.put(*ac_codes[c][0x00])  # end of band, a run of one block
+        bw.flush()
+        out += bw.out
+    out += b"\xff\xd9"
+    return bytes(out)
