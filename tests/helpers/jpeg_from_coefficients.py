@@ -161,12 +161,13 @@ def random_coefficients(rng, width, height, sampling, extreme, dense=6, small=3,
 
 
 def write_progressive(width, height, sampling, coefficients, qtables, script):
-    """A progressive (SOF2) file by spectral selection only -- no successive approximation, no end-of-band runs -- with a CHOSEN scan
-    script, for the scan layouts libjpeg's default script does not produce (DC scans of one component, DC scans of some components, AC
-    bands cut anywhere).  script: list of ("dc", [component, ...]) and ("ac", component, ss, se); every coefficient must be covered
-    exactly once and a component's DC scan must come before its AC scans.  Other arguments as write_baseline (8-bit tables only).
-    Interleaved scans walk the MCU-padded grid MCU by MCU; a scan of one component walks its REAL blocks (ceil(samples / 8) each way) in
-    raster order (T.81 A.2.2).  Returns the file as bytes."""
+    """A progressive (SOF2) file with a CHOSEN scan script, for the scan layouts libjpeg's default script does not produce (DC scans of one
+    component, DC scans of some components, AC bands cut anywhere, refinement passes over parts of a band).  script: list of
+    ("dc", [component, ...], ah, al) and ("ac", component, ss, se, ah, al) -- ah / al may be left out (0, 0: spectral selection only).  The
+    caller keeps the progression consistent (T.81 G.1.1.1.1: a first pass with ah = 0 before refinements, each with ah = the previous al and
+    al = ah - 1; a component's DC before its AC).  Coding follows jcphuff.c with end-of-band runs of ONE block (every block closes its band
+    itself).  Other arguments as write_baseline (8-bit tables only).  Interleaved scans walk the MCU-padded grid MCU by MCU; a scan of one
+    component walks its REAL blocks (ceil(samples / 8) each way) in raster order (T.81 A.2.2).  Returns the file as bytes."""
     ncomp = len(sampling)
     hmax, vmax = max(h for h, _ in sampling), max(v for _, v in sampling)
     mcus_x, mcus_y = -(-width // (8 * hmax)), -(-height // (8 * vmax))
@@ -193,15 +194,20 @@ def write_progressive(width, height, sampling, coefficients, qtables, script):
         bw = _Bits()
         if entry[0] == "dc":
             comps = list(entry[1])
+            ah, al = (entry[2], entry[3]) if len(entry) > 2 else (0, 0)
             out += b"\xff\xda" + (6 + 2 * len(comps)).to_bytes(2, "big") + bytes([len(comps)])
             for c in comps:
                 out += bytes([c + 1, 0x00 if c == 0 else 0x10])
-            out += b"\x00\x00\x00"
+            out += bytes([0, 0, (ah << 4) | al])
             pred = {c: 0 for c in comps}
 
             def dc(c, blk):
-                diff = int(blk[0]) - pred[c]
-                pred[c] = int(blk[0])
+                if ah:  # refinement: the next bit of the value (jcphuff.c encode_mcu_DC_refine)
+                    bw.put((int(blk[0]) >> al) & 1, 1)
+                    return
+                v = int(blk[0]) >> al  # arithmetic shift (encode_mcu_DC_first)
+                diff = v - pred[c]
+                pred[c] = v
                 nb, bits = _magnitude(diff)
                 assert nb <= 11
                 bw.put(*dc_codes[c][nb])
@@ -223,29 +229,59 @@ def write_progressive(width, height, sampling, coefficients, qtables, script):
                                 for bx in range(h):
                                     dc(c, coefficients[c][my * v + by][mx * h + bx])
         else:
-            _, c, ss, se = entry
+            c, ss, se = entry[1], entry[2], entry[3]
+            ah, al = (entry[4], entry[5]) if len(entry) > 4 else (0, 0)
             assert 1 <= ss <= se <= 63
-            out += b"\xff\xda" + (8).to_bytes(2, "big") + bytes([1, c + 1, 0x00 if c == 0 else 0x11, ss, se, 0x00])
+            out += b"\xff\xda" + (8).to_bytes(2, "big") + bytes([1, c + 1, 0x00 if c == 0 else 0x11, ss, se, (ah << 4) | al])
             nbx, nby = real_blocks(c)
             for y in range(nby):
                 for x in range(nbx):
                     blk = coefficients[c][y][x]
-                    run = 0
-                    for k in range(ss, se + 1):
-                        val = int(blk[ZIGZAG[k]])
-                        if val == 0:
-                            run += 1
-                            continue
-                        while run > 15:
-                            bw.put(*ac_codes[c][0xF0])
-                            run -= 16
-                        nb, bits = _magnitude(val)
-                        assert nb <= 10
-                        bw.put(*ac_codes[c][(run << 4) | nb])
-                        bw.put(bits, nb)
+                    if ah == 0:  # first pass of the band (encode_mcu_AC_first): the values shifted down by al, magnitude first
                         run = 0
-                    if run:
-                        bw.put(*ac_codes[c][0x00])  # end of band, a run of one block
+                        for k in range(ss, se + 1):
+                            val = int(blk[ZIGZAG[k]])
+                            mag = abs(val) >> al
+                            if mag == 0:
+                                run += 1
+                                continue
+                            while run > 15:
+                                bw.put(*ac_codes[c][0xF0])
+                                run -= 16
+                            nb, bits = _magnitude(mag if val > 0 else -mag)
+                            assert nb <= 10
+                            bw.put(*ac_codes[c][(run << 4) | nb])
+                            bw.put(bits, nb)
+                            run = 0
+                        if run:
+                            bw.put(*ac_codes[c][0x00])  # end of band, a run of one block
+                    else:  # refinement (encode_mcu_AC_refine)
+                        mags = {k: abs(int(blk[ZIGZAG[k]])) >> al for k in range(ss, se + 1)}
+                        eob = max([k for k in mags if mags[k] == 1], default=0)  # the last coefficient that becomes non-zero in this pass
+                        run, pending = 0, []
+                        for k in range(ss, se + 1):
+                            mag = mags[k]
+                            if mag == 0:
+                                run += 1
+                                continue
+                            while run > 15 and k <= eob:  # (not if the zeros can be folded into the end of band)
+                                bw.put(*ac_codes[c][0xF0])
+                                run -= 16
+                                for b in pending:
+                                    bw.put(b, 1)
+                                pending = []
+                            if mag > 1:  # non-zero before: its next bit, after the next symbol
+                                pending.append(mag & 1)
+                                continue
+                            bw.put(*ac_codes[c][(run << 4) | 1])
+                            bw.put(0 if int(blk[ZIGZAG[k]]) < 0 else 1, 1)
+                            for b in pending:
+                                bw.put(b, 1)
+                            pending, run = [], 0
+                        if run > 0 or pending:
+                            bw.put(*ac_codes[c][0x00])
+                            for b in pending:
+                                bw.put(b, 1)
         bw.flush()
         out += bw.out
     out += b"\xff\xd9"

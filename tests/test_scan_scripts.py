@@ -1,6 +1,6 @@
 """Progressive files with scan scripts libjpeg's default script does not produce -- DC scans of a single component of a colour picture, DC
 scans of some of the components, AC bands cut anywhere -- written from chosen coefficients by tests/helpers/jpeg_from_coefficients.py
-(spectral selection only).  The oracle's decoder (an independent restatement of jdphuff.c) must give back the coefficients; the host
+(spectral selection, and successive approximation with refinement passes over parts of a band).  The oracle's decoder (an independent restatement of jdphuff.c) must give back the coefficients; the host
 entropy decoder and the host emulation of the GPU walk + replay must agree with it; on the GPU the pixels must be the oracle's."""
 import numpy as np
 import pytest
@@ -20,6 +20,15 @@ SCRIPTS = {
     "dc_pair_then_last": [("dc", [0, 1]), ("dc", [2]), ("ac", 2, 1, 1), ("ac", 2, 2, 63), ("ac", 0, 1, 63), ("ac", 1, 1, 30), ("ac", 1, 31, 63)],
     "dc_reversed": [("dc", [2]), ("dc", [0]), ("dc", [1]), ("ac", 0, 1, 63), ("ac", 1, 1, 63), ("ac", 2, 1, 63)],
 }
+# successive approximation with refinement passes over PARTS of a band, DC refined late, chains of two to five scans per component
+SCRIPTS["refine_parts_of_bands"] = [
+    ("dc", [0, 1, 2], 0, 2), ("ac", 0, 1, 5, 0, 2), ("ac", 0, 6, 63, 0, 2), ("ac", 1, 1, 63, 0, 1), ("ac", 2, 1, 63, 0, 1),
+    ("ac", 0, 1, 5, 2, 1), ("dc", [0, 1, 2], 2, 1), ("ac", 0, 6, 63, 2, 1), ("ac", 0, 1, 20, 1, 0), ("ac", 0, 21, 63, 1, 0),
+    ("ac", 1, 1, 9, 1, 0), ("ac", 1, 10, 63, 1, 0), ("dc", [1], 1, 0), ("dc", [0, 2], 1, 0), ("ac", 2, 1, 63, 1, 0)]
+SCRIPTS["three_bit_planes"] = [
+    ("dc", [0], 0, 0), ("dc", [1, 2], 0, 0), ("ac", 0, 1, 63, 0, 3), ("ac", 1, 1, 63, 0, 3), ("ac", 2, 1, 63, 0, 3),
+    ("ac", 0, 1, 63, 3, 2), ("ac", 0, 1, 63, 2, 1), ("ac", 1, 1, 63, 3, 2), ("ac", 2, 1, 63, 3, 2), ("ac", 0, 1, 63, 1, 0),
+    ("ac", 1, 1, 63, 2, 1), ("ac", 1, 1, 63, 1, 0), ("ac", 2, 1, 63, 2, 1), ("ac", 2, 1, 63, 1, 0)]
 CASES = [(name, samp, w, h) for name in SCRIPTS for samp, w, h in ((S444, 83, 61), (S420, 83, 61), (S422, 50, 37), (S411, 130, 20), (S420, 16, 16))]
 CASES.append(("gray_bands", GRAY, 70, 45))
 SCRIPTS["gray_bands"] = [("dc", [0]), ("ac", 0, 1, 2), ("ac", 0, 3, 20), ("ac", 0, 21, 63)]
